@@ -1,0 +1,315 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE ITSELF (build container only).
+
+The reference (velocyto.py @ /root/reference) ships no tests and no golden vectors
+(SURVEY.md section 4), so the pins for this path are outputs of the reference's own code
+executed here on small seeded inputs:
+
+  * ``velocyto/speedboosted.pyx`` compiled with the reference's flags by
+    ``oracle/build_ref.py`` (-> oracle/_ref/, never committed);
+  * ``velocyto/estimation.py``, ``neighbors.py``, ``diffusion.py``, ``analysis.py`` imported
+    *from /root/reference* (nothing is copied) under a synthetic package object so that the
+    package ``__init__`` (which needs pysam/loompy/numba, absent here) does not run.
+
+Shims applied in THIS process only (reference files untouched), all forced by library
+version drift and listed in SURVEY.md section 8(c):
+  numba      -> identity ``jit`` stub (the jitted loops run as plain Python);
+  loompy/h5py-> empty stub modules (only the ctor / serialization touch them);
+  np.NAN     -> np.nan (removed in numpy 2);
+  np.stack   -> accepts a generator (analysis.py:1561);
+  scipy.sparse matrices -> ``.A`` property (removed in scipy 1.14);
+  scipy.sparse.csr -> old module alias used in type hints (neighbors.py:379,385).
+``VelocytoLoom`` objects are created with ``__new__`` and fed arrays directly (the loom
+constructor needs loompy); Sx/Ux-derived arrays are made C-contiguous before
+``estimate_transition_prob`` (the reference's own F-order trap).
+
+Only numeric inputs/outputs are written; the fixtures are data, not code.
+Usage:  python tests/golden/make_golden.py            (re-creates every fixture)
+"""
+import importlib
+import importlib.machinery
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/velocyto"
+
+
+def load_reference():
+    import scipy.sparse as sp
+    import matplotlib
+    matplotlib.use("Agg")
+    if not hasattr(np, "NAN"):
+        np.NAN = np.nan
+    _stack = np.stack
+
+    def stack(arrays, *a, **k):
+        if isinstance(arrays, types.GeneratorType):
+            arrays = list(arrays)
+        return _stack(arrays, *a, **k)
+    np.stack = stack
+    for cls in (sp.csr_matrix, sp.csc_matrix, sp.coo_matrix, sp.lil_matrix):
+        if not hasattr(cls, "A"):
+            cls.A = property(lambda self: self.toarray())
+    if not hasattr(sp, "csr") or not hasattr(getattr(sp, "csr", None), "csr_matrix"):
+        sp.csr = types.SimpleNamespace(csr_matrix=sp.csr_matrix)
+
+    numba = types.ModuleType("numba")
+
+    def jit(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return lambda f: f
+    numba.jit = jit
+    numba.njit = jit
+    sys.modules["numba"] = numba
+    for name in ("loompy", "h5py"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+
+    pkg = types.ModuleType("velocyto")
+    pkg.__path__ = [REF]
+    sys.modules["velocyto"] = pkg
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from build_ref import build
+    so = build()
+    loader = importlib.machinery.ExtensionFileLoader("velocyto.speedboosted", so)
+    spec = importlib.util.spec_from_loader("velocyto.speedboosted", loader)
+    mod = importlib.util.module_from_spec(spec)
+    loader.exec_module(mod)
+    sys.modules["velocyto.speedboosted"] = mod
+    est = importlib.import_module("velocyto.estimation")
+    nb = importlib.import_module("velocyto.neighbors")
+    dif = importlib.import_module("velocyto.diffusion")
+    ana = importlib.import_module("velocyto.analysis")
+    return est, nb, dif, ana
+
+
+def synth_counts(rng, G, C, n_clusters=4):
+    """Small synthetic spliced/unspliced counts with some structure (uint16 like a loom)."""
+    t = rng.random(C)
+    alpha = rng.lognormal(0, 1, G)
+    gamma = rng.lognormal(-0.5, 0.5, G)
+    on = rng.random(G)
+    u = alpha[:, None] * (t[None, :] > on[:, None] * 0.6) * (1 - np.exp(-3 * np.maximum(t[None, :] - on[:, None] * 0.6, 0)))
+    s = u / gamma[:, None] * (1 - np.exp(-2 * np.maximum(t[None, :] - on[:, None] * 0.6, 0))) + 0.2 * alpha[:, None]
+    size = rng.lognormal(0, 0.3, C)
+    S = rng.poisson(4 * size[None, :] * s).astype(np.uint16)
+    U = rng.poisson(2 * size[None, :] * (u + 0.05)).astype(np.uint16)
+    return S, U, t
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def golden_coldeltacor(est):
+    rng = np.random.default_rng(20180808)
+    G, C, nr = 60, 40, 12
+    e = rng.gamma(2.0, 1.0, (G, C))
+    e[rng.random((G, C)) < 0.3] = 0.0       # exact zero differences between many cells
+    e[:, 7] = e[:, 3]                       # identical cells -> zero-variance column (NaN / zero-rule)
+    d = rng.normal(0, 1, (G, C))
+    ixs = np.stack([rng.choice(C, nr, replace=False) for _ in range(C)])
+    ixs[3, 0] = 7                           # make the identical pair appear
+    ixs[5, 1] = 5                           # a cell listing itself
+    out = dict(e=e, d=d, ixs=ixs)
+    with np.errstate(all="ignore"):
+        out["full_linear"] = est.colDeltaCor(e, d, threads=1)
+        out["partial_linear"] = est.colDeltaCorpartial(e, d, ixs, threads=1)
+        for psc in (1e-10, 1.0):
+            tag = "a" if psc == 1e-10 else "b"
+            out[f"full_sqrt_{tag}"] = est.colDeltaCorSqrt(e, d, threads=1, psc=psc)
+            out[f"partial_sqrt_{tag}"] = est.colDeltaCorSqrtpartial(e, d, ixs, threads=1, psc=psc)
+            out[f"full_log10_{tag}"] = est.colDeltaCorLog10(e, d, threads=1, psc=psc)
+            out[f"partial_log10_{tag}"] = est.colDeltaCorLog10partial(e, d, ixs, threads=1, psc=psc)
+    out["psc_a"] = np.float64(1e-10)
+    out["psc_b"] = np.float64(1.0)
+    save("coldeltacor", **out)
+
+
+def golden_fits(est):
+    rng = np.random.default_rng(20180809)
+    G, C = 24, 90
+    X = rng.gamma(1.5, 1.0, (G, C))
+    gam = rng.lognormal(-0.5, 0.6, G)
+    Y = np.maximum(gam[:, None] * X + 0.15 + rng.normal(0, 0.25, (G, C)), 0)
+    X[0] = 0                                 # all-zero x  -> NaN
+    Y[1] = 0                                 # all-zero y  -> 0
+    Y[2] = 3.0 * X[2] + 2.0                  # y consistently above x (limit_gamma branch)
+    Y[3] = np.maximum(0.05 * X[3] - 0.2, 0)  # pushes gamma/offset to the box edges
+    W = (rng.random((G, C)) < 0.3).astype(float)
+    W[4] = rng.random(C)                     # non-binary weights
+    out = dict(Y=Y, X=X, W=W)
+    out["fit_slope"] = est.fit_slope(Y, X)
+    a, b = est.fit_slope_offset(Y, X)
+    out["offset_m"], out["offset_q"] = a, b
+    a, b = est.fit_slope_offset(Y, X, fixperc_q=True)
+    out["offset_fix_m"], out["offset_fix_q"] = a, b
+    for lg in (False, True):
+        t = "lg" if lg else "nolg"
+        a, r = est.fit_slope_weighted(Y, X, W, return_R2=True, limit_gamma=lg)
+        out[f"weighted_{t}_m"], out[f"weighted_{t}_R2"] = a, r
+        a, b, r = est.fit_slope_weighted_offset(Y, X, W, return_R2=True, limit_gamma=lg)
+        out[f"woffset_{t}_m"], out[f"woffset_{t}_q"], out[f"woffset_{t}_R2"] = a, b, r
+    a, b, r = est.fit_slope_weighted_offset(Y, X, W, fixperc_q=True, return_R2=True)
+    out["woffset_fix_m"], out["woffset_fix_q"], out["woffset_fix_R2"] = a, b, r
+    save("fits", **out)
+
+
+def golden_neighbors(nb):
+    rng = np.random.default_rng(20180810)
+    C, P, G = 220, 8, 30
+    centers = rng.normal(0, 4, (5, P))
+    lab = rng.integers(0, 5, C)
+    space = centers[lab] + rng.normal(0, 1, (C, P))
+    space[11] = space[10]                    # duplicate cell -> zero distance neighbour
+    data = rng.gamma(1.0, 2.0, (G, C))
+    out = dict(space=space, data=data, groups=lab.astype(np.int64))
+    k = 9
+    knn = nb.knn_distance_matrix(space, k=k, mode="distance", n_jobs=1)
+    out["knn_indices"] = knn.indices.reshape(C, k)
+    out["knn_dist"] = knn.data.reshape(C, k)
+    conn = (knn > 0).astype(float)
+    conn.setdiag(3.0)
+    w = nb.connectivity_to_weights(conn).tocsr()
+    w.sort_indices()
+    out["w_indptr"], out["w_indices"], out["w_data"] = w.indptr, w.indices, w.data
+    out["w_diag"] = np.float64(3.0)
+    out["convolved"] = np.ascontiguousarray(nb.convolve_by_sparse_weights(data, w))
+    for tag, constraint in (("bal", None), ("balc", lab.astype(np.int64))):
+        b = nb.BalancedKNN(k=k, sight_k=40, maxl=14, constraint=constraint, mode="distance", n_jobs=1)
+        b.fit(space)
+        g = b.kneighbors_graph(mode="distance")
+        out[f"{tag}_dsi"], out[f"{tag}_dist"] = b.dsi, b.dist      # the sight graph fed to the greedy loop
+        out[f"{tag}_dist_new"], out[f"{tag}_dsi_new"], out[f"{tag}_l"] = b.dist_new, b.dsi_new, b.l
+        out[f"{tag}_graph_data"], out[f"{tag}_graph_indices"] = g.data, g.indices
+    # sight exhaustion -> pad with self (neighbors.py:65-69)
+    d2, i2, l2 = nb.knn_balance(out["bal_dsi"][:, :12], out["bal_dist"][:, :12], maxl=4, k=9)
+    out["pad_dist_new"], out["pad_dsi_new"], out["pad_l"] = d2, i2, l2
+    # (dist=None together with padding crashes in the reference itself - UnboundLocalError at
+    #  neighbors.py:68 - so that combination has no defined behaviour and is not pinned.)
+    d3, i3, l3 = nb.knn_balance(out["bal_dsi"], None, maxl=14, k=9)
+    out["nd_dist_new"], out["nd_dsi_new"], out["nd_l"] = d3, i3, l3
+    save("neighbors", **out)
+
+
+def make_vlm(ana, S, U):
+    vlm = ana.VelocytoLoom.__new__(ana.VelocytoLoom)
+    vlm.S = S.astype(np.float64)
+    vlm.U = U.astype(np.float64)
+    vlm.A = np.zeros_like(vlm.S)
+    vlm.ca = {"CellID": np.arange(S.shape[1])}
+    vlm.ra = {"Gene": np.arange(S.shape[0])}
+    vlm.initial_cell_size = vlm.S.sum(0)
+    vlm.initial_Ucell_size = vlm.U.sum(0)
+    return vlm
+
+
+def golden_pipeline(ana, dif):
+    rng = np.random.default_rng(20180811)
+    G, C = 90, 160
+    S, U, t = synth_counts(rng, G, C)
+    keep = (S.sum(1) > 0) & (U.sum(1) > 0)
+    S, U = S[keep], U[keep]
+    out = dict(S=S, U=U)
+    vlm = make_vlm(ana, S, U)
+    vlm.normalize("both", size=True, log=True)
+    out["S_sz"], out["U_sz"], out["S_norm"] = vlm.S_sz, vlm.U_sz, vlm.S_norm
+    # pcs are an INPUT of the path (perform_PCA is out of scope): top singular vectors of centred S_norm
+    Xc = vlm.S_norm.T - vlm.S_norm.T.mean(0)
+    Uu, ss, _ = np.linalg.svd(Xc, full_matrices=False)
+    vlm.pcs = Uu[:, :12] * ss[:12]
+    vlm.ts = vlm.pcs[:, :2].copy()
+    out["pcs"], out["ts"] = vlm.pcs, vlm.ts
+
+    # balanced variant first (kept separately), then the default unbalanced graph used downstream
+    vlm.knn_imputation(k=12, n_pca_dims=10, balanced=True, b_sight=48, b_maxl=20, n_jobs=1)
+    out["bal_Sx"], out["bal_Ux"] = np.ascontiguousarray(vlm.Sx), np.ascontiguousarray(vlm.Ux)
+    out["bal_knn_indices"], out["bal_knn_data"] = vlm.knn.indices, vlm.knn.data
+    vlm.knn_imputation(k=12, n_pca_dims=10, diag=2.0, maximum=True, n_jobs=1)
+    out["max_Sx"], out["max_Ux"] = np.ascontiguousarray(vlm.Sx), np.ascontiguousarray(vlm.Ux)
+    vlm.knn_imputation(k=12, n_pca_dims=10, n_jobs=1)
+    out["knn_indices"] = vlm.knn.indices.reshape(C, 12)
+    out["knn_dist"] = vlm.knn.data.reshape(C, 12)
+    out["Sx"], out["Ux"] = np.ascontiguousarray(vlm.Sx), np.ascontiguousarray(vlm.Ux)
+
+    # plain fit (fit_slope) and the default weighted-offset fit
+    vlm.fit_gammas(fit_offset=False, weighted=False)
+    out["gammas_plain"] = vlm.gammas.copy()
+    for wname in ("maxmin", "maxmin_double", "sum", "prod", "maxmin_weighted"):
+        vlm.fit_gammas(weights=wname)
+        out[f"gammas_{wname}"], out[f"q_{wname}"], out[f"R2_{wname}"] = vlm.gammas.copy(), vlm.q.copy(), vlm.R2.copy()
+    vlm.fit_gammas(limit_gamma=True)
+    out["gammas_lg"], out["q_lg"], out["R2_lg"] = vlm.gammas.copy(), vlm.q.copy(), vlm.R2.copy()
+    vlm.fit_gammas(fit_offset=False, weighted=True)
+    out["gammas_w"], out["R2_w"] = vlm.gammas.copy(), vlm.R2.copy()
+    vlm.fit_gammas()
+    out["gammas"], out["q"], out["R2"] = vlm.gammas.copy(), vlm.q.copy(), vlm.R2.copy()
+
+    vlm.predict_U()
+    vlm.calculate_velocity()
+    vlm.calculate_shift(assumption="constant_unspliced", delta_t=0.7)
+    out["delta_S_cu"] = np.ascontiguousarray(vlm.delta_S)
+    vlm.calculate_shift(assumption="constant_velocity")
+    vlm.extrapolate_cell_at_t(delta_t=1.0)
+    out["Upred"], out["velocity"] = np.ascontiguousarray(vlm.Upred), np.ascontiguousarray(vlm.velocity)
+    out["delta_S"], out["Sx_sz_t"] = np.ascontiguousarray(vlm.delta_S), np.ascontiguousarray(vlm.Sx_sz_t)
+
+    for name in ("Sx", "Ux", "Sx_sz", "Ux_sz", "delta_S", "Sx_sz_t"):   # F-order trap
+        setattr(vlm, name, np.ascontiguousarray(getattr(vlm, name)))
+
+    with np.errstate(all="ignore"):
+        for transform in ("sqrt", "log", "linear", "logratio"):
+            vlm.estimate_transition_prob(hidim="Sx_sz", embed="ts", transform=transform, n_neighbors=40,
+                                         knn_random=True, sampled_fraction=0.5, calculate_randomized=False, threads=1)
+            out[f"corrcoef_{transform}"] = vlm.corrcoef.copy()
+            if transform == "sqrt":
+                out["sampling_ixs"] = vlm.sampling_ixs.copy()
+                out["neigh_ixs"] = vlm.embedding_knn.indices.reshape(C, -1).copy()
+        for transform in ("sqrt", "log", "linear"):
+            vlm.estimate_transition_prob(hidim="Sx_sz", embed="ts", transform=transform, n_neighbors=40,
+                                         knn_random=False, calculate_randomized=False, threads=1)
+            out[f"corrcoef_full_{transform}"] = vlm.corrcoef.copy()
+            if transform == "sqrt":
+                out["full_knn_indices"] = vlm.embedding_knn.indices.reshape(C, -1).copy()
+                vlm.calculate_embedding_shift(sigma_corr=0.05)
+                out["full_transition_prob"] = vlm.transition_prob.copy()
+                out["full_delta_embedding"] = vlm.delta_embedding.copy()
+                out["full_scaling"] = vlm.scaling.copy()
+        # the default path once more, then downstream stages E/F
+        vlm.estimate_transition_prob(hidim="Sx_sz", embed="ts", transform="sqrt", n_neighbors=40,
+                                     knn_random=True, sampled_fraction=0.5, calculate_randomized=False, threads=1)
+        assert np.array_equal(vlm.corrcoef, out["corrcoef_sqrt"], equal_nan=True)
+        vlm.calculate_embedding_shift(sigma_corr=0.05)
+        out["transition_prob"] = vlm.transition_prob.copy()
+        out["delta_embedding"] = vlm.delta_embedding.copy()
+        out["scaling"] = vlm.scaling.copy()
+        vlm.calculate_embedding_shift(sigma_corr=0.1, expression_scaling=False)
+        out["delta_embedding_noscale"] = vlm.delta_embedding.copy()
+        vlm.calculate_embedding_shift(sigma_corr=0.05)
+        for direction in ("forward", "backwards"):
+            vlm.prepare_markov(sigma_D=2.0, sigma_W=4.0, direction=direction)
+            out[f"tr_{direction}"] = vlm.tr.toarray()
+            vlm.run_markov(n_steps=50)
+            out[f"diffused_{direction}"] = np.asarray(vlm.diffused).ravel()
+    p0 = rng.random(C)
+    d = dif.Diffusion()
+    out["diffuse_p0"] = p0
+    out["diffuse_path_integral"] = np.asarray(d.diffuse(p0, vlm.tr, n_steps=7, mode="path_integral")).ravel()
+    out["diffuse_time_evolution"] = np.asarray(d.diffuse(p0, vlm.tr, n_steps=7, mode="time_evolution")).ravel()
+    save("pipeline", **out)
+
+
+if __name__ == "__main__":
+    est, nb, dif, ana = load_reference()
+    golden_coldeltacor(est)
+    golden_fits(est)
+    golden_neighbors(nb)
+    golden_pipeline(ana, dif)

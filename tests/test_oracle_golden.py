@@ -1,0 +1,262 @@
+"""Pin the CPU oracle (oracle/) against the committed outputs of the reference itself.
+
+tests/golden/*.npz were produced by tests/golden/make_golden.py, which runs the reference's
+own code (Cython kernels built with its flags + its Python modules imported from
+/root/reference).  These tests need neither the reference nor a GPU.
+
+Tolerances: the reference kernels are compiled with -ffast-math (reassociation), the oracle
+with strict IEEE -> correlations agree to ~1e-13 absolute; integer outputs are bit-exact.
+"""
+import numpy as np
+import pytest
+from scipy import sparse
+
+
+def nan_equal_close(a, b, atol, rtol=0.0):
+    assert a.shape == b.shape
+    na, nb = np.isnan(a), np.isnan(b)
+    assert np.array_equal(na, nb), f"NaN pattern differs: {na.sum()} vs {nb.sum()}"
+    np.testing.assert_allclose(a[~na], b[~nb], atol=atol, rtol=rtol)
+
+
+# ----------------------------------------------------------------------------- correlations
+@pytest.mark.parametrize("key,transform,psc_key", [
+    ("full_linear", "linear", None), ("full_sqrt_a", "sqrt", "psc_a"), ("full_sqrt_b", "sqrt", "psc_b"),
+    ("full_log10_a", "log10", "psc_a"), ("full_log10_b", "log10", "psc_b")])
+def test_coldeltacor_full(oracle, golden, key, transform, psc_key):
+    g = golden("coldeltacor")
+    psc = float(g[psc_key]) if psc_key else 0.0
+    got = oracle.coldeltacor(g["e"], g["d"], transform, psc)
+    ref = g[key]
+    # zero-variance columns (the diagonal, duplicate cells): the reference yields NaN or, when the
+    # centred values are only rounding noise, garbage - compare only where the reference is clean.
+    C = ref.shape[0]
+    degenerate = np.zeros((C, C), bool)
+    degenerate[np.arange(C), np.arange(C)] = True
+    degenerate[3, 7] = degenerate[7, 3] = True
+    np.testing.assert_allclose(got[~degenerate], ref[~degenerate], atol=1e-12)
+
+
+@pytest.mark.parametrize("key,transform,psc_key", [
+    ("partial_linear", "linear", None), ("partial_sqrt_a", "sqrt", "psc_a"), ("partial_sqrt_b", "sqrt", "psc_b"),
+    ("partial_log10_a", "log10", "psc_a"), ("partial_log10_b", "log10", "psc_b")])
+def test_coldeltacor_partial(oracle, golden, key, transform, psc_key):
+    g = golden("coldeltacor")
+    psc = float(g[psc_key]) if psc_key else 0.0
+    got = oracle.coldeltacor_partial(g["e"], g["d"], g["ixs"], transform, psc)
+    ref = g[key]
+    degenerate = np.zeros(ref.shape, bool)
+    degenerate[3, 7] = degenerate[5, 5] = True
+    if transform == "sqrt" or transform == "linear":
+        # identical cells give exactly 0 differences -> exact NaN in both (0 * inf)
+        assert np.isnan(ref[3, 7]) and np.isnan(got[3, 7])
+        assert np.isnan(ref[5, 5]) and np.isnan(got[5, 5])
+    np.testing.assert_allclose(got[~degenerate], ref[~degenerate], atol=1e-12)
+    # compact form is the same numbers, gathered
+    comp = oracle.coldeltacor_partial_compact(g["e"], g["d"], g["ixs"], transform, psc)
+    rows = np.arange(ref.shape[0])[:, None]
+    ok = ~degenerate[rows, g["ixs"]]
+    np.testing.assert_allclose(comp[ok], ref[rows, g["ixs"]][ok], atol=1e-12)
+
+
+# ----------------------------------------------------------------------------- fits
+def test_fit_slope(oracle, golden):
+    g = golden("fits")
+    got = oracle.fit_slope(g["Y"], g["X"])
+    assert got.dtype == np.float32
+    nan_equal_close(got, g["fit_slope"], atol=0, rtol=2e-7)
+    assert np.isnan(got[0]) and got[1] == 0
+
+
+def test_fit_slope_offset(oracle, golden):
+    g = golden("fits")
+    for exact in (False, True):
+        m, q = oracle.fit_slope_offset(g["Y"], g["X"], exact=exact)
+        nan_equal_close(m, g["offset_m"], atol=1e-5, rtol=1e-5)
+        nan_equal_close(q, g["offset_q"], atol=1e-5, rtol=1e-5)
+        m, q = oracle.fit_slope_offset(g["Y"], g["X"], fixperc_q=True, exact=exact)
+        nan_equal_close(m, g["offset_fix_m"], atol=2e-5, rtol=1e-4)
+        nan_equal_close(q, g["offset_fix_q"], atol=0, rtol=1e-6)
+
+
+@pytest.mark.parametrize("lg", [False, True])
+def test_fit_slope_weighted(oracle, golden, lg):
+    g = golden("fits")
+    t = "lg" if lg else "nolg"
+    m, r2 = oracle.fit_slope_weighted(g["Y"], g["X"], g["W"], limit_gamma=lg)
+    nan_equal_close(m, g[f"weighted_{t}_m"], atol=0, rtol=1e-6)      # same scipy call -> same floats
+    nan_equal_close(r2, g[f"weighted_{t}_R2"], atol=1e-6, rtol=1e-5)
+    m, r2 = oracle.fit_slope_weighted(g["Y"], g["X"], g["W"], limit_gamma=lg, exact=True)
+    nan_equal_close(m, g[f"weighted_{t}_m"], atol=2e-5, rtol=1e-4)   # Brent's xatol=1e-5
+
+
+@pytest.mark.parametrize("lg", [False, True])
+def test_fit_slope_weighted_offset(oracle, golden, lg):
+    g = golden("fits")
+    t = "lg" if lg else "nolg"
+    m, q, r2 = oracle.fit_slope_weighted_offset(g["Y"], g["X"], g["W"], limit_gamma=lg)
+    nan_equal_close(m, g[f"woffset_{t}_m"], atol=0, rtol=1e-6)
+    nan_equal_close(q, g[f"woffset_{t}_q"], atol=1e-7, rtol=1e-6)
+    nan_equal_close(r2, g[f"woffset_{t}_R2"], atol=1e-6, rtol=1e-5)
+    # exact box-constrained solution vs where L-BFGS-B stops: objective no worse, parameters close
+    me, qe, _ = oracle.fit_slope_weighted_offset(g["Y"], g["X"], g["W"], limit_gamma=lg, exact=True)
+    Y, X, W = g["Y"], g["X"], g["W"]
+    for i in range(2, Y.shape[0]):
+        f = lambda m_, q_: np.sum(W[i] * (-Y[i] + X[i] * m_ + q_) ** 2)
+        assert f(float(me[i]), float(qe[i])) <= f(float(m[i]), float(q[i])) * (1 + 1e-5) + 1e-9
+    nan_equal_close(me, g[f"woffset_{t}_m"], atol=2e-3, rtol=2e-3)
+    nan_equal_close(qe, g[f"woffset_{t}_q"], atol=2e-3, rtol=2e-3)
+
+
+def test_fit_slope_weighted_offset_fixperc(oracle, golden):
+    g = golden("fits")
+    m, q, r2 = oracle.fit_slope_weighted_offset(g["Y"], g["X"], g["W"], fixperc_q=True)
+    nan_equal_close(m, g["woffset_fix_m"], atol=0, rtol=1e-6)
+    nan_equal_close(q, g["woffset_fix_q"], atol=0, rtol=1e-6)
+    m, q, _ = oracle.fit_slope_weighted_offset(g["Y"], g["X"], g["W"], fixperc_q=True, exact=True)
+    nan_equal_close(m, g["woffset_fix_m"], atol=2e-5, rtol=1e-4)
+
+
+# ----------------------------------------------------------------------------- neighbours
+def test_knn_search(oracle, golden):
+    g = golden("neighbors")
+    dist, idx = oracle.knn_search(g["space"], 9)
+    assert np.all(np.diff(dist, axis=1) >= 0)          # nearest first
+    # the golden graph was captured after `(knn > 0)` (analysis.py:1006), which sorts the CSR
+    # column indices in place (scipy side effect) -> compare in column order
+    o = np.argsort(idx, axis=1)
+    idx_s, dist_s = np.take_along_axis(idx, o, 1), np.take_along_axis(dist, o, 1)
+    # neighbour identity can only differ on exact distance ties (the duplicated cell 10/11)
+    diff = idx_s != g["knn_indices"]
+    assert diff.sum() <= 4
+    np.testing.assert_allclose(dist_s[~diff], g["knn_dist"][~diff], atol=1e-9)
+
+
+def test_weights_and_convolve(oracle, golden):
+    g = golden("neighbors")
+    C = g["space"].shape[0]
+    knn = sparse.csr_matrix((g["knn_dist"].ravel(), g["knn_indices"].ravel(), np.arange(0, C * 9 + 1, 9)), shape=(C, C))
+    w = oracle.connectivity_to_weights(knn, diag=float(g["w_diag"]))
+    w.sort_indices()
+    wref = sparse.csr_matrix((g["w_data"], g["w_indices"], g["w_indptr"]), shape=(C, C))
+    assert abs(w - wref).max() < 1e-15
+    out = oracle.convolve_by_sparse_weights(g["data"], wref)
+    np.testing.assert_allclose(out, g["convolved"], rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("tag", ["bal", "balc"])
+def test_balanced_knn(oracle, golden, tag):
+    g = golden("neighbors")
+    constraint = g["groups"] if tag == "balc" else None
+    dist_new, dsi_new, l = oracle.knn_balance(g[f"{tag}_dsi"], g[f"{tag}_dist"], maxl=14, k=9, constraint=constraint)
+    assert np.array_equal(dsi_new, g[f"{tag}_dsi_new"])
+    assert np.array_equal(l, g[f"{tag}_l"])
+    assert np.array_equal(dist_new, g[f"{tag}_dist_new"])
+    # and the sight graph itself from the oracle's own exact kNN
+    d, i = oracle.knn_search(g["space"], 41, include_self=True)
+    np.testing.assert_allclose(d, g[f"{tag}_dist"], atol=1e-9)
+
+
+def test_balanced_knn_padding_and_nodist(oracle, golden):
+    g = golden("neighbors")
+    d, i, l = oracle.knn_balance(g["bal_dsi"][:, :12], g["bal_dist"][:, :12], maxl=4, k=9)
+    assert np.array_equal(i, g["pad_dsi_new"]) and np.array_equal(l, g["pad_l"]) and np.array_equal(d, g["pad_dist_new"])
+    assert (i == np.arange(i.shape[0])[:, None])[:, 1:].any(), "fixture must exercise pad-with-self"
+    d, i, l = oracle.knn_balance(g["bal_dsi"], None, maxl=14, k=9)
+    assert np.array_equal(i, g["nd_dsi_new"]) and np.array_equal(l, g["nd_l"]) and np.array_equal(d, g["nd_dist_new"])
+
+
+# ----------------------------------------------------------------------------- pipeline
+def test_pipeline_normalize_and_impute(oracle, golden):
+    g = golden("pipeline")
+    S, U = g["S"].astype(float), g["U"].astype(float)
+    S_sz, _ = oracle.normalize_size(S)
+    U_sz, _ = oracle.normalize_size(U, fix_nonfinite=True)
+    np.testing.assert_allclose(S_sz, g["S_sz"], rtol=1e-14)
+    np.testing.assert_allclose(U_sz, g["U_sz"], rtol=1e-14)
+    space = g["pcs"][:, :10]
+    knn, w, Sx, Ux = oracle.knn_imputation(S_sz, U_sz, space, k=12)
+    knn.sort_indices()                                   # see test_knn_search: golden is column-sorted
+    np.testing.assert_allclose(knn.data.reshape(-1, 12), g["knn_dist"], atol=1e-9)
+    assert (knn.indices.reshape(-1, 12) != g["knn_indices"]).sum() == 0
+    np.testing.assert_allclose(Sx, g["Sx"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(Ux, g["Ux"], rtol=1e-12, atol=1e-12)
+    _, _, Sx, Ux = oracle.knn_imputation(S_sz, U_sz, space, k=12, diag=2.0, maximum=True)
+    np.testing.assert_allclose(Sx, g["max_Sx"], rtol=1e-12, atol=1e-12)
+    _, _, Sx, Ux = oracle.knn_imputation(S_sz, U_sz, space, k=12, balanced=True, b_sight=48, b_maxl=20)
+    np.testing.assert_allclose(Sx, g["bal_Sx"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(Ux, g["bal_Ux"], rtol=1e-12, atol=1e-12)
+
+
+def test_pipeline_fit_gammas(oracle, golden):
+    g = golden("pipeline")
+    Sx, Ux = g["Sx"], g["Ux"]
+    gm, q, r2 = oracle.fit_gammas(Sx, Ux, Sx, Ux, fit_offset=False, weighted=False)
+    nan_equal_close(gm, g["gammas_plain"], atol=0, rtol=2e-7)
+    gm, q, r2 = oracle.fit_gammas(Sx, Ux, Sx, Ux)
+    nan_equal_close(gm, g["gammas"], atol=0, rtol=1e-6)
+    nan_equal_close(q, g["q"], atol=1e-7, rtol=1e-6)
+    nan_equal_close(r2, g["R2"], atol=1e-6, rtol=1e-5)
+    for wname in ("maxmin", "maxmin_double", "sum", "prod", "maxmin_weighted"):
+        gm, q, r2 = oracle.fit_gammas(Sx, Ux, Sx, Ux, weights=wname)
+        nan_equal_close(gm, g[f"gammas_{wname}"], atol=0, rtol=1e-6)
+        nan_equal_close(q, g[f"q_{wname}"], atol=1e-7, rtol=1e-6)
+    gm, q, r2 = oracle.fit_gammas(Sx, Ux, Sx, Ux, limit_gamma=True)
+    nan_equal_close(gm, g["gammas_lg"], atol=0, rtol=1e-6)
+    gm, q, r2 = oracle.fit_gammas(Sx, Ux, Sx, Ux, fit_offset=False, weighted=True)
+    nan_equal_close(gm, g["gammas_w"], atol=0, rtol=1e-6)
+    nan_equal_close(r2, g["R2_w"], atol=1e-6, rtol=1e-5)
+    # exact solver vs the reference's L-BFGS-B stopping point (rtol 1e-4, <=1% outliers)
+    gm, q, r2 = oracle.fit_gammas(Sx, Ux, Sx, Ux, exact=True)
+    rel = np.abs(gm - g["gammas"]) / np.maximum(np.abs(g["gammas"]), 1e-3)
+    assert np.mean(rel > 1e-4) <= 0.05 and rel.max() < 2e-2, (np.mean(rel > 1e-4), rel.max())
+
+
+def test_pipeline_velocity(oracle, golden):
+    g = golden("pipeline")
+    Upred, vel, dS, Sxt = oracle.velocity_chain(g["Sx"], g["Ux"], g["gammas"], g["q"])
+    for a, k in ((Upred, "Upred"), (vel, "velocity"), (dS, "delta_S"), (Sxt, "Sx_sz_t")):
+        np.testing.assert_allclose(a, g[k], rtol=1e-14, atol=1e-14)
+    _, _, dS, _ = oracle.velocity_chain(g["Sx"], g["Ux"], g["gammas"], g["q"], delta_t_shift=0.7, assumption="constant_unspliced")
+    nan_equal_close(dS, g["delta_S_cu"], atol=1e-12, rtol=1e-12)
+
+
+@pytest.mark.parametrize("transform", ["sqrt", "log", "linear", "logratio"])
+def test_pipeline_transition_knn_random(oracle, golden, transform):
+    g = golden("pipeline")
+    with np.errstate(all="ignore"):
+        cc, neigh = oracle.estimate_transition_prob(g["Sx"], g["delta_S"], g["ts"], transform=transform,
+                                                    n_neighbors=40, sampled_fraction=0.5)
+    assert np.array_equal(neigh, g["neigh_ixs"])           # same numpy RNG stream, same kNN
+    np.testing.assert_allclose(cc, g[f"corrcoef_{transform}"], atol=1e-11)
+
+
+@pytest.mark.parametrize("transform", ["sqrt", "log", "linear"])
+def test_pipeline_transition_full(oracle, golden, transform):
+    g = golden("pipeline")
+    with np.errstate(all="ignore"):
+        cc, knn_ixs = oracle.estimate_transition_prob(g["Sx"], g["delta_S"], g["ts"], transform=transform,
+                                                      n_neighbors=40, knn_random=False)
+    nan_equal_close(cc, g[f"corrcoef_full_{transform}"], atol=1e-11)
+    assert np.array_equal(np.sort(knn_ixs, 1), np.sort(g["full_knn_indices"], 1))
+
+
+def test_pipeline_embedding_shift_and_markov(oracle, golden):
+    g = golden("pipeline")
+    tp, de, sc = oracle.calculate_embedding_shift(g["corrcoef_sqrt"], g["neigh_ixs"], g["ts"], g["Sx"], g["delta_S"], 0.05)
+    np.testing.assert_allclose(tp, g["transition_prob"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(de, g["delta_embedding"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(sc, g["scaling"], rtol=1e-9, atol=1e-12)
+    _, de, _ = oracle.calculate_embedding_shift(g["corrcoef_sqrt"], g["neigh_ixs"], g["ts"], sigma_corr=0.1, expression_scaling=False)
+    np.testing.assert_allclose(de, g["delta_embedding_noscale"], rtol=1e-9, atol=1e-12)
+    with np.errstate(all="ignore"):
+        tpf, def_, scf = oracle.calculate_embedding_shift(g["corrcoef_full_sqrt"], g["full_knn_indices"], g["ts"], g["Sx"], g["delta_S"], 0.05)
+    nan_equal_close(tpf, g["full_transition_prob"], atol=1e-15, rtol=1e-12)
+    for direction in ("forward", "backwards"):
+        tr = oracle.prepare_markov(tp, g["ts"], 2.0, 4.0, direction)
+        np.testing.assert_allclose(tr, g[f"tr_{direction}"], rtol=1e-12, atol=1e-18)
+        p0 = np.ones(tr.shape[0]) / tr.shape[0]
+        np.testing.assert_allclose(oracle.diffuse(p0, tr, 50, "time_evolution").ravel(), g[f"diffused_{direction}"], rtol=1e-10)
+    tr = g["tr_backwards"]
+    np.testing.assert_allclose(oracle.diffuse(g["diffuse_p0"], tr, 7, "path_integral").ravel(), g["diffuse_path_integral"], rtol=1e-10)
+    np.testing.assert_allclose(oracle.diffuse(g["diffuse_p0"], tr, 7, "time_evolution").ravel(), g["diffuse_time_evolution"], rtol=1e-10)
