@@ -1,0 +1,185 @@
+/*
+ * velocyto_hip.h -- C ABI of libvelocyto_hip.so, the MI355X (gfx950) implementation of the
+ * velocyto.py post-counting analysis hot path.
+ *
+ * The reference has no FFI for this path: its "operator API" is a set of Python call
+ * surfaces.  Each entry point below names the reference interface it
+ * stands behind (paths relative to /root/reference/velocyto/).  A maintainer binds them
+ * with ctypes exactly as velocyto.py_amd/_lib.py does; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 (VCY_OK) or a negative status; vcy_last_error() returns a
+ *     thread-local message for the last failure.
+ *   - all array arguments are DEVICE pointers unless the name ends in `_host`.
+ *   - matrices are CELLS-MAJOR: shape (C cells, G genes), row-major with leading dimension
+ *     `ld` (elements, >= G, multiple of 4 for f32 / 2 for f64 so rows stay 16-byte aligned).
+ *     This is the reference's Fortran-ordered (G,C) array (what convolve_by_sparse_weights
+ *     returns) -- one cell's gene vector is one contiguous stream.
+ *   - `dtype` selects the storage/compute type of the matrices: VCY_F32 (production) or
+ *     VCY_F64 (reference precision; used by the parity tests).
+ *   - asynchronous on `stream` (a hipStream_t), no hidden synchronisation, no allocation:
+ *     outputs and workspaces are caller-provided (vcy_*_workspace_bytes report sizes).
+ *   - the caller owns every buffer; inputs are never written.
+ */
+#ifndef VELOCYTO_HIP_H
+#define VELOCYTO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VCY_OK 0
+#define VCY_ERR_INVALID (-1)      /* bad argument (shape, alignment, enum)          */
+#define VCY_ERR_HIP (-2)          /* HIP runtime error (launch failure, no device)  */
+#define VCY_ERR_UNSUPPORTED (-3)  /* valid request outside what the kernels cover   */
+
+typedef enum { VCY_F32 = 0, VCY_F64 = 1 } vcy_dtype;
+
+/* Element transform f of the six reference kernels (speedboosted.pyx). */
+typedef enum { VCY_LINEAR = 0, VCY_SQRT = 1, VCY_LOG10 = 2 } vcy_transform;
+
+/* Which family's branch rules apply at t == 0 (speedboosted.pyx:110-114,195-199 vs
+ * :372-378,469-473). */
+typedef enum { VCY_RULES_FULL = 0, VCY_RULES_PARTIAL = 1 } vcy_rules;
+
+typedef void *vcy_stream;  /* hipStream_t */
+
+const char *vcy_last_error(void);
+int vcy_abi_version(void);
+/* Number of CUs / LDS bytes per workgroup of the current device (host query). */
+int vcy_device_info(int *cu_count, int *lds_bytes_per_block, int64_t *hbm_bytes);
+
+/* ---------------------------------------------------------------- layout plumbing
+ * (G,C) genes-major  <->  (C,ld) cells-major tiled transpose with optional dtype change.
+ * Replaces the implicit layout of the reference's numpy arrays (analysis.py:59-61).
+ * src is (rows, cols) row-major with leading dim ld_src; dst is (cols, rows) with ld_dst.
+ * Padding columns of dst (rows <= j < ld_dst) are zero-filled.                          */
+int vcy_transpose(const void *src, void *dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst,
+                  int src_dtype, int dst_dtype, vcy_stream stream);
+
+/* ---------------------------------------------------------------- stage D: correlations
+ * speedboosted._colDeltaCorpartial / _colDeltaCorSqrtpartial / _colDeltaCorLog10partial
+ * (speedboosted.pyx:263-538, 574-610; wrappers estimation.py:36-62, 90-116, 144-170).
+ * For every cell c and every listed neighbour i = ixs[c,n]:
+ *     out[c,n] = pearson_g( f(e[i,g] - e[c,g]), d[c,g] )
+ * e, d: (C, ld) cells-major.  ixs: (C_out, nrndm) int32 rows for cells cell0..cell0+C_out-1.
+ * out : (C_out, nrndm) of `dtype` -- the COMPACT form of the reference's dense (C,C) `rm`
+ * (use vcy_scatter_rows to materialise rm[c, ixs[c,n]] += out[c,n]).
+ * Zero-variance columns give NaN exactly like the reference (0 * inf).
+ * `order` (optional, may be NULL): permutation of 0..C_out-1 giving the order in which
+ * cells are scheduled (locality-sorted orders raise Infinity-Cache reuse of shared
+ * neighbours); results do not depend on it.
+ * `rules` = VCY_RULES_PARTIAL reproduces the *partial kernels, VCY_RULES_FULL the branch
+ * rules of the full kernels on an explicit neighbour list.                                */
+int vcy_coldeltacor_partial(const void *e, const void *d, const int32_t *ixs, void *out, const int32_t *order,
+                            int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int64_t nrndm,
+                            int transform, int rules, double psc, int dtype, vcy_stream stream);
+
+/* speedboosted._colDeltaCor / _colDeltaCorSqrt / _colDeltaCorLog10 (speedboosted.pyx:13-257,
+ * 542-572; wrappers estimation.py:11-33, 65-87, 119-141): all pairs.
+ * rm is the dense (C_out, ld_rm) row block for cells cell0..cell0+C_out-1, columns 0..C-1;
+ * accumulate != 0 reproduces the reference's `rm[c,i] += ...`, 0 overwrites.             */
+int vcy_coldeltacor_full(const void *e, const void *d, void *rm, int64_t C, int64_t G, int64_t ld,
+                         int64_t cell0, int64_t C_out, int64_t ld_rm, int transform, double psc,
+                         int accumulate, int dtype, vcy_stream stream);
+
+/* rm[c, ixs[c,n]] += vals[c,n] (atomic: duplicate neighbours accumulate like the reference's
+ * scatter at speedboosted.pyx:332-336).  rm: (C_out, ld_rm) of `dtype`.                    */
+int vcy_scatter_rows(const void *vals, const int32_t *ixs, void *rm, int64_t C_out, int64_t nrndm,
+                     int64_t ld_rm, int dtype, vcy_stream stream);
+
+/* ---------------------------------------------------------------- stage A: kNN pooling
+ * neighbors.convolve_by_sparse_weights (neighbors.py:416-423) as used by
+ * VelocytoLoom.knn_imputation[_precomputed] (analysis.py:1011-1019, 1046-1050):
+ *     out[c,:] = sum_p w[p] * data[indices[p],:]   for p in [indptr[c], indptr[c+1])
+ * i.e. (data @ w.T) in the reference's layout, w a CSR (C_out x C) weight matrix whose rows
+ * sum to one.  maximum != 0 additionally takes max(out[c,:], data[cell0+c,:]).
+ * slab_genes: genes per pass (0 = default); the launch walks gene slabs so that one slab of
+ * all cells (C * slab * 4 B) stays resident in the 256 MiB Infinity Cache while it is
+ * gathered k times.                                                                      */
+int vcy_knn_pool(const void *data, void *out, const int64_t *indptr, const int32_t *indices, const void *w,
+                 int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int maximum,
+                 int64_t slab_genes, int dtype, vcy_stream stream);
+
+/* Exact Euclidean kNN in a low-dimensional space (what sklearn NearestNeighbors provides to
+ * neighbors.knn_distance_matrix :363-376, BalancedKNN.fit/kneighbors :239-243,282 and
+ * analysis.py:1547-1549).  xt: (P, ldx) TRANSPOSED coordinates (feature-major) of all C
+ * points, fp32.  x64: (C, P) row-major fp64 coordinates for the exact re-rank.
+ * For queries q0..q0+Q-1 writes the k nearest (self excluded when include_self == 0, self
+ * forced first otherwise), nearest first, ties by index: idx (Q,k) int32, dist (Q,k) fp64.
+ * workspace: vcy_knn_workspace_bytes(C, Q) bytes.                                        */
+size_t vcy_knn_workspace_bytes(int64_t C, int64_t Q);
+int vcy_knn_search(const float *xt, const double *x64, int32_t *idx, double *dist, void *workspace,
+                   int64_t C, int64_t P, int64_t ldx, int64_t q0, int64_t Q, int64_t k, int include_self,
+                   vcy_stream stream);
+
+/* neighbors.balance_knn_loop / balance_knn_loop_constrained (neighbors.py:11-140): the
+ * sequential greedy in-degree-capped selection.  HOST function on HOST pointers (the
+ * reference runs it as numba-compiled scalar code; it is O(C * sight) integer work with a
+ * loop-carried dependence).  groups_host may be NULL.                                     */
+int vcy_balance_knn_host(const int64_t *dsi_host, const double *dist_host, const int64_t *lsi_host,
+                         const int64_t *groups_host, int64_t n, int64_t K, int64_t maxl, int64_t k,
+                         int return_distance, double *dist_new_host, int64_t *dsi_new_host, int64_t *l_host);
+
+/* ---------------------------------------------------------------- stage B: gamma fits
+ * estimation.fit_slope + _fit1_slope (estimation.py:173-188, 267-279): per gene
+ *     gamma = max(0, sum_c x*y / sum_c x*x), NaN if x == 0 everywhere, 0 if y == 0 everywhere;
+ * Y = unspliced, X = spliced, (C, ld) cells-major; gamma: (G) float32 like the reference.
+ * workspace: vcy_fit_workspace_bytes(G) bytes.                                           */
+size_t vcy_fit_workspace_bytes(int64_t G);
+int vcy_fit_slope(const void *Y, const void *X, float *gamma, void *workspace, int64_t C, int64_t G,
+                  int64_t ld, int dtype, vcy_stream stream);
+
+/* Per-gene order statistics over cells with numpy.percentile's linear interpolation
+ * (analysis.py:1183-1218 use np.percentile(M, q, axis=1)).  M: (C, ld) cells-major.
+ * qs_host: nq percentiles in [0,100] (host array).  out: (nq, G) fp64.
+ * If scale_a/scale_b (G, fp64) are non-NULL the statistic is taken of
+ *     M[c,g]/scale_a[g] + M2[c,g]/scale_b[g]      (the maxmin_diag sum, analysis.py:1203-1206).
+ * workspace: vcy_quantile_workspace_bytes(C, G).                                         */
+size_t vcy_quantile_workspace_bytes(int64_t C, int64_t G);
+int vcy_gene_quantiles(const void *M, const void *M2, const double *scale_a, const double *scale_b,
+                       const double *qs_host, int nq, double *out, void *workspace, int64_t C, int64_t G,
+                       int64_t ld, int dtype, vcy_stream stream);
+
+/* estimation.fit_slope_weighted_offset / fit_slope_weighted / fit_slope_offset with the
+ * binary or dense weights of VelocytoLoom.fit_gammas (estimation.py:191-264, 300-366;
+ * analysis.py:1179-1257), solved exactly: weighted moments per gene in one pass, then the
+ * closed-form box-constrained least squares the reference hands to L-BFGS-B / Brent.
+ *   weight_mode 0: W given densely (C, ld) of `dtype`
+ *   weight_mode 1: W = (Z <= down[g]) | (Z >= up[g]) with Z = M/scale_a + M2/scale_b
+ *                  (scale pointers NULL -> Z = M), thresholds (G) fp64  -- "maxmin*" weights
+ *   weight_mode 2: unweighted (W = 1)
+ *   fit_offset != 0 fits (gamma, q) in the box [lo_gamma, up_gamma[g]] x [0, 2*sum(yw)/sum(w)];
+ *   fit_offset == 0 fits gamma only in [lo_gamma, up_gamma[g]] with fixed offset q_fixed[g]
+ *   (NULL -> 0).  up_gamma may be NULL (-> up_gamma_default).
+ * Outputs gamma, q, R2: (G) float32 (R2 unweighted, -1e16 when non-finite; :354-363).     */
+int vcy_fit_weighted(const void *Y, const void *X, int weight_mode, const void *W, const void *M, const void *M2,
+                     const double *scale_a, const double *scale_b, const double *down, const double *up,
+                     int fit_offset, int box_q, double lo_gamma, double up_gamma_default, const double *up_gamma,
+                     const double *q_fixed, float *gamma, float *q, float *R2, void *workspace, int64_t C,
+                     int64_t G, int64_t ld, int dtype, vcy_stream stream);
+
+/* ---------------------------------------------------------------- stage C: velocity chain
+ * predict_U -> calculate_velocity -> calculate_shift -> extrapolate_cell_at_t and the
+ * `dmat` transform of estimate_transition_prob, fused (analysis.py:1321-1439, 1538,
+ * 1575-1601).  Any output pointer may be NULL (not materialised).
+ *   Upred   = gamma*Sx_sz + q
+ *   velocity= Ux_sz - Upred            (|v| < eps_thr[g] -> 0 when eps_thr != NULL)
+ *   delta_S = dt_shift*velocity                       (assumption 0, constant_velocity)
+ *           = Sx*e^{-g dt} + (1-e^{-g dt})*max(Ux-q,0)/g - Sx   (assumption 1, constant_unspliced)
+ *   Sx_sz_t = Sx_sz + dt_extrap*delta_S, clipped at 0 when clip != 0
+ *   dmat    = sign(D)*sqrt(|D|+psc) | sign(D)*log10(|D|+psc) | D,  D = (Sx_sz + used_dt*delta_S) - Sx_sz
+ * gamma, q: (G) float32 as the reference stores them (q may be NULL).                      */
+int vcy_velocity_chain(const void *Sx_sz, const void *Ux_sz, const float *gamma, const float *q,
+                       const double *eps_thr, void *Upred, void *velocity, void *delta_S, void *Sx_sz_t,
+                       void *dmat, int64_t C, int64_t G, int64_t ld, double dt_shift, double dt_extrap,
+                       double used_dt, int assumption, int clip, int transform, double psc, int dtype,
+                       vcy_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VELOCYTO_HIP_H */

@@ -1,0 +1,233 @@
+// knn.hip -- stage A: exact Euclidean kNN search + the greedy balanced-kNN selection.
+//
+// Reference: sklearn.neighbors.NearestNeighbors as called by neighbors.knn_distance_matrix
+// (neighbors.py:363-376), BalancedKNN.fit/kneighbors (:239-243, 282) and
+// estimate_transition_prob (analysis.py:1547-1549); numba loops balance_knn_loop[_constrained]
+// (neighbors.py:11-140).
+//
+// Search: a workgroup owns QB = 8 query cells.
+//   phase 1  fp32 squared distances to all C candidates, lanes over candidates reading the
+//            feature-major (P, C) copy of the space (coalesced), 8 accumulators per lane;
+//            the (8, C) distance rows go to a workspace that stays L2-resident for phase 2.
+//   phase 2  per query: MSB-first radix select on the 64-bit key (sortable distance bits << 32
+//            | candidate index) -> exactly Ksel = k + margin smallest keys, ties by index,
+//            deterministic; gather them, recompute their distances exactly in fp64, bitonic-
+//            sort (fp64 distance, index) in LDS and emit the first k.
+// The fp32 pass only has to get the candidate SET right (margin of 8 near-ties); order and
+// returned distances are fp64, matching the reference's fp64 search up to exact ties.
+#include <math.h>
+#include "common.h"
+
+namespace vcy {
+
+constexpr int KNN_QB = 8;
+constexpr int KNN_MAXSEL = 4096;
+constexpr int KNN_MARGIN = 8;
+
+__device__ __forceinline__ uint32_t f32_key(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt, const double *__restrict__ x64, int32_t *__restrict__ idx_out,
+                                                     double *__restrict__ dist_out, float *__restrict__ ws, int C, int P, int64_t ldx,
+                                                     int64_t q0, int Q, int k, int ksel, int nsort, int include_self)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *sd = reinterpret_cast<double *>(smem);                    // [nsort] fp64 distances
+    int *si = reinterpret_cast<int *>(sd + nsort);                    // [nsort] indices
+    float *xq = reinterpret_cast<float *>(si + nsort);                // [QB][P]
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ unsigned s_rank, s_count;
+    const int tid = threadIdx.x;
+    const int qb0 = blockIdx.x * KNN_QB;
+    const int nq = min(KNN_QB, Q - qb0);
+
+    for (int t = tid; t < KNN_QB * P; t += 256) {
+        const int qq = t / P, p = t - qq * P;
+        xq[t] = qq < nq ? xt[(int64_t)p * ldx + q0 + qb0 + qq] : 0.f;
+    }
+    __syncthreads();
+    // ---- phase 1: distances
+    float *wrow = ws + (int64_t)qb0 * C;
+    for (int j = tid; j < C; j += 256) {
+        float acc[KNN_QB];
+#pragma unroll
+        for (int qq = 0; qq < KNN_QB; ++qq) acc[qq] = 0.f;
+        for (int p = 0; p < P; ++p) {
+            const float xv = xt[(int64_t)p * ldx + j];
+#pragma unroll
+            for (int qq = 0; qq < KNN_QB; ++qq) {
+                const float df = xq[qq * P + p] - xv;
+                acc[qq] = fmaf(df, df, acc[qq]);
+            }
+        }
+#pragma unroll
+        for (int qq = 0; qq < KNN_QB; ++qq) {
+            if (qq < nq) {
+                float v = acc[qq];
+                if ((int64_t)j == q0 + qb0 + qq) v = include_self ? -1.f : INFINITY;
+                wrow[(int64_t)qq * C + j] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: select + exact re-rank, one query at a time
+    for (int qq = 0; qq < nq; ++qq) {
+        const float *row = wrow + (int64_t)qq * C;
+        const int64_t qcell = q0 + qb0 + qq;
+        unsigned long long prefix = 0;
+        unsigned rank = (unsigned)(ksel - 1);
+        for (int pass = 0; pass < 8; ++pass) {
+            const int shift = 8 * (7 - pass);
+            hist[tid] = 0;
+            __syncthreads();
+            for (int j = tid; j < C; j += 256) {
+                const unsigned long long key = ((unsigned long long)f32_key(row[j]) << 32) | (unsigned)j;
+                const bool match = (pass == 0) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+                if (match) atomicAdd(&hist[(unsigned)((key >> shift) & 0xff)], 1u);
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const unsigned h0 = hist[tid * 4], h1 = hist[tid * 4 + 1], h2 = hist[tid * 4 + 2], h3 = hist[tid * 4 + 3];
+                const unsigned tot = h0 + h1 + h2 + h3;
+                unsigned incl = tot;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const unsigned o = __shfl_up(incl, off, 64);
+                    if (tid >= off) incl += o;
+                }
+                const unsigned excl = incl - tot;
+                if (rank >= excl && rank < incl) {
+                    unsigned r = rank - excl;
+                    int d;
+                    if (r < h0) d = 0;
+                    else if ((r -= h0) < h1) d = 1;
+                    else if ((r -= h1) < h2) d = 2;
+                    else { r -= h2; d = 3; }
+                    s_prefix = prefix | ((unsigned long long)(tid * 4 + d) << shift);
+                    s_rank = r;
+                }
+            }
+            __syncthreads();
+            prefix = s_prefix;
+            rank = s_rank;
+        }
+        // gather the ksel keys <= prefix (unordered), exact fp64 distances
+        if (tid == 0) s_count = 0;
+        for (int t = tid; t < nsort; t += 256) { sd[t] = INFINITY; si[t] = 0x7fffffff; }
+        __syncthreads();
+        for (int j = tid; j < C; j += 256) {
+            const unsigned long long key = ((unsigned long long)f32_key(row[j]) << 32) | (unsigned)j;
+            if (key <= prefix) {
+                const unsigned pos = atomicAdd(&s_count, 1u);
+                if (pos < (unsigned)nsort) si[pos] = j;
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < ksel; t += 256) {
+            const int j = si[t];
+            double d2 = 0.0;
+            const double *a = x64 + qcell * P, *b = x64 + (int64_t)j * P;
+            for (int p = 0; p < P; ++p) { const double df = a[p] - b[p]; d2 = fma(df, df, d2); }
+            if ((int64_t)j == qcell) d2 = -1.0;   // include_self: own cell sorts first
+            sd[t] = d2;
+        }
+        __syncthreads();
+        // bitonic sort of (sd, si) ascending, ties by index
+        for (int size = 2; size <= nsort; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int t = tid; t < nsort / 2; t += 256) {
+                    const int lo = 2 * t - (t & (stride - 1));
+                    const int hi = lo + stride;
+                    const bool up = ((lo & size) == 0);
+                    const double a = sd[lo], b = sd[hi];
+                    const int ia = si[lo], ib = si[hi];
+                    const bool gt = (a > b) || (a == b && ia > ib);
+                    if (gt == up) { sd[lo] = b; sd[hi] = a; si[lo] = ib; si[hi] = ia; }
+                }
+                __syncthreads();
+            }
+        }
+        for (int t = tid; t < k; t += 256) {
+            idx_out[(int64_t)(qb0 + qq) * k + t] = si[t];
+            const double d2 = sd[t];
+            dist_out[(int64_t)(qb0 + qq) * k + t] = d2 < 0.0 ? 0.0 : sqrt(d2);
+        }
+        __syncthreads();
+    }
+}
+}  // namespace vcy
+
+using namespace vcy;
+
+extern "C" size_t vcy_knn_workspace_bytes(int64_t C, int64_t Q)
+{
+    const int64_t qpad = (Q + KNN_QB - 1) / KNN_QB * KNN_QB;
+    return (size_t)qpad * (size_t)C * sizeof(float);
+}
+
+extern "C" int vcy_knn_search(const float *xt, const double *x64, int32_t *idx, double *dist, void *workspace, int64_t C, int64_t P,
+                              int64_t ldx, int64_t q0, int64_t Q, int64_t k, int include_self, vcy_stream stream)
+{
+    VCY_REQUIRE(xt && x64 && idx && dist && workspace, "knn_search: null pointer");
+    VCY_REQUIRE(C > 1 && P > 0 && ldx >= C && Q > 0 && q0 >= 0 && q0 + Q <= C, "knn_search: bad shape");
+    const int64_t avail = include_self ? C : C - 1;
+    VCY_REQUIRE(k > 0 && k <= avail, "knn_search: k exceeds the number of candidates");
+    int64_t ksel = k + KNN_MARGIN;
+    if (ksel > avail) ksel = avail;
+    if (ksel > KNN_MAXSEL)
+        return fail(VCY_ERR_UNSUPPORTED, "%s: k=%lld exceeds the in-LDS selection limit (%lld)", "knn_search", (long long)k, (long long)(KNN_MAXSEL - KNN_MARGIN));
+    int nsort = 2;
+    while (nsort < ksel) nsort <<= 1;
+    const size_t lds = (size_t)nsort * (sizeof(double) + sizeof(int)) + (size_t)KNN_QB * P * sizeof(float);
+    VCY_REQUIRE(lds <= 150 * 1024, "knn_search: feature dimension too large for LDS");
+    VCY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_knn_search), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned blocks = (unsigned)((Q + KNN_QB - 1) / KNN_QB);
+    hipLaunchKernelGGL(k_knn_search, dim3(blocks), dim3(256), lds, as_stream(stream), xt, x64, idx, dist, (float *)workspace, (int)C, (int)P,
+                       ldx, q0, (int)Q, (int)k, (int)ksel, nsort, include_self);
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}
+
+// Sequential greedy balancing (neighbors.py:47-69 / 113-137): for each cell `el` in the given
+// order take, from its distance-sorted sight list, the first k cells m != el whose in-degree
+// l[m] is still below maxl (and, if constrained, share el's group); own index -> column 0;
+// if the sight list runs out, pad with el itself at distance dist[el,0] (:65-69).
+extern "C" int vcy_balance_knn_host(const int64_t *dsi, const double *dist, const int64_t *lsi, const int64_t *groups, int64_t n,
+                                    int64_t K, int64_t maxl, int64_t k, int return_distance, double *dist_new, int64_t *dsi_new,
+                                    int64_t *l)
+{
+    VCY_REQUIRE(dsi && dist && lsi && dist_new && dsi_new && l, "balance_knn: null pointer");
+    VCY_REQUIRE(n > 0 && K >= k && k > 0, "balance_knn: sight needs to be bigger than k");
+    const int64_t w = k + 1;
+    for (int64_t t = 0; t < n * w; ++t) { dsi_new[t] = -1; dist_new[t] = 0.0; }
+    for (int64_t t = 0; t < n; ++t) l[t] = 0;
+    for (int64_t it = 0; it < n; ++it) {
+        const int64_t el = lsi[it];
+        if (el < 0 || el >= n) return fail(VCY_ERR_INVALID, "%s: lsi entry out of range", "balance_knn");
+        const int64_t *sight = dsi + el * K;
+        int64_t taken = 0, j = 0;
+        for (; j < K && taken < k; ++j) {
+            const int64_t m = sight[j];
+            if (m == el) { dsi_new[el * w] = el; continue; }
+            if (m < 0 || m >= n) return fail(VCY_ERR_INVALID, "%s: dsi entry out of range", "balance_knn");
+            if (groups && groups[m] != groups[el]) continue;
+            if (l[m] >= maxl) continue;
+            ++taken;
+            dsi_new[el * w + taken] = m;
+            if (return_distance) dist_new[el * w + taken] = dist[el * K + j];
+            ++l[m];
+        }
+        for (; taken < k;) {   // sight exhausted
+            ++taken;
+            dsi_new[el * w + taken] = el;
+            dist_new[el * w + taken] = dist[el * K];
+        }
+    }
+    if (!return_distance)
+        for (int64_t t = 0; t < n * w; ++t) dist_new[t] = 1.0;
+    return VCY_OK;
+}

@@ -1,0 +1,73 @@
+// layout.hip -- library state + layout plumbing: (G,C) genes-major <-> (C,ld) cells-major.
+//
+// The reference keeps every matrix as a numpy (genes, cells) array (analysis.py:59-61) and its
+// kernels gather columns at stride C.  On the device a cell's gene vector is one contiguous row;
+// this file holds the tiled transpose (+ dtype change) that converts at the API boundary.
+#include "common.h"
+
+namespace vcy {
+thread_local char g_err[512] = "";
+
+// 64 x 64 tile through LDS (+1 padding): reads coalesced along src columns, writes coalesced
+// along dst columns.  dst padding columns [rows, ld_dst) are zero-filled by the row's last tile.
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void k_transpose(const S *__restrict__ src, D *__restrict__ dst, int64_t rows, int64_t cols,
+                                                    int64_t ld_src, int64_t ld_dst)
+{
+    __shared__ D tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    for (int j = ty; j < 64; j += 4) {
+        const int64_t r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < rows && c < cols) ? (D)src[r * ld_src + c] : D(0);
+    }
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4) {
+        const int64_t orow = c0 + j, ocol = r0 + tx;   // dst is (cols, ld_dst)
+        if (orow < cols && ocol < ld_dst) dst[orow * ld_dst + ocol] = tile[tx][j];
+    }
+}
+
+template <typename S, typename D>
+static int launch_transpose(const void *src, void *dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst, hipStream_t st)
+{
+    // grid.y covers ld_dst (not just rows) so that the padding columns get their zeros
+    dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((ld_dst + 63) / 64));
+    hipLaunchKernelGGL((k_transpose<S, D>), grid, dim3(256), 0, st, (const S *)src, (D *)dst, rows, cols, ld_src, ld_dst);
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}
+}  // namespace vcy
+
+using namespace vcy;
+
+extern "C" const char *vcy_last_error(void) { return g_err; }
+extern "C" int vcy_abi_version(void) { return 1; }
+
+extern "C" int vcy_device_info(int *cu_count, int *lds_bytes_per_block, int64_t *hbm_bytes)
+{
+    int dev = 0;
+    VCY_CHECK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    VCY_CHECK_HIP(hipGetDeviceProperties(&p, dev));
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (lds_bytes_per_block) {
+        int v = (int)p.sharedMemPerBlock, opt = 0;
+        if (hipDeviceGetAttribute(&opt, hipDeviceAttributeSharedMemPerBlockOptin, dev) == hipSuccess && opt > v) v = opt;
+        *lds_bytes_per_block = v;
+    }
+    if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+    return VCY_OK;
+}
+
+extern "C" int vcy_transpose(const void *src, void *dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst,
+                             int src_dtype, int dst_dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows, "transpose: bad arguments");
+    hipStream_t st = as_stream(stream);
+    if (src_dtype == VCY_F32 && dst_dtype == VCY_F32) return launch_transpose<float, float>(src, dst, rows, cols, ld_src, ld_dst, st);
+    if (src_dtype == VCY_F64 && dst_dtype == VCY_F32) return launch_transpose<double, float>(src, dst, rows, cols, ld_src, ld_dst, st);
+    if (src_dtype == VCY_F32 && dst_dtype == VCY_F64) return launch_transpose<float, double>(src, dst, rows, cols, ld_src, ld_dst, st);
+    if (src_dtype == VCY_F64 && dst_dtype == VCY_F64) return launch_transpose<double, double>(src, dst, rows, cols, ld_src, ld_dst, st);
+    return fail(VCY_ERR_INVALID, "%s: bad dtype", "transpose");
+}

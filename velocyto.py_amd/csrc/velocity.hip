@@ -1,0 +1,115 @@
+// velocity.hip -- stage C: predict_U -> calculate_velocity -> calculate_shift ->
+// extrapolate_cell_at_t and the `dmat` transform of estimate_transition_prob, fused into one
+// streaming pass (analysis.py:1321-1439, 1538, 1575-1601).  The reference materialises five
+// (G,C) fp64 temporaries (48 GB at 50k x 30k); here each requested output is written once and
+// everything else stays in registers.  HBM-bound: 2 reads + (#outputs) writes of G*s per cell.
+#include "common.h"
+
+namespace vcy {
+
+template <typename T> __device__ __forceinline__ T vsqrt(T x);
+template <> __device__ __forceinline__ float vsqrt<float>(float x) { return __builtin_amdgcn_sqrtf(x); }
+template <> __device__ __forceinline__ double vsqrt<double>(double x) { return sqrt(x); }
+template <typename T> __device__ __forceinline__ T vlog10(T x);
+template <> __device__ __forceinline__ float vlog10<float>(float x) { return __builtin_amdgcn_logf(x) * 0.30102999566398120f; }
+template <> __device__ __forceinline__ double vlog10<double>(double x) { return log10(x); }
+template <typename T> __device__ __forceinline__ T vexp(T x);
+template <> __device__ __forceinline__ float vexp<float>(float x) { return __expf(x); }
+template <> __device__ __forceinline__ double vexp<double>(double x) { return exp(x); }
+
+struct VelArgs {
+    const void *Sx, *Ux;
+    const float *gamma, *q;
+    const double *eps_thr;
+    void *Upred, *velocity, *delta_S, *Sx_t, *dmat;
+    int64_t C, ld;
+    int G;
+    double dt_shift, dt_extrap, used_dt, psc;
+    int assumption, clip, transform;
+};
+
+// np.sign(D) * f(|D| + psc)  (analysis.py:1577, 1597): sign(0) = 0 -> dmat = 0 where D == 0.
+template <typename T> __device__ __forceinline__ T dmat_of(T D, int transform, T psc)
+{
+    if (transform == VCY_LINEAR) return D;
+    const T a = fabs(D) + psc;
+    const T f = transform == VCY_SQRT ? vsqrt<T>(a) : vlog10<T>(a);
+    return D > T(0) ? f : (D < T(0) ? -f : T(0) * f);
+}
+
+template <typename T> __global__ __launch_bounds__(256) void k_velocity_chain(VelArgs a)
+{
+    using V = typename Vec<T>::type;
+    constexpr int N = Vec<T>::N;
+    const int nvec = (int)(a.ld / N);
+    const int64_t total = a.C * (int64_t)nvec;
+    const T *Sx = (const T *)a.Sx, *Ux = (const T *)a.Ux;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = t / nvec;
+        const int v = (int)(t - c * nvec);
+        const int64_t o = c * a.ld + (int64_t)v * N;
+        const V sv = *reinterpret_cast<const V *>(Sx + o);
+        const V uv = *reinterpret_cast<const V *>(Ux + o);
+        const T *sp = reinterpret_cast<const T *>(&sv);
+        const T *up = reinterpret_cast<const T *>(&uv);
+        V o_up, o_vel, o_ds, o_st, o_dm;
+        T *pu = reinterpret_cast<T *>(&o_up), *pv = reinterpret_cast<T *>(&o_vel), *pd = reinterpret_cast<T *>(&o_ds),
+          *pt = reinterpret_cast<T *>(&o_st), *pm = reinterpret_cast<T *>(&o_dm);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int g = v * N + k;
+            T upred = T(0), vel = T(0), ds = T(0), st = T(0), dm = T(0);
+            if (g < a.G) {
+                const T gm = (T)a.gamma[g];
+                const T qq = a.q ? (T)a.q[g] : T(0);
+                const T s = sp[k], u = up[k];
+                upred = gm * s + qq;                               // analysis.py:1346
+                vel = u - upred;                                   // :1369
+                if (a.eps_thr && fabs((double)vel) < a.eps_thr[g]) vel = T(0);   // :1377-1379
+                if (a.assumption == 0) ds = (T)a.dt_shift * vel;   // :1399
+                else {                                             // :1403-1406
+                    T uo = u - qq;
+                    uo = uo < T(0) ? T(0) : uo;
+                    const T egt = vexp<T>(-gm * (T)a.dt_shift);
+                    ds = s * egt + (T(1) - egt) * uo / gm - s;
+                }
+                st = s + (T)a.dt_extrap * ds;                      // :1429
+                if (a.clip) st = st < T(0) ? T(0) : st;            // :1431
+                const T D = (s + (T)a.used_dt * ds) - s;           // :1538 + :1576/1596 (hi_dim_t - hi_dim)
+                dm = dmat_of<T>(D, a.transform, (T)a.psc);
+            }
+            pu[k] = upred; pv[k] = vel; pd[k] = ds; pt[k] = st; pm[k] = dm;
+        }
+        if (a.Upred) *reinterpret_cast<V *>((T *)a.Upred + o) = o_up;
+        if (a.velocity) *reinterpret_cast<V *>((T *)a.velocity + o) = o_vel;
+        if (a.delta_S) *reinterpret_cast<V *>((T *)a.delta_S + o) = o_ds;
+        if (a.Sx_t) *reinterpret_cast<V *>((T *)a.Sx_t + o) = o_st;
+        if (a.dmat) *reinterpret_cast<V *>((T *)a.dmat + o) = o_dm;
+    }
+}
+}  // namespace vcy
+
+using namespace vcy;
+
+extern "C" int vcy_velocity_chain(const void *Sx_sz, const void *Ux_sz, const float *gamma, const float *q, const double *eps_thr,
+                                  void *Upred, void *velocity, void *delta_S, void *Sx_sz_t, void *dmat, int64_t C, int64_t G,
+                                  int64_t ld, double dt_shift, double dt_extrap, double used_dt, int assumption, int clip,
+                                  int transform, double psc, int dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(Sx_sz && Ux_sz && gamma, "velocity_chain: null pointer");
+    VCY_REQUIRE(C > 0 && G > 0 && ld >= G, "velocity_chain: bad shape");
+    VCY_REQUIRE(dtype == VCY_F32 || dtype == VCY_F64, "velocity_chain: bad dtype");
+    VCY_REQUIRE(ld % (dtype == VCY_F32 ? 4 : 2) == 0, "velocity_chain: ld must keep rows 16-byte aligned");
+    VCY_REQUIRE(transform >= VCY_LINEAR && transform <= VCY_LOG10, "velocity_chain: bad transform");
+    VCY_REQUIRE(assumption == 0 || assumption == 1, "velocity_chain: bad assumption");
+    VelArgs a{Sx_sz, Ux_sz, gamma, q, eps_thr, Upred, velocity, delta_S, Sx_sz_t, dmat, C, ld, (int)G,
+              dt_shift, dt_extrap, used_dt, psc, assumption, clip, transform};
+    const int N = dtype == VCY_F32 ? 4 : 2;
+    const int64_t total = C * (ld / N);
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipStream_t st = as_stream(stream);
+    if (dtype == VCY_F32) hipLaunchKernelGGL(k_velocity_chain<float>, dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_velocity_chain<double>, dim3(blocks), dim3(256), 0, st, a);
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}

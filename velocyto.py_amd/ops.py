@@ -1,0 +1,331 @@
+"""Device-level operators: thin, typed wrappers over the C ABI (include/velocyto_hip.h).
+
+PyTorch is plumbing only here: it owns device memory and streams; every computation is a
+hand-written gfx950 kernel in libvelocyto_hip.so reached through ctypes with raw device
+pointers.  No function in this module has a CPU path.
+
+Matrices live on the device CELLS-MAJOR: ``CellMatrix.t`` has shape ``(C, ld)`` with the
+logical gene count ``G <= ld`` (ld = G rounded up to 64 elements so that every cell's gene
+vector starts 256-byte aligned).  This is the transpose of the reference's ``(G, C)`` arrays.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+F32, F64 = 0, 1
+LINEAR, SQRT, LOG10 = 0, 1, 2
+RULES_FULL, RULES_PARTIAL = 0, 1
+TRANSFORMS = {"linear": LINEAR, "sqrt": SQRT, "log10": LOG10, "log": LOG10}
+
+_DT = {torch.float32: F32, torch.float64: F64}
+
+
+def require_gpu() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("velocyto_amd needs a ROCm GPU (MI355X): there is no CPU fallback for the HIP path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def resolve_dtype(dtype) -> torch.dtype:
+    if dtype is None:
+        import os
+        dtype = os.environ.get("VELOCYTO_AMD_DTYPE", "float32")
+    if isinstance(dtype, torch.dtype):
+        out = dtype
+    else:
+        out = {"float32": torch.float32, "f32": torch.float32, "float64": torch.float64, "f64": torch.float64,
+               np.float32: torch.float32, np.float64: torch.float64}[dtype if not isinstance(dtype, np.dtype) else dtype.type]
+    if out not in _DT:
+        raise ValueError(f"unsupported dtype {dtype}")
+    return out
+
+
+def padded_ld(G: int) -> int:
+    return (G + 63) // 64 * 64
+
+
+class CellMatrix:
+    """A (C cells, G genes) matrix on the device, rows padded to ``ld`` elements."""
+
+    __slots__ = ("t", "G")
+
+    def __init__(self, t: torch.Tensor, G: int):
+        assert t.dim() == 2 and t.is_contiguous() and t.is_cuda and t.dtype in _DT and t.shape[1] >= G
+        self.t, self.G = t, int(G)
+
+    C = property(lambda self: int(self.t.shape[0]))
+    ld = property(lambda self: int(self.t.shape[1]))
+    dtype = property(lambda self: self.t.dtype)
+    code = property(lambda self: _DT[self.t.dtype])
+
+    @classmethod
+    def empty(cls, C: int, G: int, dtype=None, zero_pad: bool = True) -> "CellMatrix":
+        dev = require_gpu()
+        ld = padded_ld(G)
+        t = torch.empty((C, ld), dtype=resolve_dtype(dtype), device=dev)
+        if zero_pad and ld > G:
+            t[:, G:].zero_()
+        return cls(t, G)
+
+    @classmethod
+    def from_genes_major(cls, a, dtype=None) -> "CellMatrix":
+        """(G, C) numpy / torch array (any order, any float/int dtype) -> device cells-major."""
+        dev = require_gpu()
+        dt = resolve_dtype(dtype)
+        if isinstance(a, CellMatrix):
+            return a if a.dtype == dt else a.astype(dt)
+        if isinstance(a, np.ndarray):
+            if a.dtype not in (np.float32, np.float64):
+                a = a.astype(np.float64)
+            if a.flags.f_contiguous and not a.flags.c_contiguous:
+                # Fortran (G,C) == C-order (C,G): already cells-major, no transpose needed
+                src = torch.from_numpy(np.ascontiguousarray(a.T)).to(dev)
+                return cls.from_cells_major(src, dt)
+            src = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        else:
+            src = a.to(dev)
+            if src.dtype not in _DT:
+                src = src.double()
+            src = src.contiguous()
+        G, C = src.shape
+        out = cls(torch.empty((C, padded_ld(G)), dtype=dt, device=dev), G)
+        _lib.check(_lib.lib().vcy_transpose(src.data_ptr(), out.t.data_ptr(), G, C, C, out.ld, _DT[src.dtype], out.code, _stream()), "transpose")
+        return out
+
+    @classmethod
+    def from_cells_major(cls, a, dtype=None) -> "CellMatrix":
+        """(C, G) array -> padded device matrix (a plain padded copy, no transpose)."""
+        dev = require_gpu()
+        dt = resolve_dtype(dtype)
+        src = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
+        src = src.to(dev)
+        C, G = src.shape
+        out = cls(torch.zeros((C, padded_ld(G)), dtype=dt, device=dev), G)
+        out.t[:, :G] = src.to(dt)
+        return out
+
+    def astype(self, dtype) -> "CellMatrix":
+        dt = resolve_dtype(dtype)
+        return self if dt == self.dtype else CellMatrix(self.t.to(dt), self.G)
+
+    def clone(self) -> "CellMatrix":
+        return CellMatrix(self.t.clone(), self.G)
+
+    def rows(self, c0: int, c1: int) -> "CellMatrix":
+        return CellMatrix(self.t[c0:c1], self.G)
+
+    def to_genes_major(self, dtype=np.float64, order: str = "C") -> np.ndarray:
+        """Back to the reference's (G, C) numpy layout."""
+        C, G = self.C, self.G
+        if order == "F":   # Fortran (G,C) is exactly our memory order: plain copy
+            return self.t[:, :G].to("cpu").numpy().astype(dtype, copy=False).T
+        dst = torch.empty((G, C), dtype=self.dtype, device=self.t.device)
+        _lib.check(_lib.lib().vcy_transpose(self.t.data_ptr(), dst.data_ptr(), C, G, self.ld, C, self.code, self.code, _stream()), "transpose")
+        return dst.cpu().numpy().astype(dtype, copy=False)
+
+    def to_cells_major(self, dtype=np.float64) -> np.ndarray:
+        return self.t[:, : self.G].to("cpu").numpy().astype(dtype, copy=False)
+
+
+def _as_i32(ixs, dev) -> torch.Tensor:
+    if isinstance(ixs, torch.Tensor):
+        return ixs.to(device=dev, dtype=torch.int32).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(ixs).astype(np.int32)).to(dev)
+
+
+# --------------------------------------------------------------------------- stage D
+def coldeltacor_partial(e: CellMatrix, d: CellMatrix, ixs, transform: int, rules: int = RULES_PARTIAL, psc: float = 0.0,
+                        cell0: int = 0, order: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Compact correlations out[c, n] = corr(cell0 + c, ixs[c, n]); ixs: (C_out, nrndm)."""
+    assert e.t.shape == d.t.shape and e.dtype == d.dtype and e.G == d.G
+    ix = _as_i32(ixs, e.t.device)
+    C_out, nrndm = ix.shape
+    if ix.numel() and (int(ix.min()) < 0 or int(ix.max()) >= e.C):
+        raise ValueError("neighbour index out of range")
+    if out is None:
+        out = torch.empty((C_out, nrndm), dtype=e.dtype, device=e.t.device)
+    if order is not None:
+        order = order.to(device=e.t.device, dtype=torch.int32).contiguous()
+        assert order.numel() == C_out
+    _lib.check(_lib.lib().vcy_coldeltacor_partial(e.t.data_ptr(), d.t.data_ptr(), ix.data_ptr(), out.data_ptr(), _p(order),
+                                                  e.C, e.G, e.ld, cell0, C_out, nrndm, transform, rules, float(psc), e.code,
+                                                  _stream()), "coldeltacor_partial")
+    return out
+
+
+def coldeltacor_full(e: CellMatrix, d: CellMatrix, transform: int, psc: float = 0.0, cell0: int = 0,
+                     C_out: Optional[int] = None, rm: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """Dense correlation rows rm[c, i] for c in [cell0, cell0+C_out), all i."""
+    assert e.t.shape == d.t.shape and e.dtype == d.dtype
+    C_out = e.C - cell0 if C_out is None else C_out
+    if rm is None:
+        rm = torch.zeros((C_out, e.C), dtype=e.dtype, device=e.t.device)
+        accumulate = False
+    assert rm.is_contiguous() and rm.shape == (C_out, e.C) and rm.dtype == e.dtype
+    _lib.check(_lib.lib().vcy_coldeltacor_full(e.t.data_ptr(), d.t.data_ptr(), rm.data_ptr(), e.C, e.G, e.ld, cell0, C_out,
+                                               rm.shape[1], transform, float(psc), int(accumulate), e.code, _stream()),
+               "coldeltacor_full")
+    return rm
+
+
+def scatter_rows(vals: torch.Tensor, ixs, ncols: int, rm: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """rm[c, ixs[c,n]] += vals[c,n]  (the reference's dense (C,C) `rm`, speedboosted.pyx:332-336)."""
+    ix = _as_i32(ixs, vals.device)
+    C_out, nrndm = ix.shape
+    if rm is None:
+        rm = torch.zeros((C_out, ncols), dtype=vals.dtype, device=vals.device)
+    _lib.check(_lib.lib().vcy_scatter_rows(vals.contiguous().data_ptr(), ix.data_ptr(), rm.data_ptr(), C_out, nrndm, rm.shape[1],
+                                           _DT[vals.dtype], _stream()), "scatter_rows")
+    return rm
+
+
+# --------------------------------------------------------------------------- stage A
+def knn_pool(data: CellMatrix, indptr, indices, weights, maximum: bool = False, cell0: int = 0,
+             C_out: Optional[int] = None, slab_genes: int = 0, out: Optional[CellMatrix] = None) -> CellMatrix:
+    """out[c,:] = sum_p w[p] data[indices[p],:] over CSR row c (neighbors.py:416-423 on device)."""
+    dev = data.t.device
+    C_out = data.C - cell0 if C_out is None else C_out
+    ip = (indptr if isinstance(indptr, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(indptr).astype(np.int64))).to(device=dev, dtype=torch.int64).contiguous()
+    ix = _as_i32(indices, dev)
+    w = (weights if isinstance(weights, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(weights))).to(device=dev, dtype=data.dtype).contiguous()
+    assert ip.numel() == C_out + 1 and ix.numel() == w.numel()
+    if ix.numel() and (int(ix.min()) < 0 or int(ix.max()) >= data.C):
+        raise ValueError("neighbour index out of range")
+    if out is None:
+        out = CellMatrix.empty(C_out, data.G, data.dtype)
+    _lib.check(_lib.lib().vcy_knn_pool(data.t.data_ptr(), out.t.data_ptr(), ip.data_ptr(), ix.data_ptr(), w.data_ptr(), data.C,
+                                       data.G, data.ld, cell0, C_out, int(maximum), int(slab_genes), data.code, _stream()), "knn_pool")
+    return out
+
+
+def knn_search(space, k: int, include_self: bool = False, q0: int = 0, Q: Optional[int] = None,
+               query_block: int = 8192) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Exact Euclidean kNN of rows q0..q0+Q of `space` (C, P) among all C rows.
+    Returns (idx int32 (Q,k), dist float64 (Q,k)), nearest first, ties by index."""
+    dev = require_gpu()
+    x64 = (torch.from_numpy(np.ascontiguousarray(space, dtype=np.float64)) if not isinstance(space, torch.Tensor) else space.double()).to(dev).contiguous()
+    C, P = x64.shape
+    Q = C - q0 if Q is None else Q
+    ldx = (C + 63) // 64 * 64
+    xt = torch.zeros((P, ldx), dtype=torch.float32, device=dev)
+    xt[:, :C] = x64.t().float()
+    idx = torch.empty((Q, k), dtype=torch.int32, device=dev)
+    dist = torch.empty((Q, k), dtype=torch.float64, device=dev)
+    L = _lib.lib()
+    qb = min(Q, query_block)
+    ws = torch.empty(int(L.vcy_knn_workspace_bytes(C, qb)), dtype=torch.uint8, device=dev)
+    for s in range(0, Q, qb):
+        n = min(qb, Q - s)
+        _lib.check(L.vcy_knn_search(xt.data_ptr(), x64.data_ptr(), idx[s:s + n].data_ptr(), dist[s:s + n].data_ptr(), ws.data_ptr(),
+                                    C, P, ldx, q0 + s, n, k, int(include_self), _stream()), "knn_search")
+    return idx, dist
+
+
+def balance_knn_host(dsi: np.ndarray, dist: Optional[np.ndarray], lsi: np.ndarray, groups: Optional[np.ndarray], maxl: int, k: int
+                     ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Host greedy balancing loop (neighbors.py:11-140) in C++ (vcy_balance_knn_host)."""
+    dsi = np.ascontiguousarray(dsi, dtype=np.int64)
+    n, K = dsi.shape
+    if K < k:
+        raise AssertionError("sight needs to be bigger than k")
+    return_distance = dist is not None
+    if dist is None:
+        dist = np.ones(dsi.shape, dtype=np.float64)
+        dist[:, 0] = 0
+    dist = np.ascontiguousarray(dist, dtype=np.float64)
+    lsi = np.ascontiguousarray(lsi, dtype=np.int64)
+    g = None if groups is None else np.ascontiguousarray(groups, dtype=np.int64)
+    dist_new = np.empty((n, k + 1), dtype=np.float64)
+    dsi_new = np.empty((n, k + 1), dtype=np.int64)
+    l = np.empty(n, dtype=np.int64)
+    _lib.check(_lib.lib().vcy_balance_knn_host(dsi.ctypes.data, dist.ctypes.data, lsi.ctypes.data, None if g is None else g.ctypes.data,
+                                               n, K, int(maxl), int(k), int(return_distance), dist_new.ctypes.data,
+                                               dsi_new.ctypes.data, l.ctypes.data), "balance_knn")
+    return dist_new, dsi_new, l
+
+
+# --------------------------------------------------------------------------- stage B
+_fit_ws = {}
+
+
+def _fit_workspace(G: int, dev) -> torch.Tensor:
+    key = (G, str(dev))
+    if key not in _fit_ws:
+        _fit_ws.clear()
+        _fit_ws[key] = torch.empty(int(_lib.lib().vcy_fit_workspace_bytes(G)), dtype=torch.uint8, device=dev)
+    return _fit_ws[key]
+
+
+def fit_slope(Y: CellMatrix, X: CellMatrix) -> torch.Tensor:
+    """gamma (G,) float32 = max(0, <x,y>/<x,x>) per gene (estimation.py:173-188, 267-279)."""
+    assert Y.t.shape == X.t.shape and Y.dtype == X.dtype
+    gamma = torch.empty(Y.G, dtype=torch.float32, device=Y.t.device)
+    ws = _fit_workspace(Y.G, Y.t.device)
+    _lib.check(_lib.lib().vcy_fit_slope(Y.t.data_ptr(), X.t.data_ptr(), gamma.data_ptr(), ws.data_ptr(), Y.C, Y.G, Y.ld, Y.code, _stream()), "fit_slope")
+    return gamma
+
+
+def gene_quantiles(M: CellMatrix, qs: Sequence[float], M2: Optional[CellMatrix] = None, scale_a: Optional[torch.Tensor] = None,
+                   scale_b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """np.percentile(M_or_Z, qs, axis=cells) -> (len(qs), G) float64 on device."""
+    qs = np.ascontiguousarray(qs, dtype=np.float64).ravel()
+    out = torch.empty((len(qs), M.G), dtype=torch.float64, device=M.t.device)
+    ws = torch.empty(int(_lib.lib().vcy_quantile_workspace_bytes(M.C, M.G)) // (2 if M.code == F32 else 1), dtype=torch.uint8, device=M.t.device)
+    _lib.check(_lib.lib().vcy_gene_quantiles(M.t.data_ptr(), None if M2 is None else M2.t.data_ptr(), _p(scale_a), _p(scale_b),
+                                             qs.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), len(qs), out.data_ptr(), ws.data_ptr(),
+                                             M.C, M.G, M.ld, M.code, _stream()), "gene_quantiles")
+    return out
+
+
+def fit_weighted(Y: CellMatrix, X: CellMatrix, weight_mode: int, W: Optional[CellMatrix] = None, M: Optional[CellMatrix] = None,
+                 M2: Optional[CellMatrix] = None, scale_a=None, scale_b=None, down=None, up=None, fit_offset: bool = True,
+                 box_q: bool = True, lo_gamma: float = 1e-8, up_gamma_default: float = 20.0, up_gamma=None, q_fixed=None,
+                 want_R2: bool = True) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+    dev = Y.t.device
+    G = Y.G
+    gamma = torch.empty(G, dtype=torch.float32, device=dev)
+    q = torch.empty(G, dtype=torch.float32, device=dev)
+    R2 = torch.empty(G, dtype=torch.float32, device=dev) if want_R2 else None
+    ws = _fit_workspace(G, dev)
+    f64 = lambda t: None if t is None else t.to(device=dev, dtype=torch.float64).contiguous()
+    scale_a, scale_b, down, up, up_gamma, q_fixed = map(f64, (scale_a, scale_b, down, up, up_gamma, q_fixed))
+    _lib.check(_lib.lib().vcy_fit_weighted(Y.t.data_ptr(), X.t.data_ptr(), weight_mode, None if W is None else W.t.data_ptr(),
+                                           None if M is None else M.t.data_ptr(), None if M2 is None else M2.t.data_ptr(),
+                                           _p(scale_a), _p(scale_b), _p(down), _p(up), int(fit_offset), int(box_q), float(lo_gamma),
+                                           float(up_gamma_default), _p(up_gamma), _p(q_fixed), gamma.data_ptr(), q.data_ptr(), _p(R2),
+                                           ws.data_ptr(), Y.C, G, Y.ld, Y.code, _stream()), "fit_weighted")
+    return gamma, q, R2
+
+
+# --------------------------------------------------------------------------- stage C
+def velocity_chain(Sx_sz: CellMatrix, Ux_sz: CellMatrix, gamma: torch.Tensor, q: Optional[torch.Tensor], *, want=("dmat",),
+                   eps_thr: Optional[torch.Tensor] = None, dt_shift: float = 1.0, dt_extrap: float = 1.0, used_dt: float = 1.0,
+                   assumption: int = 0, clip: bool = True, transform: int = SQRT, psc: float = 1e-10) -> dict:
+    """Fused predict_U -> velocity -> shift -> extrapolate -> dmat; `want` names the outputs to
+    materialise among Upred, velocity, delta_S, Sx_sz_t, dmat.  Returns {name: CellMatrix}."""
+    names = ("Upred", "velocity", "delta_S", "Sx_sz_t", "dmat")
+    outs = {n: (CellMatrix(torch.empty_like(Sx_sz.t), Sx_sz.G) if n in want else None) for n in names}
+    dev = Sx_sz.t.device
+    gamma = gamma.to(device=dev, dtype=torch.float32).contiguous()
+    q = None if q is None else q.to(device=dev, dtype=torch.float32).contiguous()
+    eps_thr = None if eps_thr is None else eps_thr.to(device=dev, dtype=torch.float64).contiguous()
+    ptr = lambda n: None if outs[n] is None else outs[n].t.data_ptr()
+    _lib.check(_lib.lib().vcy_velocity_chain(Sx_sz.t.data_ptr(), Ux_sz.t.data_ptr(), gamma.data_ptr(), _p(q), _p(eps_thr), ptr("Upred"),
+                                             ptr("velocity"), ptr("delta_S"), ptr("Sx_sz_t"), ptr("dmat"), Sx_sz.C, Sx_sz.G, Sx_sz.ld,
+                                             float(dt_shift), float(dt_extrap), float(used_dt), int(assumption), int(clip), int(transform),
+                                             float(psc), Sx_sz.code, _stream()), "velocity_chain")
+    return {n: m for n, m in outs.items() if m is not None}
