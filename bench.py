@@ -1,0 +1,315 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X: cells/sec through knn_imputation -> fit_slope -> colDeltaCor.
+
+Workload (BASELINE.json configs[2], SURVEY.md section 8d "cfg3"): synthetic 50 000 cells x 30 000 genes,
+k = 30 kNN in a 30-d PCA space, estimate_transition_prob(transform="sqrt", n_neighbors=500,
+sampled_fraction=0.5) => nrndm = 250.  One timed "step" = one pass of the path over the whole
+dataset, inputs (S_sz, U_sz, pcs, sampled embedding neighbours) already resident in HBM:
+
+  A  knn_imputation : exact kNN search in pcs + connectivity weights + pooling of S_sz and U_sz
+  B  fit_slope      : per-gene gamma = max(0, <Sx,Ux>/<Sx,Sx>)
+  C  velocity chain : predict_U -> velocity -> delta_S -> signed-sqrt dmat (fused)
+  D  colDeltaCorSqrtpartial on the sampled embedding neighbours (the dominant kernel)
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): cells are sharded, total work
+fixed ("strong" scaling): ranks all-reduce the fit moments, all-gather the Sx shards (every rank
+needs all of `e`) and all-gather the compact correlation rows.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_cdc_partial), from HIP-event
+timing of that launch; `cpu_baseline` times the REFERENCE's own compiled kernel (oracle/_ref) plus the
+oracle port for stages A-C on a bounded closed sub-problem on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK = 8.0e12   # B/s, MI355X spec (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cells", type=int, default=50000)
+    ap.add_argument("--genes", type=int, default=30000)
+    ap.add_argument("--k", type=int, default=30)
+    ap.add_argument("--pca-dims", type=int, default=30)
+    ap.add_argument("--n-neighbors", type=int, default=500)
+    ap.add_argument("--sampled-fraction", type=float, default=0.5)
+    ap.add_argument("--cpu-cells", type=int, default=1024, help="cells of the closed CPU-baseline sub-problem")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass (else null)")
+    ap.add_argument("--order", choices=["natural", "embedding"], default="embedding",
+                    help="schedule order of the cells in stage D (results are order-independent)")
+    return ap.parse_args()
+
+
+def synth(C, G, P, dev, seed=20180811):
+    """Seeded synthetic counts with velocity structure, generated on the device in cell blocks and
+    size-normalised (the a1 pre-step, not in the metric).  Returns cells-major f32 (C, ld) tensors."""
+    from velocyto_amd import ops
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    ld = ops.padded_ld(G)
+    S = torch.zeros((C, ld), dtype=torch.float32, device=dev)
+    U = torch.zeros((C, ld), dtype=torch.float32, device=dev)
+    alpha = torch.exp(torch.randn(G, generator=gen, device=dev))
+    gamma = torch.exp(-0.5 + 0.5 * torch.randn(G, generator=gen, device=dev))
+    t_on = torch.rand(G, generator=gen, device=dev) * 0.7
+    switching = (torch.rand(G, generator=gen, device=dev) < 0.6).float()
+    t = torch.rand(C, generator=gen, device=dev)
+    branch = (torch.rand(C, generator=gen, device=dev) < 0.5).float()
+    branch_gene = (torch.rand(G, generator=gen, device=dev) < 0.3).float()
+    size = torch.exp(0.3 * torch.randn(C, generator=gen, device=dev))
+    blk = 4096
+    for s in range(0, C, blk):
+        tt = t[s:s + blk, None]
+        tau = torch.clamp(tt - t_on[None, :], min=0.0) * switching[None, :] + (1 - switching[None, :]) * 1.0
+        gate = 1.0 - branch_gene[None, :] * branch[s:s + blk, None] * (tt > 0.5).float()
+        u = alpha[None, :] * (1 - torch.exp(-4.0 * tau)) * gate
+        sp = (alpha / gamma)[None, :] * (1 - torch.exp(-2.0 * gamma[None, :] * tau)) * gate
+        sz = size[s:s + blk, None]
+        U[s:s + blk, :G] = torch.poisson(0.3 * sz * u, generator=gen)
+        S[s:s + blk, :G] = torch.poisson(sz * sp, generator=gen)
+    # a1 pre-step (analysis.py:535-582): size normalisation
+    for M in (S, U):
+        cs = M.sum(1)
+        M.mul_((cs.mean() / cs.clamp(min=1.0))[:, None])
+    # pcs: top-P principal components of log2(S_sz + 1) (perform_PCA is upstream of the path; randomised SVD here)
+    L = torch.log2(S[:, :G] + 1.0)
+    L -= L.mean(0, keepdim=True)
+    Uu, Ss, _ = torch.svd_lowrank(L, q=P, niter=2)
+    pcs = (Uu * Ss).double().contiguous()
+    del L
+    return ops.CellMatrix(S, G), ops.CellMatrix(U, G), pcs
+
+
+def sample_neighbors_device(embedding, n_neighbors, sampled_fraction, dev, seed=15071990):
+    """Embedding kNN (HIP kernel) + weighted subsampling without replacement (analysis.py:1547-1572) on the device.
+    The reference draws with numpy's legacy RNG on the host; for the benchmark the draw is an input."""
+    from velocyto_amd import ops
+    idx, _ = ops.knn_search(embedding, n_neighbors + 1, include_self=False)
+    n1 = n_neighbors + 1
+    p = torch.linspace(0.5, 0.1, n1, device=dev, dtype=torch.float64)
+    p = p / p.sum()
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    # Efraimidis-Spirakis: the m largest u^(1/p) are a weighted sample without replacement
+    keys = torch.log(torch.rand((idx.shape[0], n1), generator=gen, device=dev, dtype=torch.float64)) / p[None, :]
+    m = int(sampled_fraction * n1)
+    sel = torch.topk(keys, m, dim=1).indices
+    return torch.gather(idx, 1, sel).contiguous(), idx
+
+
+def embedding_order(embedding, dev):
+    """Morton order of the 2-d embedding: consecutive workgroups share neighbours (Infinity-Cache reuse)."""
+    e = embedding[:, :2].float()
+    q = ((e - e.min(0).values) / (e.max(0).values - e.min(0).values + 1e-30) * 65535).long()
+
+    def spread(v):
+        v = (v | (v << 8)) & 0x00FF00FF
+        v = (v | (v << 4)) & 0x0F0F0F0F
+        v = (v | (v << 2)) & 0x33333333
+        v = (v | (v << 1)) & 0x55555555
+        return v
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << 1)
+    return torch.argsort(code).to(torch.int32)
+
+
+class Pipeline:
+    def __init__(self, args, dev, rank, world):
+        from velocyto_amd import ops, distributed
+        self.ops, self.D = ops, distributed
+        self.a, self.dev, self.rank, self.world = args, dev, rank, world
+        C, G = args.cells, args.genes
+        self.S, self.U, self.pcs = synth(C, G, args.pca_dims, dev)
+        self.space = self.pcs[:, :args.pca_dims].contiguous()
+        emb = self.pcs[:, :2].contiguous()
+        self.neigh, _ = sample_neighbors_device(emb, args.n_neighbors, args.sampled_fraction, dev)
+        self.nrndm = int(self.neigh.shape[1])
+        self.c0, self.c1 = distributed.shard_bounds(C, world, rank)
+        nloc = self.c1 - self.c0
+        self.neigh_loc = self.neigh[self.c0:self.c1].contiguous()
+        order = embedding_order(emb[self.c0:self.c1], dev) if args.order == "embedding" else None
+        self.order = order
+        # persistent outputs
+        self.Sx_loc = ops.CellMatrix.empty(nloc, G, torch.float32)
+        self.Ux_loc = ops.CellMatrix.empty(nloc, G, torch.float32)
+        self.Sx_full = self.Sx_loc if world == 1 else ops.CellMatrix.empty(C, G, torch.float32)
+        self.corr_loc = torch.empty((nloc, self.nrndm), dtype=torch.float32, device=dev)
+        self.corr = self.corr_loc if world == 1 else torch.empty((C, self.nrndm), dtype=torch.float32, device=dev)
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(10)]
+        self.stage_ms = np.zeros(5)
+        self.d_ms = []
+
+    def step(self, timed=False):
+        ops, a = self.ops, self.a
+        C, G, k = a.cells, a.genes, a.k
+        c0, c1 = self.c0, self.c1
+        nloc = c1 - c0
+        ev = self.ev
+        ev[0].record()
+        # ---- A: kNN graph (analysis.py:1005) -> connectivity weights (:1006-1010) -> pooling (:1012-1013)
+        idx, dist_ = ops.knn_search(self.space, k, include_self=False, q0=c0, Q=nloc)
+        conn = (dist_ > 0).to(torch.float32)                                   # (knn > 0): zero-distance neighbours drop out
+        wrow = torch.cat([torch.ones((nloc, 1), device=self.dev), conn], 1)     # diag = 1
+        wrow = wrow / wrow.sum(1, keepdim=True)
+        indices = torch.cat([torch.arange(c0, c1, device=self.dev, dtype=torch.int32)[:, None], idx], 1).contiguous()
+        indptr = torch.arange(0, (nloc + 1) * (k + 1), k + 1, device=self.dev, dtype=torch.int64)
+        ops.knn_pool(self.S, indptr, indices, wrow.contiguous(), cell0=c0, C_out=nloc, out=self.Sx_loc, validate=False)
+        ops.knn_pool(self.U, indptr, indices, wrow.contiguous(), cell0=c0, C_out=nloc, out=self.Ux_loc, validate=False)
+        ev[1].record()
+        # ---- B: fit_slope (estimation.py:267-279); sharded: all-reduce of the per-gene moments
+        mom = ops.fit_slope_moments(self.Ux_loc, self.Sx_loc)
+        self.D.all_reduce_sum(mom)
+        gamma = ops.fit_slope_from_moments(mom)
+        ev[2].record()
+        # ---- C: predict_U -> velocity -> shift -> dmat, fused
+        dmat = ops.velocity_chain(self.Sx_loc, self.Ux_loc, gamma, None, want=("dmat",), transform=ops.SQRT, psc=1e-10)["dmat"]
+        ev[3].record()
+        # ---- D: colDeltaCorSqrtpartial; sharded: every rank needs all of e = Sx_sz
+        if self.world > 1:
+            self.D.all_gather_rows(self.Sx_loc.t, C, out=self.Sx_full.t)
+        ev[4].record()
+        ops.coldeltacor_partial(self.Sx_full, dmat, self.neigh_loc, ops.SQRT, ops.RULES_PARTIAL, 1e-10, cell0=c0,
+                                d_row0=c0, order=self.order, out=self.corr_loc, validate=False)
+        ev[5].record()
+        if self.world > 1:
+            self.D.all_gather_rows(self.corr_loc, C, out=self.corr)
+        ev[6].record()
+        if timed:
+            torch.cuda.synchronize()
+            self.stage_ms += np.array([ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3]),
+                                       ev[3].elapsed_time(ev[4]) + ev[5].elapsed_time(ev[6]), ev[4].elapsed_time(ev[5])])
+            self.d_ms.append(ev[4].elapsed_time(ev[5]))
+        return gamma
+
+
+def cpu_baseline(pipe, args):
+    """Reference kernels (oracle/_ref: velocyto/speedboosted.pyx built with its own flags) for stage D and the
+    oracle port for A-C, on a closed sub-problem of `cpu_cells` cells (all genes, same k / nrndm)."""
+    import oracle
+    Cs = min(args.cpu_cells, args.cells)
+    G = args.genes
+    cores = os.cpu_count() or 1
+    S = pipe.S.t[:Cs, :G].double().cpu().numpy().T.copy()     # (G, Cs) reference layout
+    U = pipe.U.t[:Cs, :G].double().cpu().numpy().T.copy()
+    space = pipe.space[:Cs].cpu().numpy()
+    rng = np.random.default_rng(0)
+    nr = min(pipe.nrndm, Cs - 1)
+    ixs = np.stack([rng.choice(Cs, nr, replace=False) for _ in range(Cs)]).astype(np.intp)
+    t0 = time.perf_counter()
+    _, _, Sx, Ux = oracle.knn_imputation(S, U, space, k=min(args.k, Cs - 1))
+    tA = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    gam = oracle.fit_slope(Ux, Sx)
+    tB = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    _, _, dS, _ = oracle.velocity_chain(Sx, Ux, gam, None)
+    dmat = oracle.delta_transform(Sx, Sx + dS, "sqrt", 1e-10)
+    tC = time.perf_counter() - t0
+    kind = "port"
+    ref_so = [f for f in os.listdir(os.path.join(ROOT, "oracle", "_ref"))] if os.path.isdir(os.path.join(ROOT, "oracle", "_ref")) else []
+    t0 = time.perf_counter()
+    if any(f.startswith("speedboosted") and f.endswith(".so") for f in ref_so):
+        import importlib.machinery
+        import importlib.util
+        so = os.path.join(ROOT, "oracle", "_ref", [f for f in ref_so if f.endswith(".so")][0])
+        loader = importlib.machinery.ExtensionFileLoader("speedboosted", so)
+        mod = importlib.util.module_from_spec(importlib.util.spec_from_loader("speedboosted", loader))
+        loader.exec_module(mod)
+        out = np.zeros((Cs, Cs))
+        mod._colDeltaCorSqrtpartial(np.ascontiguousarray(Sx), np.ascontiguousarray(dmat), out, ixs, cores, 1e-10)
+        kind = "reference"
+    else:
+        oracle.coldeltacor_partial_compact(Sx, dmat, ixs, "sqrt", 1e-10, threads=cores)
+    tD = time.perf_counter() - t0
+    total = tA + tB + tC + tD
+    return {"value": Cs / total, "unit": "cells/s", "cores": cores, "kind": kind,
+            "sample": f"closed sub-problem of {Cs} cells x {G} genes, k={min(args.k, Cs - 1)}, nrndm={nr}: stage D by the "
+                      f"reference's own compiled kernel ({tD:.2f} s), stages A-C by the oracle port ({tA:.2f}+{tB:.2f}+{tC:.2f} s); "
+                      "per-cell cost of D is size-independent, the O(C^2) kNN is cheaper at this size (favours the CPU)",
+            "stage_s": {"A": tA, "B": tB, "C": tC, "D": tD}}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    import velocyto_amd  # noqa: F401
+    from velocyto_amd import _lib
+    _lib.lib()   # fail loudly if the HIP library is missing
+
+    pipe = Pipeline(a, dev, rank, world)
+    for _ in range(a.warmup):
+        pipe.step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        pipe.step(timed=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / a.steps * 1e3
+
+    if rank == 0:
+        C, G, nr = a.cells, a.genes, pipe.nrndm
+        nloc = pipe.c1 - pipe.c0
+        d_ms = float(np.mean(pipe.d_ms))
+        alg_bytes = nloc * ((nr + 2) * G * 4 + nr * (4 + 4))          # (nrndm+2)*G*s + nrndm*(idx+out) per cell
+        achieved = alg_bytes / (d_ms * 1e-3)
+        stage = pipe.stage_ms / a.steps
+        res = {
+            "metric": "cells/sec through knn_imputation->fit_slope->colDeltaCor, 50k cells x 30k genes",
+            "value": C / (ms_per_step * 1e-3), "unit": "cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic {C} cells x {G} genes (BASELINE.json configs[2]): knn_imputation(k={a.k}, "
+                                   f"{a.pca_dims} PCs) -> fit_slope -> velocity chain -> colDeltaCorSqrtpartial(nrndm={nr}, "
+                                   f"n_neighbors={a.n_neighbors}, sampled_fraction={a.sampled_fraction}, psc=1e-10)",
+                       "cells": C, "genes": G, "k": a.k, "nrndm": nr,
+                       "parallelism": "single GPU" if world == 1 else f"cells sharded over {world} GPUs (RCCL all-reduce of fit "
+                                      "moments, all-gather of Sx shards and of correlation rows)",
+                       "stage_ms": {"A_knn_imputation": stage[0], "B_fit_slope": stage[1], "C_velocity_chain": stage[2],
+                                    "D_exchange": stage[3], "D_coldeltacor": stage[4]},
+                       "cell_order_D": a.order},
+            "roofline": {"bound": "hbm", "kernel": "k_cdc_partial<float, SQRT, PARTIAL>", "achieved": achieved / 1e9,
+                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+                         "traffic": a.traffic_bytes, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": d_ms},
+        }
+        if not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(pipe, a)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -65,7 +65,9 @@ int vcy_transpose(const void *src, void *dst, int64_t rows, int64_t cols, int64_
  * (speedboosted.pyx:263-538, 574-610; wrappers estimation.py:36-62, 90-116, 144-170).
  * For every cell c and every listed neighbour i = ixs[c,n]:
  *     out[c,n] = pearson_g( f(e[i,g] - e[c,g]), d[c,g] )
- * e, d: (C, ld) cells-major.  ixs: (C_out, nrndm) int32 rows for cells cell0..cell0+C_out-1.
+ * e: (C, ld) cells-major, all cells (any cell can be a neighbour).  d: cells-major rows for cells
+ * d_row0, d_row0+1, ... (d_row0 = 0 for a full matrix; a cell-sharded rank passes only its own
+ * rows with d_row0 = cell0).  ixs: (C_out, nrndm) int32 rows for cells cell0..cell0+C_out-1.
  * out : (C_out, nrndm) of `dtype` -- the COMPACT form of the reference's dense (C,C) `rm`
  * (use vcy_scatter_rows to materialise rm[c, ixs[c,n]] += out[c,n]).
  * Zero-variance columns give NaN exactly like the reference (0 * inf).
@@ -75,8 +77,8 @@ int vcy_transpose(const void *src, void *dst, int64_t rows, int64_t cols, int64_
  * `rules` = VCY_RULES_PARTIAL reproduces the *partial kernels, VCY_RULES_FULL the branch
  * rules of the full kernels on an explicit neighbour list.                                */
 int vcy_coldeltacor_partial(const void *e, const void *d, const int32_t *ixs, void *out, const int32_t *order,
-                            int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int64_t nrndm,
-                            int transform, int rules, double psc, int dtype, vcy_stream stream);
+                            int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int64_t d_row0,
+                            int64_t nrndm, int transform, int rules, double psc, int dtype, vcy_stream stream);
 
 /* speedboosted._colDeltaCor / _colDeltaCorSqrt / _colDeltaCorLog10 (speedboosted.pyx:13-257,
  * 542-572; wrappers estimation.py:11-33, 65-87, 119-141): all pairs.
@@ -108,8 +110,9 @@ int vcy_knn_pool(const void *data, void *out, const int64_t *indptr, const int32
  * neighbors.knn_distance_matrix :363-376, BalancedKNN.fit/kneighbors :239-243,282 and
  * analysis.py:1547-1549).  xt: (P, ldx) TRANSPOSED coordinates (feature-major) of all C
  * points, fp32.  x64: (C, P) row-major fp64 coordinates for the exact re-rank.
- * For queries q0..q0+Q-1 writes the k nearest (self excluded when include_self == 0, self
- * forced first otherwise), nearest first, ties by index: idx (Q,k) int32, dist (Q,k) fp64.
+ * For queries q0..q0+Q-1 writes the k nearest (the query itself excluded when include_self == 0,
+ * an ordinary distance-0 candidate otherwise), nearest first, ties by index: idx (Q,k) int32,
+ * dist (Q,k) fp64.
  * workspace: vcy_knn_workspace_bytes(C, Q) bytes.                                        */
 size_t vcy_knn_workspace_bytes(int64_t C, int64_t Q);
 int vcy_knn_search(const float *xt, const double *x64, int32_t *idx, double *dist, void *workspace,
@@ -132,6 +135,13 @@ int vcy_balance_knn_host(const int64_t *dsi_host, const double *dist_host, const
 size_t vcy_fit_workspace_bytes(int64_t G);
 int vcy_fit_slope(const void *Y, const void *X, float *gamma, void *workspace, int64_t C, int64_t G,
                   int64_t ld, int dtype, vcy_stream stream);
+
+/* The two halves of vcy_fit_slope for cell-sharded runs: each rank reduces its own cells to
+ * moments (3, G) fp64 = [sum x*x, sum x*y, sum y*y], the ranks all-reduce(sum) that 3*G vector
+ * (RCCL), and every rank finishes the fit from the global moments.                        */
+int vcy_fit_slope_moments(const void *Y, const void *X, double *moments, void *workspace, int64_t C, int64_t G,
+                          int64_t ld, int dtype, vcy_stream stream);
+int vcy_fit_slope_from_moments(const double *moments, float *gamma, int64_t G, vcy_stream stream);
 
 /* Per-gene order statistics over cells with numpy.percentile's linear interpolation
  * (analysis.py:1183-1218 use np.percentile(M, q, axis=1)).  M: (C, ld) cells-major.

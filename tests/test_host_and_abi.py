@@ -40,7 +40,7 @@ def test_no_cpu_fallback_in_product():
 
 def test_argument_validation_without_gpu(lib):
     L = lib.lib()
-    rc = L.vcy_coldeltacor_partial(None, None, None, None, None, 4, 4, 4, 0, 4, 2, 1, 1, 0.0, 0, None)
+    rc = L.vcy_coldeltacor_partial(None, None, None, None, None, 4, 4, 4, 0, 4, 0, 2, 1, 1, 0.0, 0, None)
     assert rc == -1 and b"null pointer" in L.vcy_last_error()
     rc = L.vcy_balance_knn_host(None, None, None, None, 1, 1, 1, 1, 1, None, None, None)
     assert rc == -1

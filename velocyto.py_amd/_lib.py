@@ -28,7 +28,7 @@ SIGNATURES = {
     "vcy_abi_version": (c_int, []),
     "vcy_device_info": (c_int, [ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_i64)]),
     "vcy_transpose": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp]),
-    "vcy_coldeltacor_partial": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
+    "vcy_coldeltacor_partial": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                                         c_int, c_int, c_dbl, c_int, c_vp]),
     "vcy_coldeltacor_full": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_dbl,
                                      c_int, c_int, c_vp]),
@@ -39,6 +39,8 @@ SIGNATURES = {
     "vcy_balance_knn_host": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp]),
     "vcy_fit_workspace_bytes": (c_sz, [c_i64]),
     "vcy_fit_slope": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]),
+    "vcy_fit_slope_moments": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]),
+    "vcy_fit_slope_from_moments": (c_int, [c_vp, c_vp, c_i64, c_vp]),
     "vcy_quantile_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "vcy_gene_quantiles": (c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_dbl), c_int, c_vp, c_vp, c_i64, c_i64, c_i64,
                                    c_int, c_vp]),

@@ -59,7 +59,7 @@ template <typename T, int TR, int RULES>
 __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, const T *__restrict__ d,
                                                        const int32_t *__restrict__ ixs, T *__restrict__ out,
                                                        const int32_t *__restrict__ order, int G, int64_t ld,
-                                                       int64_t cell0, int nrndm, int gchunk, T psc)
+                                                       int64_t cell0, int64_t d_row0, int nrndm, int gchunk, T psc)
 {
     using V = typename Vec<T>::type;
     constexpr int N = Vec<T>::N;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, c
     const int cl = order ? order[blockIdx.x] : (int)blockIdx.x;  // local output row
     const int64_t c = cell0 + cl;
     const T *erow_c = e + c * ld;
-    const T *drow_c = d + c * ld;
+    const T *drow_c = d + (c - d_row0) * ld;
 
     for (int n = tid; n < 3 * nrndm; n += blockDim.x) acc[n] = T(0);
     double sb = 0.0, sbb = 0.0;
@@ -282,7 +282,7 @@ static int query_device()
 
 template <typename T, int TR, int RULES>
 static int launch_partial(const void *e, const void *d, const int32_t *ixs, void *out, const int32_t *order, int64_t G,
-                          int64_t ld, int64_t cell0, int64_t C_out, int64_t nrndm, double psc, hipStream_t st)
+                          int64_t ld, int64_t cell0, int64_t C_out, int64_t d_row0, int64_t nrndm, double psc, hipStream_t st)
 {
     constexpr int N = Vec<T>::N;
     const int quantum = 64 * N;  // one wave-instruction worth of elements
@@ -300,18 +300,18 @@ static int launch_partial(const void *e, const void *d, const int32_t *ixs, void
     VCY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int threads = (nrndm >= 16) ? 1024 : (nrndm >= 8 ? 512 : 256);
     hipLaunchKernelGGL(kern, dim3((unsigned)C_out), dim3(threads), lds, st, (const T *)e, (const T *)d, ixs, (T *)out, order,
-                       (int)G, ld, cell0, (int)nrndm, (int)gchunk, (T)psc);
+                       (int)G, ld, cell0, d_row0, (int)nrndm, (int)gchunk, (T)psc);
     VCY_LAUNCH_CHECK();
     return VCY_OK;
 }
 
 template <typename T>
 static int dispatch_partial(const void *e, const void *d, const int32_t *ixs, void *out, const int32_t *order, int64_t G,
-                            int64_t ld, int64_t cell0, int64_t C_out, int64_t nrndm, int transform, int rules, double psc,
-                            hipStream_t st)
+                            int64_t ld, int64_t cell0, int64_t C_out, int64_t d_row0, int64_t nrndm, int transform, int rules,
+                            double psc, hipStream_t st)
 {
 #define VCY_CASE(TR, RU) \
-    if (transform == TR && rules == RU) return launch_partial<T, TR, RU>(e, d, ixs, out, order, G, ld, cell0, C_out, nrndm, psc, st);
+    if (transform == TR && rules == RU) return launch_partial<T, TR, RU>(e, d, ixs, out, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st);
     VCY_CASE(VCY_LINEAR, VCY_RULES_PARTIAL)
     VCY_CASE(VCY_LINEAR, VCY_RULES_FULL)
     VCY_CASE(VCY_SQRT, VCY_RULES_PARTIAL)
@@ -346,20 +346,21 @@ static int dispatch_full(const void *e, const void *d, void *rm, int64_t C, int6
 using namespace vcy;
 
 extern "C" int vcy_coldeltacor_partial(const void *e, const void *d, const int32_t *ixs, void *out, const int32_t *order,
-                                       int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int64_t nrndm,
-                                       int transform, int rules, double psc, int dtype, vcy_stream stream)
+                                       int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int64_t d_row0,
+                                       int64_t nrndm, int transform, int rules, double psc, int dtype, vcy_stream stream)
 {
     VCY_REQUIRE(e && d && ixs && out, "coldeltacor_partial: null pointer");
     VCY_REQUIRE(C > 0 && G > 0 && nrndm > 0 && C_out > 0 && cell0 >= 0 && cell0 + C_out <= C, "coldeltacor_partial: bad shape");
     VCY_REQUIRE(ld >= G, "coldeltacor_partial: ld < G");
+    VCY_REQUIRE(d_row0 >= 0 && d_row0 <= cell0, "coldeltacor_partial: d must cover cells cell0..cell0+C_out-1");
     VCY_REQUIRE(dtype == VCY_F32 || dtype == VCY_F64, "coldeltacor_partial: bad dtype");
     VCY_REQUIRE(ld % (dtype == VCY_F32 ? 4 : 2) == 0, "coldeltacor_partial: ld must keep rows 16-byte aligned");
     VCY_REQUIRE(((uintptr_t)e % 16 == 0) && ((uintptr_t)d % 16 == 0), "coldeltacor_partial: e/d must be 16-byte aligned");
     int rc = query_device();
     if (rc) return rc;
     hipStream_t st = as_stream(stream);
-    if (dtype == VCY_F32) return dispatch_partial<float>(e, d, ixs, out, order, G, ld, cell0, C_out, nrndm, transform, rules, psc, st);
-    return dispatch_partial<double>(e, d, ixs, out, order, G, ld, cell0, C_out, nrndm, transform, rules, psc, st);
+    if (dtype == VCY_F32) return dispatch_partial<float>(e, d, ixs, out, order, G, ld, cell0, C_out, d_row0, nrndm, transform, rules, psc, st);
+    return dispatch_partial<double>(e, d, ixs, out, order, G, ld, cell0, C_out, d_row0, nrndm, transform, rules, psc, st);
 }
 
 extern "C" int vcy_coldeltacor_full(const void *e, const void *d, void *rm, int64_t C, int64_t G, int64_t ld, int64_t cell0,

@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256) void k_moments_plain(const T *__restrict__ Y, 
     }
 }
 
-// estimation.py:173-188: not any(x) -> NaN; not any(y) -> 0; else nnls == max(0, <x,y>/<x,x>).
-__global__ void k_fit_slope_final(const double *__restrict__ part, float *__restrict__ gamma, int G)
+// fixed-order reduction of the FIT_CB per-block partials -> moments (3, G)
+__global__ void k_fit_slope_reduce(const double *__restrict__ part, double *__restrict__ mom, int G)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
@@ -83,6 +83,15 @@ __global__ void k_fit_slope_final(const double *__restrict__ part, float *__rest
         const double *p = part + ((int64_t)cb * 3) * G + g;
         sxx += p[0]; sxy += p[(int64_t)G]; syy += p[2 * (int64_t)G];
     }
+    mom[g] = sxx; mom[(int64_t)G + g] = sxy; mom[2 * (int64_t)G + g] = syy;
+}
+
+// estimation.py:173-188: not any(x) -> NaN; not any(y) -> 0; else nnls == max(0, <x,y>/<x,x>).
+__global__ void k_fit_slope_final(const double *__restrict__ mom, float *__restrict__ gamma, int G)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const double sxx = mom[g], sxy = mom[(int64_t)G + g], syy = mom[2 * (int64_t)G + g];
     double m;
     if (!(sxx > 0)) m = NAN;
     else if (!(syy > 0)) m = 0.0;
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(256) void k_gene_quantiles(const T *__restrict__ Z,
     const int g = blockIdx.x, tid = threadIdx.x;
     const T *row = Z + (int64_t)g * C;
     for (int qi = 0; qi < nq; ++qi) {
-        const double h = (double)(C - 1) * qa.q[qi] / 100.0;
+        const double h = __dmul_rn((double)(C - 1), qa.q[qi] / 100.0);   // numpy: (n-1) * (q/100)
         const int lo = (int)floor(h);
         const double t = h - lo;
         U prefix = 0;
@@ -336,9 +345,10 @@ __global__ __launch_bounds__(256) void k_gene_quantiles(const T *__restrict__ Z,
         if (tid == 0) {
             T vhi = vlo;
             if (lo + 1 < C && s_cnt_le < (unsigned)(lo + 2)) vhi = Key<T>::dec((U)s_min_gt);
-            const double a = (double)vlo, b = (double)vhi, diff = b - a;
-            double r = a + diff * t;
-            if (t >= 0.5) r = b - diff * (1.0 - t);
+            // numpy _lerp, without fma contraction so the rounding matches numpy's mul-then-add
+            const double a = (double)vlo, b = (double)vhi, diff = __dsub_rn(b, a);
+            double r = __dadd_rn(a, __dmul_rn(diff, t));
+            if (t >= 0.5) r = __dsub_rn(b, __dmul_rn(diff, __dsub_rn(1.0, t)));
             if (t == 0.0) r = a;
             out[(int64_t)qi * G + g] = r;
         }
@@ -352,23 +362,42 @@ using namespace vcy;
 
 extern "C" size_t vcy_fit_workspace_bytes(int64_t G) { return (size_t)FIT_CB * FIT_NMOM * (size_t)G * sizeof(double); }
 
-extern "C" int vcy_fit_slope(const void *Y, const void *X, float *gamma, void *workspace, int64_t C, int64_t G, int64_t ld,
-                             int dtype, vcy_stream stream)
+extern "C" int vcy_fit_slope_moments(const void *Y, const void *X, double *moments, void *workspace, int64_t C, int64_t G,
+                                     int64_t ld, int dtype, vcy_stream stream)
 {
-    VCY_REQUIRE(Y && X && gamma && workspace, "fit_slope: null pointer");
-    VCY_REQUIRE(C > 0 && G > 0 && ld >= G, "fit_slope: bad shape");
-    VCY_REQUIRE(dtype == VCY_F32 || dtype == VCY_F64, "fit_slope: bad dtype");
+    VCY_REQUIRE(Y && X && moments && workspace, "fit_slope_moments: null pointer");
+    VCY_REQUIRE(C > 0 && G > 0 && ld >= G, "fit_slope_moments: bad shape");
+    VCY_REQUIRE(dtype == VCY_F32 || dtype == VCY_F64, "fit_slope_moments: bad dtype");
     const int N = dtype == VCY_F32 ? 4 : 2;
-    VCY_REQUIRE(ld % N == 0, "fit_slope: ld must keep rows 16-byte aligned");
+    VCY_REQUIRE(ld % N == 0, "fit_slope_moments: ld must keep rows 16-byte aligned");
     hipStream_t st = as_stream(stream);
     const int nvec = (int)((G + N - 1) / N);
     dim3 grid((unsigned)((nvec + 255) / 256), FIT_CB);
     if (dtype == VCY_F32) hipLaunchKernelGGL(k_moments_plain<float>, grid, dim3(256), 0, st, (const float *)Y, (const float *)X, (double *)workspace, (int)C, (int)G, ld);
     else hipLaunchKernelGGL(k_moments_plain<double>, grid, dim3(256), 0, st, (const double *)Y, (const double *)X, (double *)workspace, (int)C, (int)G, ld);
     VCY_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_fit_slope_final, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, (const double *)workspace, gamma, (int)G);
+    hipLaunchKernelGGL(k_fit_slope_reduce, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, (const double *)workspace, moments, (int)G);
     VCY_LAUNCH_CHECK();
     return VCY_OK;
+}
+
+extern "C" int vcy_fit_slope_from_moments(const double *moments, float *gamma, int64_t G, vcy_stream stream)
+{
+    VCY_REQUIRE(moments && gamma && G > 0, "fit_slope_from_moments: bad arguments");
+    hipLaunchKernelGGL(k_fit_slope_final, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, as_stream(stream), moments, gamma, (int)G);
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}
+
+extern "C" int vcy_fit_slope(const void *Y, const void *X, float *gamma, void *workspace, int64_t C, int64_t G, int64_t ld,
+                             int dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(Y && X && gamma && workspace, "fit_slope: null pointer");
+    // partials use FIT_CB*3*G doubles of the FIT_CB*FIT_NMOM*G workspace; the reduced moments sit behind them
+    double *mom = (double *)workspace + (size_t)FIT_CB * 3 * (size_t)G;
+    int rc = vcy_fit_slope_moments(Y, X, mom, workspace, C, G, ld, dtype, stream);
+    if (rc) return rc;
+    return vcy_fit_slope_from_moments(mom, gamma, G, stream);
 }
 
 extern "C" int vcy_fit_weighted(const void *Y, const void *X, int weight_mode, const void *W, const void *M, const void *M2,

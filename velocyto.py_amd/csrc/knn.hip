@@ -14,7 +14,9 @@
 //            deterministic; gather them, recompute their distances exactly in fp64, bitonic-
 //            sort (fp64 distance, index) in LDS and emit the first k.
 // The fp32 pass only has to get the candidate SET right (margin of 8 near-ties); order and
-// returned distances are fp64, matching the reference's fp64 search up to exact ties.
+// returned distances are fp64, matching the reference's fp64 search up to exact ties (which
+// sklearn orders arbitrarily and this kernel orders by index; with include_self the query is an
+// ordinary candidate at distance 0).
 #include <math.h>
 #include "common.h"
 
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
         for (int qq = 0; qq < KNN_QB; ++qq) {
             if (qq < nq) {
                 float v = acc[qq];
-                if ((int64_t)j == q0 + qb0 + qq) v = include_self ? -1.f : INFINITY;
+                if (!include_self && (int64_t)j == q0 + qb0 + qq) v = INFINITY;   // query excluded (kneighbors_graph(X=None))
                 wrow[(int64_t)qq * C + j] = v;
             }
         }
@@ -132,7 +134,6 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
             double d2 = 0.0;
             const double *a = x64 + qcell * P, *b = x64 + (int64_t)j * P;
             for (int p = 0; p < P; ++p) { const double df = a[p] - b[p]; d2 = fma(df, df, d2); }
-            if ((int64_t)j == qcell) d2 = -1.0;   // include_self: own cell sorts first
             sd[t] = d2;
         }
         __syncthreads();
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
         for (int t = tid; t < k; t += 256) {
             idx_out[(int64_t)(qb0 + qq) * k + t] = si[t];
             const double d2 = sd[t];
-            dist_out[(int64_t)(qb0 + qq) * k + t] = d2 < 0.0 ? 0.0 : sqrt(d2);
+            dist_out[(int64_t)(qb0 + qq) * k + t] = sqrt(d2);
         }
         __syncthreads();
     }

@@ -13,9 +13,6 @@ template <> __device__ __forceinline__ double vsqrt<double>(double x) { return s
 template <typename T> __device__ __forceinline__ T vlog10(T x);
 template <> __device__ __forceinline__ float vlog10<float>(float x) { return __builtin_amdgcn_logf(x) * 0.30102999566398120f; }
 template <> __device__ __forceinline__ double vlog10<double>(double x) { return log10(x); }
-template <typename T> __device__ __forceinline__ T vexp(T x);
-template <> __device__ __forceinline__ float vexp<float>(float x) { return __expf(x); }
-template <> __device__ __forceinline__ double vexp<double>(double x) { return exp(x); }
 
 struct VelArgs {
     const void *Sx, *Ux;
@@ -70,8 +67,11 @@ template <typename T> __global__ __launch_bounds__(256) void k_velocity_chain(Ve
                 else {                                             // :1403-1406
                     T uo = u - qq;
                     uo = uo < T(0) ? T(0) : uo;
-                    const T egt = vexp<T>(-gm * (T)a.dt_shift);
-                    ds = s * egt + (T(1) - egt) * uo / gm - s;
+                    // the reference forms exp(-gammas*dt) and (1 - egt) in FLOAT32 (gammas is a float32
+                    // array and numpy keeps float32 for array*python-scalar) before mixing with fp64 data
+                    const float egt32 = expf(-(a.gamma[g] * (float)a.dt_shift));
+                    const T egt = (T)egt32, omegt = (T)(1.0f - egt32);
+                    ds = s * egt + omegt * uo / gm - s;
                 }
                 st = s + (T)a.dt_extrap * ds;                      // :1429
                 if (a.clip) st = st < T(0) ? T(0) : st;            // :1431

@@ -149,12 +149,16 @@ def _as_i32(ixs, dev) -> torch.Tensor:
 
 # --------------------------------------------------------------------------- stage D
 def coldeltacor_partial(e: CellMatrix, d: CellMatrix, ixs, transform: int, rules: int = RULES_PARTIAL, psc: float = 0.0,
-                        cell0: int = 0, order: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Compact correlations out[c, n] = corr(cell0 + c, ixs[c, n]); ixs: (C_out, nrndm)."""
-    assert e.t.shape == d.t.shape and e.dtype == d.dtype and e.G == d.G
+                        cell0: int = 0, order: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                        d_row0: int = 0, validate: bool = True) -> torch.Tensor:
+    """Compact correlations out[c, n] = corr(cell0 + c, ixs[c, n]); ixs: (C_out, nrndm).
+    `d` may hold only the rows of cells d_row0.. (cell-sharded runs); `validate` range-checks ixs
+    (a device->host sync; hot loops that built ixs themselves pass False)."""
+    assert e.ld == d.ld and e.dtype == d.dtype and e.G == d.G
     ix = _as_i32(ixs, e.t.device)
     C_out, nrndm = ix.shape
-    if ix.numel() and (int(ix.min()) < 0 or int(ix.max()) >= e.C):
+    assert d_row0 <= cell0 and cell0 + C_out <= d_row0 + d.C
+    if validate and ix.numel() and (int(ix.min()) < 0 or int(ix.max()) >= e.C):
         raise ValueError("neighbour index out of range")
     if out is None:
         out = torch.empty((C_out, nrndm), dtype=e.dtype, device=e.t.device)
@@ -162,8 +166,8 @@ def coldeltacor_partial(e: CellMatrix, d: CellMatrix, ixs, transform: int, rules
         order = order.to(device=e.t.device, dtype=torch.int32).contiguous()
         assert order.numel() == C_out
     _lib.check(_lib.lib().vcy_coldeltacor_partial(e.t.data_ptr(), d.t.data_ptr(), ix.data_ptr(), out.data_ptr(), _p(order),
-                                                  e.C, e.G, e.ld, cell0, C_out, nrndm, transform, rules, float(psc), e.code,
-                                                  _stream()), "coldeltacor_partial")
+                                                  e.C, e.G, e.ld, cell0, C_out, d_row0, nrndm, transform, rules, float(psc),
+                                                  e.code, _stream()), "coldeltacor_partial")
     return out
 
 
@@ -195,7 +199,8 @@ def scatter_rows(vals: torch.Tensor, ixs, ncols: int, rm: Optional[torch.Tensor]
 
 # --------------------------------------------------------------------------- stage A
 def knn_pool(data: CellMatrix, indptr, indices, weights, maximum: bool = False, cell0: int = 0,
-             C_out: Optional[int] = None, slab_genes: int = 0, out: Optional[CellMatrix] = None) -> CellMatrix:
+             C_out: Optional[int] = None, slab_genes: int = 0, out: Optional[CellMatrix] = None,
+             validate: bool = True) -> CellMatrix:
     """out[c,:] = sum_p w[p] data[indices[p],:] over CSR row c (neighbors.py:416-423 on device)."""
     dev = data.t.device
     C_out = data.C - cell0 if C_out is None else C_out
@@ -203,7 +208,7 @@ def knn_pool(data: CellMatrix, indptr, indices, weights, maximum: bool = False, 
     ix = _as_i32(indices, dev)
     w = (weights if isinstance(weights, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(weights))).to(device=dev, dtype=data.dtype).contiguous()
     assert ip.numel() == C_out + 1 and ix.numel() == w.numel()
-    if ix.numel() and (int(ix.min()) < 0 or int(ix.max()) >= data.C):
+    if validate and ix.numel() and (int(ix.min()) < 0 or int(ix.max()) >= data.C):
         raise ValueError("neighbour index out of range")
     if out is None:
         out = CellMatrix.empty(C_out, data.G, data.dtype)
@@ -276,6 +281,21 @@ def fit_slope(Y: CellMatrix, X: CellMatrix) -> torch.Tensor:
     gamma = torch.empty(Y.G, dtype=torch.float32, device=Y.t.device)
     ws = _fit_workspace(Y.G, Y.t.device)
     _lib.check(_lib.lib().vcy_fit_slope(Y.t.data_ptr(), X.t.data_ptr(), gamma.data_ptr(), ws.data_ptr(), Y.C, Y.G, Y.ld, Y.code, _stream()), "fit_slope")
+    return gamma
+
+
+def fit_slope_moments(Y: CellMatrix, X: CellMatrix) -> torch.Tensor:
+    """(3, G) fp64 [sum xx, sum xy, sum yy] over this matrix's cells (all-reduce these across ranks)."""
+    mom = torch.empty((3, Y.G), dtype=torch.float64, device=Y.t.device)
+    ws = _fit_workspace(Y.G, Y.t.device)
+    _lib.check(_lib.lib().vcy_fit_slope_moments(Y.t.data_ptr(), X.t.data_ptr(), mom.data_ptr(), ws.data_ptr(), Y.C, Y.G, Y.ld, Y.code, _stream()), "fit_slope_moments")
+    return mom
+
+
+def fit_slope_from_moments(mom: torch.Tensor) -> torch.Tensor:
+    G = mom.shape[1]
+    gamma = torch.empty(G, dtype=torch.float32, device=mom.device)
+    _lib.check(_lib.lib().vcy_fit_slope_from_moments(mom.contiguous().data_ptr(), gamma.data_ptr(), G, _stream()), "fit_slope_from_moments")
     return gamma
 
 
