@@ -148,9 +148,14 @@ int vcy_fit_slope_from_moments(const double *moments, float *gamma, int64_t G, v
  * qs_host: nq percentiles in [0,100] (host array).  out: (nq, G) fp64.
  * If scale_a/scale_b (G, fp64) are non-NULL the statistic is taken of
  *     M[c,g]/scale_a[g] + M2[c,g]/scale_b[g]      (the maxmin_diag sum, analysis.py:1203-1206).
+ * Conditional percentiles (estimation.py:200-202, 222, 229-231, 255: y[x > percentile(x,90)],
+ * y[x <= percentile(x,1)]): mask_mode 1 keeps cells with mask_src[c,g] > mask_thr[g], 2 keeps
+ * mask_src[c,g] <= mask_thr[g], 0 = no mask (mask_src, mask_thr NULL); a gene with no cell kept
+ * gives NaN.
  * workspace: vcy_quantile_workspace_bytes(C, G).                                         */
 size_t vcy_quantile_workspace_bytes(int64_t C, int64_t G);
 int vcy_gene_quantiles(const void *M, const void *M2, const double *scale_a, const double *scale_b,
+                       const void *mask_src, const double *mask_thr, int mask_mode,
                        const double *qs_host, int nq, double *out, void *workspace, int64_t C, int64_t G,
                        int64_t ld, int dtype, vcy_stream stream);
 
@@ -188,6 +193,67 @@ int vcy_velocity_chain(const void *Sx_sz, const void *Ux_sz, const float *gamma,
                        void *dmat, int64_t C, int64_t G, int64_t ld, double dt_shift, double dt_extrap,
                        double used_dt, int assumption, int clip, int transform, double psc, int dtype,
                        vcy_stream stream);
+
+/* The non-default weight constructions of VelocytoLoom.fit_gammas (analysis.py:1182-1192,
+ * 1208-1219), materialised densely for vcy_fit_weighted(weight_mode 0).  Per-gene fp64 vectors:
+ *   mode 0 "sum"   W = S/pa + U/pb            mode 1 "prod"  W = (S/pa)*(U/pb)
+ *   mode 2 "maxmin_weighted"  R = (clip(S,pa,pb)-pa)/(pb-pa), W = 0.5 (R^power + (1-R)^power)
+ *   mode 3 "maxmin_double"    W = [Z<=pa | Z>=pb] + [S<=pc | S>=pd],  Z = S/sa + U/sb          */
+int vcy_gamma_weights(const void *S, const void *U, void *W, const double *pa, const double *pb, const double *pc,
+                      const double *pd, const double *sa, const double *sb, int64_t C, int64_t G, int64_t ld, int mode,
+                      double power, int dtype, vcy_stream stream);
+
+/* ---------------------------------------------------------------- pre-step a1: normalisation
+ * VelocytoLoom._normalize_S/_normalize_U/_normalize_Sx/_normalize_Ux (analysis.py:535-631):
+ * cell_size = M.sum(over genes) per cell;  out_sz = factor[c]*M (non-finite -> 0 when
+ * fix_nonfinite, :580);  out_norm = log2(out_sz + pcount).  out_sz / out_norm may be NULL;
+ * factor NULL = 1 (size=False).                                                            */
+int vcy_row_sums(const void *M, double *out, int64_t C, int64_t G, int64_t ld, int dtype, vcy_stream stream);
+int vcy_scale_log(const void *M, const double *factor, void *out_sz, void *out_norm, int64_t C, int64_t G, int64_t ld,
+                  double pcount, int fix_nonfinite, int dtype, vcy_stream stream);
+
+/* ---------------------------------------------------------------- estimate_transition_prob helpers
+ * dmat (and, for logratio, the transformed expression e_out) from a STORED delta_S
+ * (analysis.py:1538, 1575-1601, 1637-1663): hi_dim_t = hi_dim + used_dt*delta_S;
+ * mode 0 linear: dmat = hi_dim_t - hi_dim; 1 sqrt / 2 log10: sign(D) f(|D| + psc);
+ * 3 logratio: e_out = log2(hi_dim + psc), dmat = log2(|hi_dim_t| + psc) - e_out.          */
+int vcy_delta_transform(const void *hi_dim, const void *delta_S, void *dmat, void *e_out, int64_t C, int64_t G, int64_t ld,
+                        double used_dt, int mode, double psc, int dtype, vcy_stream stream);
+/* np.fill_diagonal(corrcoef, 0) and corrcoef[isnan] = nan_to (analysis.py:1604-1612, 1666-1668) on
+ * the compact (C_out, nrndm) form; nan_count (device int, may be NULL) counts the NaNs seen.  */
+int vcy_corr_fixup(void *vals, const int32_t *ixs, int64_t cell0, int64_t C_out, int64_t nrndm, int zero_self, int fix_nan,
+                   double nan_to, int *nan_count, int dtype, vcy_stream stream);
+
+/* ---------------------------------------------------------------- stage E: calculate_embedding_shift
+ * (analysis.py:1670-1733) in neighbour-list form.  corr, ixs: (C_out, n) compact correlations and
+ * the embedding_knn non-zeros of each row; embedding: (C, edim <= 4) fp64.
+ *   tp[c,k]    = exp(corr/sigma) / sum_k exp(corr/sigma)          (transition_prob non-zeros)
+ *   wdiff[c,k] = tp[c,k] - 1/n                                    (pooling weights of :1716)
+ *   delta_embedding[c,:] = sum_k wdiff[c,k] * unit(emb[ixs[c,k]] - emb[c])     (:1704-1712)
+ * tp / wdiff may be NULL.  expression_scaling = vcy_knn_pool with wdiff, then
+ * vcy_row_cosproj(delta_S, estim_delta): out[c] = <a_c, b_c> / |b_c|  (:1717).              */
+int vcy_transition_prob(const void *corr, const int32_t *ixs, const double *embedding, int edim, void *tp, void *wdiff,
+                        double *delta_embedding, int64_t cell0, int64_t C_out, int64_t n, double sigma_corr, int dtype,
+                        vcy_stream stream);
+int vcy_row_cosproj(const void *A, const void *B, double *out, int64_t C, int64_t G, int64_t ld, int dtype, vcy_stream stream);
+
+/* ---------------------------------------------------------------- stage F: prepare_markov
+ * VelocytoLoom.prepare_markov (analysis.py:1818-1863) with cells_ixs=None: dense (n, n) Markov
+ * matrix tr = rownorm(0.8 rownorm(P*K_D, diag := row max) + 0.2 rownorm(K_W)).  P as CSR
+ * (indptr, indices, fp64 values): transition_prob for "forward", its transpose for "backwards".
+ * embedding (n, edim <= 4) fp64; tr (n, n) of `dtype`.                                      */
+int vcy_prepare_markov(const int64_t *indptr, const int32_t *indices, const double *pval, const double *embedding, int edim,
+                       void *tr, int64_t n, double sigma_D, double sigma_W, int dtype, vcy_stream stream);
+
+/* ---------------------------------------------------------------- stage F: Diffusion.diffuse step
+ * (diffusion.py:93-105): y = x . tr, optionally accum += y (path_integral).  tr dense row-major
+ * (n, n) of `dtype`, or CSC (column pointers / row indices / values) for sparse matrices;
+ * x, y, accum fp64 (n).  workspace: vcy_diffuse_workspace_bytes(n).                        */
+size_t vcy_diffuse_workspace_bytes(int64_t n);
+int vcy_diffuse_step_dense(const void *tr, const double *x, double *y, double *accum, void *workspace, int64_t n, int dtype,
+                           vcy_stream stream);
+int vcy_diffuse_step_csc(const int64_t *colptr, const int32_t *rowidx, const void *val, const double *x, double *y,
+                         double *accum, int64_t n, int dtype, vcy_stream stream);
 
 #ifdef __cplusplus
 }

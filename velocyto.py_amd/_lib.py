@@ -42,8 +42,19 @@ SIGNATURES = {
     "vcy_fit_slope_moments": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]),
     "vcy_fit_slope_from_moments": (c_int, [c_vp, c_vp, c_i64, c_vp]),
     "vcy_quantile_workspace_bytes": (c_sz, [c_i64, c_i64]),
-    "vcy_gene_quantiles": (c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_dbl), c_int, c_vp, c_vp, c_i64, c_i64, c_i64,
-                                   c_int, c_vp]),
+    "vcy_gene_quantiles": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, ctypes.POINTER(c_dbl), c_int, c_vp, c_vp, c_i64,
+                                   c_i64, c_i64, c_int, c_vp]),
+    "vcy_gamma_weights": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_dbl, c_int, c_vp]),
+    "vcy_prepare_markov": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_dbl, c_dbl, c_int, c_vp]),
+    "vcy_row_sums": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]),
+    "vcy_scale_log": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_dbl, c_int, c_int, c_vp]),
+    "vcy_delta_transform": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_dbl, c_int, c_dbl, c_int, c_vp]),
+    "vcy_corr_fixup": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_dbl, c_vp, c_int, c_vp]),
+    "vcy_transition_prob": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_dbl, c_int, c_vp]),
+    "vcy_row_cosproj": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]),
+    "vcy_diffuse_workspace_bytes": (c_sz, [c_i64]),
+    "vcy_diffuse_step_dense": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),
+    "vcy_diffuse_step_csc": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),
     "vcy_fit_weighted": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_dbl, c_dbl,
                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]),
     "vcy_velocity_chain": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64,

@@ -1,0 +1,572 @@
+"""Drop-in for the numeric methods of ``velocyto.analysis.VelocytoLoom`` (analysis.py:26-2342).
+
+Same method names, keyword arguments, defaults and attribute names as the reference; every
+(genes x cells) matrix attribute lives on the MI355X as a cells-major ``ops.CellMatrix`` and is
+converted to the reference's numpy ``(genes, cells)`` float64 array only when it is read
+(``vlm.Sx``) - assigning a numpy array to such an attribute uploads it.  All hot loops are the HIP
+kernels of libvelocyto_hip.so; nothing falls back to the CPU.
+
+Covered: normalize/_normalize_*, knn_imputation[_precomputed], fit_gammas (all
+weight modes and fit branches), predict_U, calculate_velocity, calculate_shift,
+extrapolate_cell_at_t, estimate_transition_prob (knn_random and full, four transforms, randomised
+control), calculate_embedding_shift, prepare_markov, run_markov.  Filtering / plotting / PCA / t-SNE
+are outside the path (``pcs`` / ``ts`` are inputs; ``perform_PCA`` is a scikit-learn pass-through).
+
+Known, deliberate differences from the reference (each has a test):
+  * matrices are accepted in any memory order (the reference's F-order trap is gone);
+  * ``corrcoef`` / ``transition_prob`` are kept compact (cells x neighbours) on the device and
+    densified to (cells, cells) only when the attribute is read;
+  * default weighted fit = exact box-constrained least squares instead of L-BFGS-B's stopping point;
+  * ``permute_rows_nsign`` (randomised control) draws from torch's device RNG: statistical parity only,
+    as with the reference's numba RNG.
+"""
+from __future__ import annotations
+
+import logging
+import warnings
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+from scipy import sparse
+
+from . import ops
+from .diffusion import Diffusion
+from .neighbors import BalancedKNN, connectivity_to_weights, knn_distance_matrix
+from .ops import CellMatrix
+
+_MATRIX_ATTRS = frozenset(["S", "U", "A", "S_sz", "U_sz", "S_norm", "U_norm", "Sx", "Ux", "Sx_sz", "Ux_sz", "Sx_norm", "Ux_norm",
+                           "Upred", "velocity", "delta_S", "delta_S_rndm", "Sx_sz_t", "Sx_t"])
+_LAZY_DENSE = frozenset(["corrcoef", "corrcoef_random", "transition_prob", "transition_prob_random", "tr"])
+
+
+class VelocytoLoom:
+    """Device-resident counterpart of velocyto.VelocytoLoom (analysis.py:26-94).
+
+    ``VelocytoLoom(loom_filepath)`` reads a .loom file (needs loompy or h5py);
+    ``VelocytoLoom.from_arrays(S, U, A=None, ca=None, ra=None)`` starts from in-memory layers."""
+
+    def __init__(self, loom_filepath: str = None, dtype=None) -> None:
+        object.__setattr__(self, "_dev", {})
+        object.__setattr__(self, "_host", {})
+        object.__setattr__(self, "_dtype", ops.resolve_dtype(dtype))
+        if loom_filepath is not None:
+            from .loom_io import read_loom
+            self.loom_filepath = loom_filepath
+            layers, ca, ra = read_loom(loom_filepath)                 # analysis.py:56-64
+            self._init_layers(layers["spliced"], layers["unspliced"], layers.get("ambiguous"), ca, ra)
+
+    @classmethod
+    def from_arrays(cls, S, U, A=None, ca: Dict = None, ra: Dict = None, dtype=None) -> "VelocytoLoom":
+        self = cls(None, dtype=dtype)
+        self._init_layers(S, U, A, ca, ra)
+        return self
+
+    def _init_layers(self, S, U, A, ca, ra) -> None:
+        self.S = S
+        self.U = U
+        if A is not None:
+            self.A = A
+        self.ca = dict(ca) if ca is not None else {"CellID": np.arange(self.dev("S").C)}
+        self.ra = dict(ra) if ra is not None else {"Gene": np.arange(self.dev("S").G)}
+        self.initial_cell_size = ops.row_sums(self.dev("S")).cpu().numpy()      # analysis.py:66-67
+        self.initial_Ucell_size = ops.row_sums(self.dev("U")).cpu().numpy()
+
+    # ------------------------------------------------------------------ attribute plumbing
+    def dev(self, name: str) -> CellMatrix:
+        """The device matrix behind a (genes x cells) attribute."""
+        try:
+            return self._dev[name]
+        except KeyError:
+            raise AttributeError(f"{name} has not been computed yet") from None
+
+    def __getattr__(self, name: str):
+        if name in _MATRIX_ATTRS:
+            d = object.__getattribute__(self, "_dev")
+            if name in d:
+                h = object.__getattribute__(self, "_host")
+                if name not in h:
+                    h[name] = d[name].to_genes_major(order="F")      # same values/strides the reference ends up with
+                return h[name]
+        elif name in _LAZY_DENSE:
+            return self._densify(name)
+        raise AttributeError(f"'{type(self).__name__}' object has no attribute '{name}'")
+
+    def __setattr__(self, name: str, value) -> None:
+        if name in _MATRIX_ATTRS:
+            self._host.pop(name, None)
+            self._dev[name] = value if isinstance(value, CellMatrix) else CellMatrix.from_genes_major(np.asarray(value), self._dtype)
+        else:
+            object.__setattr__(self, name, value)
+
+    def __delattr__(self, name: str) -> None:
+        if name in _MATRIX_ATTRS:
+            self._dev.pop(name)
+            self._host.pop(name, None)
+        else:
+            object.__delattr__(self, name)
+
+    def _set_dev(self, name: str, m: CellMatrix) -> None:
+        self._host.pop(name, None)
+        self._dev[name] = m
+
+    def _densify(self, name: str):
+        """(cells, cells) numpy views of the compact device results (read-only convenience)."""
+        st = self.__dict__
+        if name in ("corrcoef", "corrcoef_random"):
+            key = "_corr" + ("_random" if name.endswith("random") else "")
+            if key not in st:
+                raise AttributeError(name)
+            v = st[key]
+            if v.shape[1] == v.shape[0] and st.get("corr_calc") == "full":
+                return v.double().cpu().numpy()
+            return ops.scatter_rows(v, st["_neigh"], v.shape[0]).double().cpu().numpy()
+        if name in ("transition_prob", "transition_prob_random"):
+            key = "_tp" + ("_random" if name.endswith("random") else "")
+            if key not in st:
+                raise AttributeError(name)
+            return ops.scatter_rows(st[key], st["_tp_ixs"], st[key].shape[0]).double().cpu().numpy()
+        if name == "tr":
+            if "_tr_dev" not in st:
+                raise AttributeError(name)
+            return sparse.csr_matrix(st["_tr_dev"].double().cpu().numpy())
+        raise AttributeError(name)
+
+    # ------------------------------------------------------------------ a1 normalisation
+    def _size_factor(self, M: CellMatrix, relative_size, target_size) -> Tuple[torch.Tensor, torch.Tensor, float]:
+        cell_size = ops.row_sums(M) if relative_size is None else torch.as_tensor(np.asarray(relative_size, dtype=np.float64), device=M.t.device)
+        avg = float(cell_size.mean()) if target_size is None else float(target_size)
+        return cell_size, avg / cell_size, avg
+
+    def _normalize_S(self, size: bool = True, log: bool = True, pcount: float = 1, relative_size: Any = None, target_size: Any = None) -> None:
+        """analysis.py:535-551."""
+        S = self.dev("S")
+        if size:
+            rel = relative_size if type(relative_size) is np.ndarray else None
+            cs, fac, avg = self._size_factor(S, rel, target_size)
+            self.cell_size, self.avg_size, self.norm_factor = cs.cpu().numpy(), avg, fac.cpu().numpy()
+        else:
+            fac, self.norm_factor = None, 1
+        sz, nm = ops.scale_log(S, fac, True, log, pcount)
+        self._set_dev("S_sz", sz)
+        if log:
+            self._set_dev("S_norm", nm)
+
+    def _normalize_U(self, size: bool = True, log: bool = True, pcount: float = 1, use_S_size: bool = False,
+                     relative_size: np.ndarray = None, target_size: Any = None) -> None:
+        """analysis.py:553-582."""
+        U = self.dev("U")
+        if size:
+            if use_S_size:
+                rel = self.cell_size if hasattr(self, "cell_size") else ops.row_sums(self.dev("S")).cpu().numpy()
+            elif type(relative_size) is np.ndarray:
+                rel = relative_size
+            else:
+                rel = None
+            cs, fac, avg = self._size_factor(U, rel, target_size)
+            self.Ucell_size, self.Uavg_size, self.Unorm_factor = cs.cpu().numpy(), avg, fac.cpu().numpy()
+        else:
+            fac, self.Unorm_factor = None, 1
+        sz, nm = ops.scale_log(U, fac, True, log, pcount, fix_nonfinite=True)
+        self._set_dev("U_sz", sz)
+        if log:
+            self._set_dev("U_norm", nm)
+
+    def _normalize_Sx(self, size: bool = True, log: bool = True, pcount: float = 1, relative_size: Any = None, target_size: Any = None) -> None:
+        """analysis.py:584-600."""
+        Sx = self.dev("Sx")
+        if size:
+            cs, fac, avg = self._size_factor(Sx, relative_size if relative_size is not None and np.size(relative_size) > 0 and np.any(relative_size) else None, target_size)
+            self.xcell_size, self.xavg_size, self.xnorm_factor = cs.cpu().numpy(), avg, fac.cpu().numpy()
+        else:
+            fac, self.xnorm_factor = None, 1
+        sz, nm = ops.scale_log(Sx, fac, True, log, pcount)
+        self._set_dev("Sx_sz", sz)
+        if log:
+            self._set_dev("Sx_norm", nm)
+
+    def _normalize_Ux(self, size: bool = True, log: bool = True, pcount: float = 1, use_Sx_size: bool = False, relative_size: Any = None,
+                      target_size: Any = None) -> None:
+        """analysis.py:602-631."""
+        Ux = self.dev("Ux")
+        if size:
+            if use_Sx_size:
+                rel = self.xcell_size if hasattr(self, "cell_size") else ops.row_sums(self.dev("Sx")).cpu().numpy()
+            elif type(relative_size) is np.ndarray:
+                rel = relative_size
+            else:
+                rel = None
+            cs, fac, avg = self._size_factor(Ux, rel, target_size)
+            self.xUcell_size, self.xUavg_size, self.xUnorm_factor = cs.cpu().numpy(), avg, fac.cpu().numpy()
+        else:
+            fac, self.xUnorm_factor = None, 1
+        sz, nm = ops.scale_log(Ux, fac, True, log, pcount, fix_nonfinite=True)
+        self._set_dev("Ux_sz", sz)
+        if log:
+            self._set_dev("Ux_norm", nm)
+
+    def normalize(self, which: str = "both", size: bool = True, log: bool = True, pcount: float = 1, relative_size: np.ndarray = None,
+                  use_S_size_for_U: bool = False, target_size: Tuple[float, float] = (None, None)) -> None:
+        """analysis.py:633-676."""
+        if which == "both":
+            self._normalize_S(size=size, log=log, pcount=pcount, relative_size=relative_size, target_size=target_size[0])
+            self._normalize_U(size=size, log=log, pcount=pcount, use_S_size=use_S_size_for_U, relative_size=relative_size, target_size=target_size[1])
+        if "S" == which:
+            self._normalize_S(size=size, log=log, pcount=pcount, relative_size=relative_size, target_size=target_size[0])
+        if "U" == which:
+            self._normalize_U(size=size, log=log, pcount=pcount, use_S_size=use_S_size_for_U, relative_size=relative_size, target_size=target_size[1])
+        if which == "imputed":
+            self._normalize_Sx(size=size, log=log, pcount=pcount, relative_size=relative_size, target_size=target_size[0])
+            self._normalize_Ux(size=size, log=log, pcount=pcount, use_Sx_size=use_S_size_for_U, relative_size=relative_size, target_size=target_size[1])
+        if "Sx" == which:
+            self._normalize_Sx(size=size, log=log, pcount=pcount, relative_size=relative_size, target_size=target_size[0])
+        if "Ux" == which:
+            self._normalize_Ux(size=size, log=log, pcount=pcount, use_Sx_size=use_S_size_for_U, relative_size=relative_size, target_size=target_size[1])
+
+    def perform_PCA(self, which: str = "S_norm", n_components: int = None, div_by_std: bool = False) -> None:
+        """analysis.py:678-702 -- upstream of the hot path; scikit-learn pass-through on the host."""
+        from sklearn.decomposition import PCA
+        X = getattr(self, which)
+        self.pca = PCA(n_components=n_components)
+        self.pcs = self.pca.fit_transform((X / X.std(0)).T if div_by_std else X.T)
+
+    # ------------------------------------------------------------------ stage A
+    def knn_imputation(self, k: int = None, pca_space: float = True, metric: str = "euclidean", diag: float = 1, n_pca_dims: int = None,
+                       maximum: bool = False, size_norm: bool = True, balanced: bool = False, b_sight: int = None, b_maxl: int = None,
+                       group_constraint: Union[str, np.ndarray] = None, n_jobs: int = 8) -> None:
+        """analysis.py:933-1023."""
+        N = self.dev("S").C
+        if k is None:
+            k = int(N * 0.025)
+        if b_sight is None and balanced:
+            b_sight = np.maximum(int(k * 8), N - 1)
+        if b_maxl is None and balanced:
+            b_maxl = np.maximum(int(k * 4), N - 1)
+        space = self.pcs[:, :n_pca_dims] if pca_space else self.S_norm.T
+        if balanced:
+            constraint = None
+            if group_constraint is not None:
+                constraint = np.array(self.cluster_ix) if isinstance(group_constraint, str) and group_constraint == "clusters" else np.asarray(group_constraint)
+            bknn = BalancedKNN(k=k, sight_k=b_sight, maxl=b_maxl, metric=metric, constraint=constraint, mode="distance", n_jobs=n_jobs)
+            bknn.fit(space)
+            self.knn = bknn.kneighbors_graph(mode="distance")
+        else:
+            if group_constraint is not None:
+                raise ValueError("group_constraint is currently supported only if the argument balanced is set to True")
+            self.knn = knn_distance_matrix(space, metric=metric, k=k, mode="distance", n_jobs=n_jobs)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            connectivity = (self.knn > 0).astype(float)          # :1006 (also column-sorts self.knn in place, like scipy does there)
+            connectivity.setdiag(diag)
+        self.knn_smoothing_w = connectivity_to_weights(connectivity)
+        self._pool(self.knn_smoothing_w, maximum, "S_sz" if size_norm else "S", "U_sz" if size_norm else "U")
+
+    def knn_imputation_precomputed(self, knn_smoothing_w: sparse.spmatrix, maximum: bool = False) -> None:
+        """analysis.py:1025-1053."""
+        self._pool(knn_smoothing_w, maximum, "S_sz", "U_sz")
+
+    def _pool(self, w: sparse.spmatrix, maximum: bool, s_name: str, u_name: str) -> None:
+        w = sparse.csr_matrix(w)
+        assert np.allclose(np.asarray(w.sum(1)).ravel(), 1), "weight matrix need to sum to one over the columns"   # neighbors.py:422
+        indptr, indices, vals = w.indptr.astype(np.int64), w.indices.astype(np.int32), np.ascontiguousarray(w.data, dtype=np.float64)
+        Sx = ops.knn_pool(self.dev(s_name), indptr, indices, vals, maximum=maximum)
+        Ux = ops.knn_pool(self.dev(u_name), indptr, indices, vals, maximum=maximum)
+        self._set_dev("Sx", Sx)
+        self._set_dev("Ux", Ux)
+        self._set_dev("Sx_sz", Sx.clone())                        # :1022-1023 separate copies for backwards compatibility
+        self._set_dev("Ux_sz", Ux.clone())
+
+    # ------------------------------------------------------------------ stage B
+    def fit_gammas(self, steady_state_bool: np.ndarray = None, use_imputed_data: bool = True, use_size_norm: bool = True,
+                   fit_offset: bool = True, fixperc_q: bool = False, weighted: bool = True, weights: Any = "maxmin_diag",
+                   limit_gamma: bool = False, maxmin_perc: List[float] = [2, 98], maxmin_weighted_pow: float = 15) -> None:
+        """analysis.py:1120-1260."""
+        from .estimation import _fixperc_q, _median_and_up_gamma, _weighted_offset_device
+        if steady_state_bool is not None:
+            raise NotImplementedError("steady_state_bool: the reference's own handling is ambiguous (analysis.py:1159, SURVEY appendix 4)")
+        self.steady_state = np.ones(self.dev("S").C, dtype=bool)
+        if use_imputed_data:
+            tmpS, tmpU = (self.dev("Sx_sz"), self.dev("Ux_sz")) if use_size_norm else (self.dev("Sx"), self.dev("Ux"))
+        else:
+            tmpS, tmpU = (self.dev("S_sz"), self.dev("U_sz")) if use_size_norm else (self.dev("S"), self.dev("U"))
+        perc = [float(p) for p in maxmin_perc]
+        wmode, wargs = 2, {}
+        if weighted:
+            if type(weights) is np.ndarray:
+                wmode, wargs = 0, dict(W=CellMatrix.from_genes_major(weights, tmpS.dtype))
+            elif weights in ("sum", "prod"):
+                pS, pU = ops.gene_quantiles(tmpS, [99])[0], ops.gene_quantiles(tmpU, [99])[0]
+                wmode, wargs = 0, dict(W=ops.gamma_weights(tmpS, tmpU, 0 if weights == "sum" else 1, pS, pU))
+            elif weights == "maxmin_weighted":
+                q = ops.gene_quantiles(tmpS, perc)
+                wmode, wargs = 0, dict(W=ops.gamma_weights(tmpS, None, 2, q[0], q[1], power=maxmin_weighted_pow))
+            elif weights == "maxmin":
+                q = ops.gene_quantiles(tmpS, perc)
+                wmode, wargs = 1, dict(M=tmpS, down=q[0], up=q[1])
+            elif weights in ("maxmin_diag", "maxmin_double"):
+                Sx, Ux = self.dev("Sx"), self.dev("Ux")
+                dS, dU = self._maxnorm_denominator(Sx), self._maxnorm_denominator(Ux)
+                q = ops.gene_quantiles(Sx, perc, M2=Ux, scale_a=dS, scale_b=dU)
+                if weights == "maxmin_diag":
+                    wmode, wargs = 1, dict(M=Sx, M2=Ux, scale_a=dS, scale_b=dU, down=q[0], up=q[1])
+                else:
+                    q2 = ops.gene_quantiles(Sx, perc)
+                    wmode, wargs = 0, dict(W=ops.gamma_weights(Sx, Ux, 3, q[0], q[1], q2[0], q2[1], dS, dU))
+            else:
+                raise ValueError(f"weights={weights!r} is not supported")
+        R2 = None
+        if fit_offset:
+            if weighted:
+                g, q, R2 = _weighted_offset_device(tmpU, tmpS, wmode, wargs, False, limit_gamma)
+            else:
+                if limit_gamma:
+                    logging.warning("limit_gamma not implemented with this settings")
+                g, q, _ = ops.fit_weighted(tmpU, tmpS, 2, fit_offset=True, box_q=False, want_R2=False)
+        elif fixperc_q:
+            if weighted:
+                g, q, _ = _weighted_offset_device(tmpU, tmpS, wmode, wargs, True, limit_gamma)
+            else:
+                if limit_gamma:
+                    logging.warning("limit_gamma not implemented with this settings")
+                g, q, _ = ops.fit_weighted(tmpU, tmpS, 2, fit_offset=False, lo_gamma=0.0, up_gamma_default=20.0, q_fixed=_fixperc_q(tmpU, tmpS), want_R2=False)
+        else:
+            if weighted:
+                if limit_gamma:
+                    g, _, R2 = ops.fit_weighted(tmpU, tmpS, wmode, fit_offset=False, lo_gamma=1e-8, up_gamma=_median_and_up_gamma(tmpU, tmpS), **wargs)
+                else:
+                    g, _, R2 = ops.fit_weighted(tmpU, tmpS, wmode, fit_offset=False, lo_gamma=0.0, up_gamma_default=20.0, **wargs)
+            else:
+                if limit_gamma:
+                    logging.warning("limit_gamma not implemented with this settings")
+                g = ops.fit_slope(tmpU, tmpS)
+            q = torch.zeros_like(g)
+        g = torch.where(torch.isfinite(g), g, torch.zeros_like(g))                     # :1260
+        self._gammas_dev, self._q_dev = g, q
+        self.gammas, self.q = g.cpu().numpy(), q.cpu().numpy()
+        if R2 is not None:
+            self.R2 = R2.cpu().numpy()
+
+    @staticmethod
+    def _maxnorm_denominator(M: CellMatrix) -> torch.Tensor:
+        """percentile(M, 99.9) with zeros replaced by max(max(row), 0.001)   (analysis.py:1197-1202)."""
+        q = ops.gene_quantiles(M, [99.9, 100])
+        return torch.where(q[0] == 0, torch.clamp(q[1], min=0.001), q[0])
+
+    # ------------------------------------------------------------------ stage C
+    def _chain(self, want: Tuple[str, ...]) -> Dict[str, CellMatrix]:
+        st = self.__dict__
+        which_S = st.get("which_S_for_pred", "Sx_sz")
+        Sd = self.dev(which_S)
+        Ud = self.dev("Ux_sz" if which_S == "Sx_sz" else "Ux")
+        gam = torch.as_tensor(np.asarray(getattr(self, st.get("_which_gamma", "gammas")), dtype=np.float32))
+        off = st.get("_which_offset", "q")
+        q = None if off is None else torch.as_tensor(np.asarray(getattr(self, off), dtype=np.float32))
+        eps_thr = None
+        if st.get("_vel_eps"):
+            up = ops.velocity_chain(Sd, Ud, gam, q, want=("Upred",))["Upred"]
+            eps_thr = ops.gene_quantiles(up, [100])[0] * float(st["_vel_eps"])   # Upred.max(1) * eps   (:1378)
+        return ops.velocity_chain(Sd, Ud, gam, q, want=want, eps_thr=eps_thr, dt_shift=st.get("_shift_dt", 1.0),
+                                  dt_extrap=st.get("_extrap_dt", 1.0), used_dt=st.get("used_delta_t", 1.0),
+                                  assumption=st.get("_assumption", 0), clip=st.get("_clip", True))
+
+    def predict_U(self, which_gamma: str = "gammas", which_S: str = "Sx_sz", which_offset: str = "q") -> None:
+        """analysis.py:1321-1346."""
+        self.which_S_for_pred = which_S
+        self._which_gamma, self._which_offset = which_gamma, which_offset
+        if which_offset is None and (hasattr(self, "q_W") or hasattr(self, "q")):
+            logging.warning("Predicting U without intercept but intercept was previously fit! Set which_offset='q' or 'q_W' ")
+        self._set_dev("Upred", self._chain(("Upred",))["Upred"])
+
+    def calculate_velocity(self, kind: str = "residual", eps: float = None) -> None:
+        """analysis.py:1348-1379."""
+        if kind != "residual":
+            raise NotImplementedError(f"Velocity calculation kind={kind} is not implemented")
+        if self.which_S_for_pred not in ("Sx_sz", "Sx"):
+            raise NotImplementedError(f"Not implemented with which_S = {self.which_S_for_pred}")
+        self._vel_eps = eps
+        self._set_dev("velocity", self._chain(("velocity",))["velocity"])
+
+    def calculate_shift(self, assumption: str = "constant_velocity", delta_t: float = 1) -> None:
+        """analysis.py:1381-1408."""
+        if assumption not in ("constant_velocity", "constant_unspliced"):
+            raise NotImplementedError(f"Assumption {assumption} is not implemented")
+        self._assumption, self._shift_dt = (0 if assumption == "constant_velocity" else 1), float(delta_t)
+        self._set_dev("delta_S", self._chain(("delta_S",))["delta_S"])
+
+    def extrapolate_cell_at_t(self, delta_t: float = 1, clip: bool = True) -> None:
+        """analysis.py:1410-1439."""
+        self._extrap_dt, self._clip = float(delta_t), bool(clip)
+        if clip:
+            self.used_delta_t = delta_t
+        out = self._chain(("Sx_sz_t",))["Sx_sz_t"]
+        if self.which_S_for_pred == "Sx_sz":
+            self._set_dev("Sx_sz_t", out)
+        elif self.which_S_for_pred == "Sx":
+            self._set_dev("Sx_t", out)
+        else:
+            raise NotImplementedError("not implemented for other situations other than Sx or Sx_sz")
+
+    # ------------------------------------------------------------------ stage D
+    def estimate_transition_prob(self, hidim: str = "Sx_sz", embed: str = "ts", transform: str = "sqrt", ndims: int = None,
+                                 n_sight: int = None, psc: float = None, knn_random: bool = True, sampled_fraction: float = 0.3,
+                                 sampling_probs: Tuple[float, float] = (0.5, 0.1), max_dist_embed: float = None, n_jobs: int = 4,
+                                 threads: int = None, calculate_randomized: bool = True, random_seed: int = 15071990, **kwargs) -> None:
+        """analysis.py:1452-1668."""
+        self.which_hidim = hidim
+        n_neighbors = kwargs.pop("n_neighbors", None)
+        if kwargs:
+            logging.warning(f"keyword arguments were passed but could not be interpreted {kwargs}")
+        C = self.dev("S").C
+        if n_sight is None and n_neighbors is None:
+            n_neighbors = int(C / 5)
+        if (n_sight is not None) and (n_neighbors is not None) and n_neighbors != n_sight:
+            raise ValueError("n_sight and n_neighbors are different names for the same parameter, they cannot be set differently")
+        if n_sight is not None and n_neighbors is None:
+            n_neighbors = n_sight
+        if psc is None:
+            psc = 1.0 if transform in ("log", "logratio") else (1e-10 if transform == "sqrt" else 0)
+        if transform not in ("log", "logratio", "linear", "sqrt"):
+            raise NotImplementedError(f"transform={transform} is not a valid parameter")
+        if "pcs" in hidim:
+            raise NotImplementedError("hidim='pcs' (velocity in PCA space) is not on the accelerated path")
+        if ndims is not None:
+            raise ValueError(f"ndims was set to {ndims} but hidim != 'pcs'. Set ndims = None for hidim='{hidim}'")
+        if knn_random:
+            np.random.seed(random_seed)                                            # :1529
+        hi = self.dev(hidim)
+        dS = self.dev("delta_S")
+        embedding = np.asarray(getattr(self, embed), dtype=np.float64)
+        self.embedding = embedding
+        mode = {"linear": 0, "sqrt": 1, "log": 2, "logratio": 3}[transform]
+        kern = {"linear": ops.LINEAR, "sqrt": ops.SQRT, "log": ops.LOG10, "logratio": ops.LINEAR}[transform]
+        dmat, e_alt = ops.delta_transform(hi, dS, self.used_delta_t, mode, psc)     # :1538, 1575-1601
+        e = e_alt if transform == "logratio" else hi
+        dmat_r = None
+        if calculate_randomized:
+            self._set_dev("delta_S_rndm", _permute_rows_nsign(dS, random_seed))     # :1540-1541
+            dmat_r, _ = ops.delta_transform(hi, self.dev("delta_S_rndm"), self.used_delta_t, mode, psc)
+        # embedding kNN, n_neighbors + 1 nearest (query excluded)                    :1547-1549
+        knn_ix, _ = ops.knn_search(embedding, n_neighbors + 1, include_self=False)
+        if knn_random:
+            self.corr_calc = "knn_random"
+            neigh_ixs = knn_ix.cpu().numpy().astype(np.int64)
+            p = np.linspace(sampling_probs[0], sampling_probs[1], neigh_ixs.shape[1])
+            p = p / p.sum()
+            size = int(sampled_fraction * (n_neighbors + 1))
+            # identical numpy legacy-RNG stream to the reference (:1561-1564)
+            sampling_ixs = np.stack([np.random.choice(neigh_ixs.shape[1], size=(size,), replace=False, p=p) for _ in range(C)], 0)
+            self.sampling_ixs = sampling_ixs
+            neigh_ixs = neigh_ixs[np.arange(C)[:, None], sampling_ixs]
+            nonzero = neigh_ixs.shape[0] * neigh_ixs.shape[1]
+            self.embedding_knn = sparse.csr_matrix((np.ones(nonzero), neigh_ixs.ravel(), np.arange(0, nonzero + 1, neigh_ixs.shape[1])),
+                                                   shape=(C, C))
+            neigh = torch.from_numpy(neigh_ixs.astype(np.int32)).to(hi.t.device)
+            self._neigh = neigh
+            self._corr = ops.coldeltacor_partial(e, dmat, neigh, kern, ops.RULES_PARTIAL, psc, validate=False)
+            if ops.corr_fixup(self._corr, neigh, zero_self=True, fix_nan=True, nan_to=1.0):                      # :1604-1607
+                logging.warning("Nans encountered in corrcoef and corrected to 1s. If not identical cells were present it is probably a small isolated cluster converging after imputation.")
+            if calculate_randomized:
+                self._corr_random = ops.coldeltacor_partial(e, dmat_r, neigh, kern, ops.RULES_PARTIAL, psc, validate=False)
+                if ops.corr_fixup(self._corr_random, neigh, zero_self=True, fix_nan=True, nan_to=1.0):
+                    logging.warning("Nans encountered in corrcoef_random and corrected to 1s. If not identical cells were present it is probably a small isolated cluster converging after imputation.")
+            else:
+                self.__dict__.pop("_corr_random", None)
+        else:
+            self.corr_calc = "full"
+            k1 = n_neighbors + 1
+            ix = knn_ix.cpu().numpy().astype(np.int64)
+            order = np.argsort(ix, axis=1)                                          # sklearn's connectivity graph is what it is; keep CSR canonical
+            self.embedding_knn = sparse.csr_matrix((np.ones(C * k1), np.take_along_axis(ix, order, 1).ravel(), np.arange(0, C * k1 + 1, k1)), shape=(C, C))
+            self._neigh = knn_ix
+            self._corr = ops.coldeltacor_full(e, dmat, kern, psc)
+            _fill_diagonal_zero(self._corr)                                          # :1666 (off-diagonal NaNs are kept)
+            if calculate_randomized:
+                self._corr_random = ops.coldeltacor_full(e, dmat_r, kern, psc)
+                _fill_diagonal_zero(self._corr_random)
+            else:
+                self.__dict__.pop("_corr_random", None)
+
+    # ------------------------------------------------------------------ stage E
+    def calculate_embedding_shift(self, sigma_corr: float = 0.05, expression_scaling: bool = True, scaling_penalty: float = 1.) -> None:
+        """analysis.py:1670-1733, in neighbour-list form (no (cells, cells) temporaries)."""
+        if self.corr_calc not in ("full", "knn_random"):
+            raise NotImplementedError(f"Weird value self.corr_calc={self.corr_calc}")
+        neigh = self._neigh
+        hi = self.dev(self.which_hidim)
+        dev = hi.t.device
+
+        def one(corr, dS_name):
+            c = corr if self.corr_calc == "knn_random" else torch.gather(corr, 1, neigh.long())
+            tp, wd, de = ops.transition_prob(c.contiguous(), neigh, self.embedding, sigma_corr)
+            scaling = None
+            if expression_scaling:
+                n = neigh.shape[1]
+                indptr = torch.arange(0, (neigh.shape[0] + 1) * n, n, dtype=torch.int64, device=dev)
+                estim = ops.knn_pool(hi, indptr, neigh.reshape(-1), wd.reshape(-1), validate=False)       # hi_dim @ (P - knn/n).T   (:1716)
+                cos_proj = ops.row_cosproj(self.dev(dS_name), estim)                                       # :1717
+                scaling = torch.clamp(cos_proj / scaling_penalty, 0, 1)                                    # NaN stays NaN, like np.clip
+                de = de * scaling[:, None]
+            return tp, de, scaling
+
+        tp, de, sc = one(self._corr, "delta_S")
+        self._tp, self._tp_ixs = tp, neigh
+        self.delta_embedding = de.cpu().numpy()
+        if sc is not None:
+            self.scaling = sc.cpu().numpy()
+        if "_corr_random" in self.__dict__:
+            tp, de, sc = one(self._corr_random, "delta_S_rndm")
+            self._tp_random = tp
+            self.delta_embedding_random = de.cpu().numpy()
+            if sc is not None:
+                self.scaling_rndm = sc.cpu().numpy()
+
+    # ------------------------------------------------------------------ stage F
+    def prepare_markov(self, sigma_D: np.ndarray, sigma_W: np.ndarray, direction: str = "forward", cells_ixs: np.ndarray = None) -> None:
+        """analysis.py:1818-1863 (cells_ixs=None)."""
+        if cells_ixs is not None:
+            raise NotImplementedError("prepare_markov on a subset of cells (cells_ixs) is not on the accelerated path yet")
+        if direction not in ("forward", "backwards"):
+            raise NotImplementedError(f"{direction} is not an implemented direction")
+        tp, ixs = self._tp.double().cpu().numpy(), self._tp_ixs.cpu().numpy().astype(np.int64)
+        C, n = tp.shape
+        P = sparse.csr_matrix((tp.ravel(), ixs.ravel(), np.arange(0, C * n + 1, n)), shape=(C, C))
+        if direction == "backwards":
+            P = sparse.csr_matrix(P.T)
+        P.sort_indices()
+        self._tr_dev = ops.prepare_markov(P.indptr, P.indices, P.data, self.embedding, sigma_D, sigma_W, dtype=torch.float64)
+
+    def run_markov(self, starting_p: np.ndarray = None, n_steps: int = 2500, mode: str = "time_evolution") -> None:
+        """analysis.py:1865-1887."""
+        tr = self._tr_dev
+        if starting_p is None:
+            starting_p = np.ones(tr.shape[0]) / tr.shape[0]
+        self.diffused = Diffusion().diffuse(starting_p, tr, n_steps=n_steps, mode=mode)[0]
+
+    # ------------------------------------------------------------------ bookkeeping kept from the reference
+    def to_hdf5(self, filename: str, **kwargs) -> None:
+        raise NotImplementedError("HDF5 checkpointing needs h5py (absent in this image); SURVEY.md section 8f rank 4")
+
+
+def _fill_diagonal_zero(m: torch.Tensor) -> None:
+    m.diagonal().zero_()
+
+
+def _permute_rows_nsign(dS: CellMatrix, seed: int) -> CellMatrix:
+    """analysis.py:2407-2420: per gene, shuffle the values across cells and flip signs at random.
+    RNG plumbing (torch device generator; the reference uses numba's) - statistical parity only."""
+    dev = dS.t.device
+    gen = torch.Generator(device=dev).manual_seed(int(seed))
+    out = torch.zeros_like(dS.t)
+    C, G = dS.C, dS.G
+    blk = max(1, int(2e8 // max(C, 1)))
+    for g0 in range(0, G, blk):
+        g1 = min(G, g0 + blk)
+        perm = torch.argsort(torch.rand((C, g1 - g0), generator=gen, device=dev), dim=0)
+        sign = torch.randint(0, 2, (C, g1 - g0), generator=gen, device=dev, dtype=torch.int8).to(dS.dtype) * 2 - 1
+        out[:, g0:g1] = torch.gather(dS.t[:, g0:g1], 0, perm) * sign
+    return CellMatrix(out, G)
+
+
+def gaussian_kernel(X: np.ndarray, mu: float = 0, sigma: float = 1) -> np.ndarray:
+    """analysis.py:2449-2451."""
+    return np.exp(-(X - mu)**2 / (2 * sigma**2)) / np.sqrt(2 * np.pi * sigma**2)

@@ -224,9 +224,15 @@ __global__ void k_fit_weighted_final(const double *__restrict__ part, int fit_of
 
 // ---------------------------------------------------------------- per-gene order statistics
 // Step 1: gene-major key matrix Z (G, C): 64x64 LDS tile transpose of zvalue(M, M2).
+// Optional mask (conditional percentiles of estimation.py:200-202, 222, 229-231, 255):
+//   mask_mode 1 keeps cells with mask_src[c,g] >  mask_thr[g]   (y[x > percentile(x, 90)])
+//   mask_mode 2 keeps cells with mask_src[c,g] <= mask_thr[g]   (y[x <= percentile(x, 1)])
+// masked-out entries become +inf, sort last, and are not counted by k_gene_quantiles.
 template <typename T>
 __global__ __launch_bounds__(256) void k_build_z(const T *__restrict__ M, const T *__restrict__ M2, const double *__restrict__ scale_a,
-                                                  const double *__restrict__ scale_b, T *__restrict__ Z, int C, int G, int64_t ld)
+                                                  const double *__restrict__ scale_b, const T *__restrict__ mask_src,
+                                                  const double *__restrict__ mask_thr, int mask_mode, T *__restrict__ Z, int C, int G,
+                                                  int64_t ld)
 {
     __shared__ T tile[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -241,6 +247,11 @@ __global__ __launch_bounds__(256) void k_build_z(const T *__restrict__ M, const 
         if (c < C && g < G) {
             const int64_t o = (int64_t)c * ld + g;
             z = zvalue<T>(M[o], two ? M2[o] : T(0), den_a, den_b, two);
+            if (mask_mode) {
+                const double mv = (double)mask_src[o], th = mask_thr[g];
+                const bool keep = mask_mode == 1 ? (mv > th) : (mv <= th);
+                if (!keep) z = (T)INFINITY;
+            }
         }
         tile[j][tx] = z;
     }
@@ -272,7 +283,7 @@ template <> struct Key<double> {
 //   t < 0.5 ? v[lo] + (v[lo+1]-v[lo]) t : v[lo+1] - (v[lo+1]-v[lo]) (1-t)      (numpy _lerp)
 template <typename T>
 __global__ __launch_bounds__(256) void k_gene_quantiles(const T *__restrict__ Z, QArgs qa, int nq,
-                                                         double *__restrict__ out, int C, int G)
+                                                         double *__restrict__ out, int C, int G, int masked)
 {
     using U = typename Key<T>::U;
     constexpr int PASSES = sizeof(U);
@@ -283,8 +294,21 @@ __global__ __launch_bounds__(256) void k_gene_quantiles(const T *__restrict__ Z,
     __shared__ unsigned long long s_min_gt;
     const int g = blockIdx.x, tid = threadIdx.x;
     const T *row = Z + (int64_t)g * C;
+    int nvalid = C;
+    if (masked) {   // entries removed by the mask were stored as +inf
+        if (tid == 0) s_cnt_le = 0;
+        __syncthreads();
+        unsigned cnt = 0;
+        for (int c = tid; c < C; c += 256) cnt += (row[c] < (T)INFINITY) ? 1u : 0u;
+        cnt = wave_sum(cnt);
+        if ((tid & 63) == 0) atomicAdd(&s_cnt_le, cnt);
+        __syncthreads();
+        nvalid = (int)s_cnt_le;
+        __syncthreads();
+    }
     for (int qi = 0; qi < nq; ++qi) {
-        const double h = __dmul_rn((double)(C - 1), qa.q[qi] / 100.0);   // numpy: (n-1) * (q/100)
+        if (nvalid == 0) { if (tid == 0) out[(int64_t)qi * G + g] = NAN; continue; }
+        const double h = __dmul_rn((double)(nvalid - 1), qa.q[qi] / 100.0);   // numpy: (n-1) * (q/100)
         const int lo = (int)floor(h);
         const double t = h - lo;
         U prefix = 0;
@@ -344,7 +368,7 @@ __global__ __launch_bounds__(256) void k_gene_quantiles(const T *__restrict__ Z,
         __syncthreads();
         if (tid == 0) {
             T vhi = vlo;
-            if (lo + 1 < C && s_cnt_le < (unsigned)(lo + 2)) vhi = Key<T>::dec((U)s_min_gt);
+            if (lo + 1 < nvalid && s_cnt_le < (unsigned)(lo + 2)) vhi = Key<T>::dec((U)s_min_gt);
             // numpy _lerp, without fma contraction so the rounding matches numpy's mul-then-add
             const double a = (double)vlo, b = (double)vhi, diff = __dsub_rn(b, a);
             double r = __dadd_rn(a, __dmul_rn(diff, t));
@@ -433,9 +457,11 @@ extern "C" int vcy_fit_weighted(const void *Y, const void *X, int weight_mode, c
 
 extern "C" size_t vcy_quantile_workspace_bytes(int64_t C, int64_t G) { return (size_t)C * (size_t)G * sizeof(double); }
 
-extern "C" int vcy_gene_quantiles(const void *M, const void *M2, const double *scale_a, const double *scale_b, const double *qs_host,
-                                  int nq, double *out, void *workspace, int64_t C, int64_t G, int64_t ld, int dtype, vcy_stream stream)
+extern "C" int vcy_gene_quantiles(const void *M, const void *M2, const double *scale_a, const double *scale_b, const void *mask_src,
+                                  const double *mask_thr, int mask_mode, const double *qs_host, int nq, double *out, void *workspace,
+                                  int64_t C, int64_t G, int64_t ld, int dtype, vcy_stream stream)
 {
+    VCY_REQUIRE(mask_mode >= 0 && mask_mode <= 2 && (mask_mode == 0 || (mask_src && mask_thr)), "gene_quantiles: bad mask arguments");
     VCY_REQUIRE(M && qs_host && out && workspace && nq > 0 && nq <= 16, "gene_quantiles: bad arguments");
     VCY_REQUIRE(C > 0 && G > 0 && ld >= G, "gene_quantiles: bad shape");
     VCY_REQUIRE((scale_a == nullptr) == (scale_b == nullptr) && (scale_a == nullptr || M2), "gene_quantiles: scale_a/scale_b/M2 go together");
@@ -447,13 +473,13 @@ extern "C" int vcy_gene_quantiles(const void *M, const void *M2, const double *s
     void *Z = workspace;   // gene-major key matrix (G, C) of dtype
     dim3 gridz((unsigned)((G + 63) / 64), (unsigned)((C + 63) / 64));
     if (dtype == VCY_F32) {
-        hipLaunchKernelGGL(k_build_z<float>, gridz, dim3(256), 0, st, (const float *)M, (const float *)M2, scale_a, scale_b, (float *)Z, (int)C, (int)G, ld);
+        hipLaunchKernelGGL(k_build_z<float>, gridz, dim3(256), 0, st, (const float *)M, (const float *)M2, scale_a, scale_b, (const float *)mask_src, mask_thr, mask_mode, (float *)Z, (int)C, (int)G, ld);
         VCY_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_gene_quantiles<float>, dim3((unsigned)G), dim3(256), 0, st, (const float *)Z, qs_dev, nq, out, (int)C, (int)G);
+        hipLaunchKernelGGL(k_gene_quantiles<float>, dim3((unsigned)G), dim3(256), 0, st, (const float *)Z, qs_dev, nq, out, (int)C, (int)G, mask_mode != 0);
     } else {
-        hipLaunchKernelGGL(k_build_z<double>, gridz, dim3(256), 0, st, (const double *)M, (const double *)M2, scale_a, scale_b, (double *)Z, (int)C, (int)G, ld);
+        hipLaunchKernelGGL(k_build_z<double>, gridz, dim3(256), 0, st, (const double *)M, (const double *)M2, scale_a, scale_b, (const double *)mask_src, mask_thr, mask_mode, (double *)Z, (int)C, (int)G, ld);
         VCY_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_gene_quantiles<double>, dim3((unsigned)G), dim3(256), 0, st, (const double *)Z, qs_dev, nq, out, (int)C, (int)G);
+        hipLaunchKernelGGL(k_gene_quantiles<double>, dim3((unsigned)G), dim3(256), 0, st, (const double *)Z, qs_dev, nq, out, (int)C, (int)G, mask_mode != 0);
     }
     VCY_LAUNCH_CHECK();
     return VCY_OK;

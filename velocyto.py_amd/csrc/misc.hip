@@ -1,0 +1,424 @@
+// misc.hip -- the small streaming kernels around the four hot stages:
+//   normalisation pre-step (analysis.py:535-631), the dmat transform of estimate_transition_prob
+//   on a stored delta_S (analysis.py:1538, 1575-1601), the diag/NaN fix-ups (:1604-1612), the
+//   transition-probability / embedding-shift step in neighbour-list form (:1670-1733) and the
+//   Markov step of Diffusion.diffuse (diffusion.py:93-105).
+#include <math.h>
+#include "common.h"
+
+namespace vcy {
+
+// ---------------------------------------------------------------- a1: normalisation
+// cell_size[c] = sum_g M[c,g]  (S.sum(0) in the reference's layout): one wave per cell row.
+template <typename T>
+__global__ __launch_bounds__(256) void k_row_sums(const T *__restrict__ M, double *__restrict__ out, int64_t C, int G, int64_t ld)
+{
+    using V = typename Vec<T>::type;
+    constexpr int N = Vec<T>::N;
+    const int lane = threadIdx.x & 63;
+    const int64_t c = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (c >= C) return;
+    const T *row = M + c * ld;
+    double s = 0.0;
+    const int nvec = G / N;
+    for (int v = lane; v < nvec; v += 64) {
+        const V x = reinterpret_cast<const V *>(row)[v];
+        const T *xp = reinterpret_cast<const T *>(&x);
+#pragma unroll
+        for (int k = 0; k < N; ++k) s += (double)xp[k];
+    }
+    for (int g = nvec * N + lane; g < G; g += 64) s += (double)row[g];
+    s = wave_sum(s);
+    if (lane == 0) out[c] = s;
+}
+
+// out_sz[c,g] = factor[c] * M[c,g] (non-finite -> 0 when fix != 0, analysis.py:580);
+// out_norm[c,g] = log2(out_sz + pcount) (analysis.py:551); either output may be NULL.
+template <typename T>
+__global__ __launch_bounds__(256) void k_scale_log(const T *__restrict__ M, const double *__restrict__ factor, T *__restrict__ out_sz,
+                                                    T *__restrict__ out_norm, int64_t C, int G, int64_t ld, double pcount, int fix)
+{
+    const int64_t total = C * ld;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = t / ld;
+        const int g = (int)(t - c * ld);
+        T v = T(0), l = T(0);
+        if (g < G) {
+            double x = (factor ? factor[c] : 1.0) * (double)M[t];
+            if (fix && !isfinite(x)) x = 0.0;
+            v = (T)x;
+            l = (T)log2(x + pcount);
+        }
+        if (out_sz) out_sz[t] = v;
+        if (out_norm) out_norm[t] = l;
+    }
+}
+
+// ---------------------------------------------------------------- dmat from a stored delta_S
+template <typename T>
+__global__ __launch_bounds__(256) void k_delta_transform(const T *__restrict__ hi, const T *__restrict__ dS, T *__restrict__ dmat,
+                                                          T *__restrict__ e_out, int64_t C, int G, int64_t ld, T used_dt, int mode, T psc)
+{
+    // mode 0 linear, 1 sqrt, 2 log10 (sign(D) f(|D|+psc), D = (hi + dt*dS) - hi); 3 logratio:
+    // e_out = log2(hi + psc), dmat = log2(|hi + dt*dS| + psc) - e_out   (analysis.py:1583-1584)
+    const int64_t total = C * ld;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(t % ld);
+        T d = T(0), eo = T(0);
+        if (g < G) {
+            const T h = hi[t];
+            const T ht = h + used_dt * dS[t];
+            if (mode == 3) {
+                eo = (T)log2((double)(h + psc));
+                d = (T)log2((double)(fabs(ht) + psc)) - eo;
+            } else {
+                const T D = ht - h;
+                if (mode == 0) d = D;
+                else {
+                    const double a = (double)fabs(D) + (double)psc;
+                    const T f = (T)(mode == 1 ? sqrt(a) : log10(a));
+                    d = D > T(0) ? f : (D < T(0) ? -f : T(0) * f);
+                }
+            }
+        }
+        dmat[t] = d;
+        if (e_out) e_out[t] = eo;
+    }
+}
+
+// np.fill_diagonal(corrcoef, 0); corrcoef[isnan] = nan_to   (analysis.py:1604-1606) on the compact form
+template <typename T>
+__global__ void k_corr_fixup(T *__restrict__ vals, const int32_t *__restrict__ ixs, int64_t cell0, int64_t total, int nrndm,
+                             int zero_self, int fix_nan, T nan_to, int *__restrict__ nan_count)
+{
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = cell0 + t / nrndm;
+        T v = vals[t];
+        if (zero_self && ixs[t] == c) v = T(0);
+        else if (v != v) {
+            if (nan_count) atomicAdd(nan_count, 1);
+            if (fix_nan) v = nan_to;
+        }
+        vals[t] = v;
+    }
+}
+
+// ---------------------------------------------------------------- stage E: transition probabilities
+// One wave per cell over its neighbour list (n entries):
+//   p_n = exp(corr[c,n]/sigma) / sum_n exp(corr/sigma)                 (analysis.py:1697-1698)
+//   u_n = (emb[i_n] - emb[c]) / |emb[i_n] - emb[c]|, 0 on the diagonal  (:1704-1708; 0/0 = NaN otherwise)
+//   delta_embedding[c] = sum_n p_n u_n - (1/n) sum_n u_n               (:1710-1712)
+//   wdiff[c,n] = p_n - 1/n        (weights of the expression-scaling pooling, :1716)
+template <typename T>
+__global__ __launch_bounds__(256) void k_transition_prob(const T *__restrict__ corr, const int32_t *__restrict__ ixs,
+                                                          const double *__restrict__ emb, int edim, T *__restrict__ tp, T *__restrict__ wdiff,
+                                                          double *__restrict__ delta_emb, int64_t cell0, int64_t C_out, int n, double sigma)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t cl = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (cl >= C_out) return;
+    const int64_t c = cell0 + cl;
+    const T *crow = corr + cl * n;
+    const int32_t *irow = ixs + cl * n;
+    double z = 0.0;
+    for (int k = lane; k < n; k += 64) z += exp((double)crow[k] / sigma);
+    z = wave_sum(z);
+    double acc[4] = {0, 0, 0, 0};   // edim <= 4
+    for (int k = lane; k < n; k += 64) {
+        const double p = exp((double)crow[k] / sigma) / z;
+        const int i = irow[k];
+        if (tp) tp[cl * n + k] = (T)p;
+        if (wdiff) wdiff[cl * n + k] = (T)(p - 1.0 / n);
+        double nrm = 0.0, dv[4];
+        for (int a = 0; a < edim; ++a) { dv[a] = emb[(int64_t)i * edim + a] - emb[c * edim + a]; nrm += dv[a] * dv[a]; }
+        nrm = sqrt(nrm);
+        for (int a = 0; a < edim; ++a) {
+            const double u = (i == c) ? 0.0 : dv[a] / nrm;
+            acc[a] += (p - 1.0 / n) * u;
+        }
+    }
+    for (int a = 0; a < edim; ++a) {
+        const double s = wave_sum(acc[a]);
+        if (lane == 0) delta_emb[cl * edim + a] = s;
+    }
+}
+
+// cos_proj[c] = sum_g a[c,g] b[c,g] / sqrt(sum_g b[c,g]^2)   (analysis.py:1717), one wave per cell
+template <typename T>
+__global__ __launch_bounds__(256) void k_row_cosproj(const T *__restrict__ A, const T *__restrict__ B, double *__restrict__ out, int64_t C,
+                                                      int G, int64_t ld)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t c = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (c >= C) return;
+    const T *a = A + c * ld, *b = B + c * ld;
+    double sab = 0, sbb = 0;
+    for (int g = lane; g < G; g += 64) { const double x = a[g], y = b[g]; sab = fma(x, y, sab); sbb = fma(y, y, sbb); }
+    sab = wave_sum(sab); sbb = wave_sum(sbb);
+    if (lane == 0) out[c] = sab / sqrt(sbb);
+}
+
+// ---------------------------------------------------------------- stage F: Markov step  y = x . T
+// dense row-major T (n, n): y[j] = sum_i x[i] T[i,j]; lanes over j (coalesced rows), rows split over
+// blockIdx.y with a deterministic two-stage reduction through `part` (gridDim.y, n).
+template <typename T>
+__global__ __launch_bounds__(256) void k_vecmat_dense(const T *__restrict__ Tm, const double *__restrict__ x, double *__restrict__ part, int n)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int per = (n + gridDim.y - 1) / gridDim.y;
+    const int i0 = blockIdx.y * per, i1 = min(n, i0 + per);
+    double acc = 0.0;
+    for (int i = i0; i < i1; ++i) acc = fma(x[i], (double)Tm[(int64_t)i * n + j], acc);
+    part[(int64_t)blockIdx.y * n + j] = acc;
+}
+__global__ void k_vecmat_reduce(const double *__restrict__ part, double *__restrict__ y, double *__restrict__ accum, int n, int nparts)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double s = 0.0;
+    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * n + j];
+    y[j] = s;
+    if (accum) accum[j] += s;     // path_integral: result = result + x   (diffusion.py:99)
+}
+// CSC form (column gather): y[j] = sum_p val[p] x[row[p]], one wave per column
+template <typename T>
+__global__ __launch_bounds__(256) void k_vecmat_csc(const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx, const T *__restrict__ val,
+                                                     const double *__restrict__ x, double *__restrict__ y, double *__restrict__ accum, int n)
+{
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (j >= n) return;
+    double acc = 0.0;
+    for (int64_t p = colptr[j] + lane; p < colptr[j + 1]; p += 64) acc = fma((double)val[p], x[rowidx[p]], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) { y[j] = acc; if (accum) accum[j] += acc; }
+}
+
+// ---------------------------------------------------------------- fit_gammas weight variants
+// The non-default W constructions of VelocytoLoom.fit_gammas (analysis.py:1182-1192, 1208-1219),
+// written densely so that vcy_fit_weighted(weight_mode 0) can consume them:
+//   mode 0 "sum"            W = S/pa + U/pb                              (pa, pb = 99th percentiles)
+//   mode 1 "prod"           W = (S/pa) * (U/pb)
+//   mode 2 "maxmin_weighted" R = (clip(S, pa, pb) - pa) / (pb - pa);  W = 0.5 (R^pw + (1-R)^pw)
+//   mode 3 "maxmin_double"  W = [Z<=pa | Z>=pb] + [S<=pc | S>=pd],  Z = S/sa + U/sb
+template <typename T>
+__global__ __launch_bounds__(256) void k_gamma_weights(const T *__restrict__ S, const T *__restrict__ U, T *__restrict__ W,
+                                                        const double *__restrict__ pa, const double *__restrict__ pb,
+                                                        const double *__restrict__ pc, const double *__restrict__ pd,
+                                                        const double *__restrict__ sa, const double *__restrict__ sb, int64_t C, int G,
+                                                        int64_t ld, int mode, double pw)
+{
+    const int64_t total = C * ld;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(t % ld);
+        T w = T(0);
+        if (g < G) {
+            const double s = (double)S[t];
+            if (mode == 0) w = (T)(s / pa[g] + (double)U[t] / pb[g]);
+            else if (mode == 1) w = (T)((s / pa[g]) * ((double)U[t] / pb[g]));
+            else if (mode == 2) {
+                const double lo = pa[g], hi = pb[g];
+                const double r = (fmin(fmax(s, lo), hi) - lo) / (hi - lo);
+                w = (T)(0.5 * (pow(r, pw) + pow(1.0 - r, pw)));
+            } else {
+                const double z = (double)(T)(S[t] / (T)sa[g] + U[t] / (T)sb[g]);   // same T arithmetic as k_build_z
+                w = (T)(((z <= pa[g] || z >= pb[g]) ? 1.0 : 0.0) + ((s <= pc[g] || s >= pd[g]) ? 1.0 : 0.0));
+            }
+        }
+        W[t] = w;
+    }
+}
+
+// ---------------------------------------------------------------- prepare_markov (analysis.py:1818-1863)
+// One workgroup per row c of the dense (n, n) Markov matrix.  P arrives as CSR (the transition
+// probabilities, or their transpose for direction="backwards"); emb is (n, edim) fp64.
+//   t[c,j]  = P[c,j] * K(dist(c,j); sigma_D);  t[c,c] = max_j t[c,j];  t /= sum_j t      (:1853-1857)
+//   kw[c,j] = K(dist(c,j); sigma_W) / sum_j K                                         (:1859-1860)
+//   tr      = 0.8 t + 0.2 kw, rows renormalised                                        (:1861-1862)
+// K(x; s) = exp(-x^2 / (2 s^2)) / sqrt(2 pi s^2)   (gaussian_kernel, :2449-2451)
+__device__ __forceinline__ double gauss_k(double x, double s) { return exp(-(x * x) / (2.0 * s * s)) / sqrt(2.0 * 3.14159265358979323846 * s * s); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_prepare_markov(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                         const double *__restrict__ pval, const double *__restrict__ emb, int edim,
+                                                         T *__restrict__ tr, int n, double sigma_D, double sigma_W)
+{
+    __shared__ double red[8];
+    __shared__ double s_vals[4];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double ec[4];
+    for (int a = 0; a < edim; ++a) ec[a] = emb[(int64_t)c * edim + a];
+    auto dist_to = [&](int j) {
+        double d2 = 0.0;
+        for (int a = 0; a < edim; ++a) { const double df = emb[(int64_t)j * edim + a] - ec[a]; d2 += df * df; }
+        return sqrt(d2);
+    };
+    // dense noise kernel row sum
+    double kw = 0.0;
+    for (int j = tid; j < n; j += 256) kw += gauss_k(dist_to(j), sigma_W);
+    kw = block_sum(kw, red);
+    // sparse part: max and sum of P * K_D over the stored entries (zeros elsewhere -> max >= 0)
+    const int64_t p0 = indptr[c], p1 = indptr[c + 1];
+    double mx = 0.0, sm = 0.0;
+    for (int64_t p = p0 + tid; p < p1; p += 256) {
+        const int j = indices[p];
+        const double v = pval[p] * gauss_k(dist_to(j), sigma_D);
+        mx = fmax(mx, v);
+        if (j != c) sm += v;
+    }
+    mx = wave_max(mx);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    sm = block_sum(sm, red) + mx;      // diagonal := row maximum
+    T *row = tr + (int64_t)c * n;
+    for (int j = tid; j < n; j += 256) row[j] = (T)(0.2 * gauss_k(dist_to(j), sigma_W) / kw);
+    __syncthreads();
+    for (int64_t p = p0 + tid; p < p1; p += 256) {
+        const int j = indices[p];
+        if (j != c) row[j] = (T)((double)row[j] + 0.8 * (pval[p] * gauss_k(dist_to(j), sigma_D)) / sm);
+    }
+    if (tid == 0) row[c] = (T)((double)row[c] + 0.8 * mx / sm);
+    __syncthreads();
+    double tot = 0.0;
+    for (int j = tid; j < n; j += 256) tot += (double)row[j];
+    tot = block_sum(tot, red);
+    for (int j = tid; j < n; j += 256) row[j] = (T)((double)row[j] / tot);
+    (void)s_vals;
+}
+
+static inline int grid_for(int64_t total) { const int64_t b = (total + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+}  // namespace vcy
+
+using namespace vcy;
+
+extern "C" int vcy_row_sums(const void *M, double *out, int64_t C, int64_t G, int64_t ld, int dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(M && out && C > 0 && G > 0 && ld >= G, "row_sums: bad arguments");
+    const unsigned blocks = (unsigned)((C + 3) / 4);
+    if (dtype == VCY_F32) hipLaunchKernelGGL(k_row_sums<float>, dim3(blocks), dim3(256), 0, as_stream(stream), (const float *)M, out, C, (int)G, ld);
+    else if (dtype == VCY_F64) hipLaunchKernelGGL(k_row_sums<double>, dim3(blocks), dim3(256), 0, as_stream(stream), (const double *)M, out, C, (int)G, ld);
+    else return fail(VCY_ERR_INVALID, "%s: bad dtype", "row_sums");
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}
+
+extern "C" int vcy_scale_log(const void *M, const double *factor, void *out_sz, void *out_norm, int64_t C, int64_t G, int64_t ld,
+                             double pcount, int fix_nonfinite, int dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(M && (out_sz || out_norm) && C > 0 && G > 0 && ld >= G, "scale_log: bad arguments");
+    const int blocks = grid_for(C * ld);
+    if (dtype == VCY_F32) hipLaunchKernelGGL(k_scale_log<float>, dim3(blocks), dim3(256), 0, as_stream(stream), (const float *)M, factor, (float *)out_sz, (float *)out_norm, C, (int)G, ld, pcount, fix_nonfinite);
+    else if (dtype == VCY_F64) hipLaunchKernelGGL(k_scale_log<double>, dim3(blocks), dim3(256), 0, as_stream(stream), (const double *)M, factor, (double *)out_sz, (double *)out_norm, C, (int)G, ld, pcount, fix_nonfinite);
+    else return fail(VCY_ERR_INVALID, "%s: bad dtype", "scale_log");
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}
+
+extern "C" int vcy_delta_transform(const void *hi_dim, const void *delta_S, void *dmat, void *e_out, int64_t C, int64_t G, int64_t ld,
+                                   double used_dt, int mode, double psc, int dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(hi_dim && delta_S && dmat && C > 0 && G > 0 && ld >= G, "delta_transform: bad arguments");
+    VCY_REQUIRE(mode >= 0 && mode <= 3 && (mode != 3 || e_out), "delta_transform: bad mode (3 = logratio needs e_out)");
+    const int blocks = grid_for(C * ld);
+    if (dtype == VCY_F32) hipLaunchKernelGGL(k_delta_transform<float>, dim3(blocks), dim3(256), 0, as_stream(stream), (const float *)hi_dim, (const float *)delta_S, (float *)dmat, (float *)e_out, C, (int)G, ld, (float)used_dt, mode, (float)psc);
+    else if (dtype == VCY_F64) hipLaunchKernelGGL(k_delta_transform<double>, dim3(blocks), dim3(256), 0, as_stream(stream), (const double *)hi_dim, (const double *)delta_S, (double *)dmat, (double *)e_out, C, (int)G, ld, used_dt, mode, psc);
+    else return fail(VCY_ERR_INVALID, "%s: bad dtype", "delta_transform");
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}
+
+extern "C" int vcy_corr_fixup(void *vals, const int32_t *ixs, int64_t cell0, int64_t C_out, int64_t nrndm, int zero_self, int fix_nan,
+                              double nan_to, int *nan_count, int dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(vals && ixs && C_out > 0 && nrndm > 0, "corr_fixup: bad arguments");
+    const int64_t total = C_out * nrndm;
+    const int blocks = grid_for(total);
+    if (dtype == VCY_F32) hipLaunchKernelGGL(k_corr_fixup<float>, dim3(blocks), dim3(256), 0, as_stream(stream), (float *)vals, ixs, cell0, total, (int)nrndm, zero_self, fix_nan, (float)nan_to, nan_count);
+    else if (dtype == VCY_F64) hipLaunchKernelGGL(k_corr_fixup<double>, dim3(blocks), dim3(256), 0, as_stream(stream), (double *)vals, ixs, cell0, total, (int)nrndm, zero_self, fix_nan, nan_to, nan_count);
+    else return fail(VCY_ERR_INVALID, "%s: bad dtype", "corr_fixup");
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}
+
+extern "C" int vcy_transition_prob(const void *corr, const int32_t *ixs, const double *embedding, int edim, void *tp, void *wdiff,
+                                   double *delta_embedding, int64_t cell0, int64_t C_out, int64_t n, double sigma_corr, int dtype,
+                                   vcy_stream stream)
+{
+    VCY_REQUIRE(corr && ixs && embedding && delta_embedding && C_out > 0 && n > 0 && edim > 0 && edim <= 4 && sigma_corr > 0, "transition_prob: bad arguments");
+    const unsigned blocks = (unsigned)((C_out + 3) / 4);
+    if (dtype == VCY_F32) hipLaunchKernelGGL(k_transition_prob<float>, dim3(blocks), dim3(256), 0, as_stream(stream), (const float *)corr, ixs, embedding, edim, (float *)tp, (float *)wdiff, delta_embedding, cell0, C_out, (int)n, sigma_corr);
+    else if (dtype == VCY_F64) hipLaunchKernelGGL(k_transition_prob<double>, dim3(blocks), dim3(256), 0, as_stream(stream), (const double *)corr, ixs, embedding, edim, (double *)tp, (double *)wdiff, delta_embedding, cell0, C_out, (int)n, sigma_corr);
+    else return fail(VCY_ERR_INVALID, "%s: bad dtype", "transition_prob");
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}
+
+extern "C" int vcy_row_cosproj(const void *A, const void *B, double *out, int64_t C, int64_t G, int64_t ld, int dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(A && B && out && C > 0 && G > 0 && ld >= G, "row_cosproj: bad arguments");
+    const unsigned blocks = (unsigned)((C + 3) / 4);
+    if (dtype == VCY_F32) hipLaunchKernelGGL(k_row_cosproj<float>, dim3(blocks), dim3(256), 0, as_stream(stream), (const float *)A, (const float *)B, out, C, (int)G, ld);
+    else if (dtype == VCY_F64) hipLaunchKernelGGL(k_row_cosproj<double>, dim3(blocks), dim3(256), 0, as_stream(stream), (const double *)A, (const double *)B, out, C, (int)G, ld);
+    else return fail(VCY_ERR_INVALID, "%s: bad dtype", "row_cosproj");
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}
+
+extern "C" size_t vcy_diffuse_workspace_bytes(int64_t n) { return (size_t)64 * (size_t)n * sizeof(double); }
+
+extern "C" int vcy_diffuse_step_dense(const void *tr, const double *x, double *y, double *accum, void *workspace, int64_t n, int dtype,
+                                      vcy_stream stream)
+{
+    VCY_REQUIRE(tr && x && y && workspace && n > 0 && x != y, "diffuse_step_dense: bad arguments");
+    const int nparts = n >= 4096 ? 64 : (n >= 512 ? 16 : 1);
+    dim3 grid((unsigned)((n + 255) / 256), nparts);
+    hipStream_t st = as_stream(stream);
+    if (dtype == VCY_F32) hipLaunchKernelGGL(k_vecmat_dense<float>, grid, dim3(256), 0, st, (const float *)tr, x, (double *)workspace, (int)n);
+    else if (dtype == VCY_F64) hipLaunchKernelGGL(k_vecmat_dense<double>, grid, dim3(256), 0, st, (const double *)tr, x, (double *)workspace, (int)n);
+    else return fail(VCY_ERR_INVALID, "%s: bad dtype", "diffuse_step_dense");
+    VCY_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_vecmat_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double *)workspace, y, accum, (int)n, nparts);
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}
+
+extern "C" int vcy_diffuse_step_csc(const int64_t *colptr, const int32_t *rowidx, const void *val, const double *x, double *y,
+                                    double *accum, int64_t n, int dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(colptr && rowidx && val && x && y && n > 0 && x != y, "diffuse_step_csc: bad arguments");
+    const unsigned blocks = (unsigned)((n + 3) / 4);
+    if (dtype == VCY_F32) hipLaunchKernelGGL(k_vecmat_csc<float>, dim3(blocks), dim3(256), 0, as_stream(stream), colptr, rowidx, (const float *)val, x, y, accum, (int)n);
+    else if (dtype == VCY_F64) hipLaunchKernelGGL(k_vecmat_csc<double>, dim3(blocks), dim3(256), 0, as_stream(stream), colptr, rowidx, (const double *)val, x, y, accum, (int)n);
+    else return fail(VCY_ERR_INVALID, "%s: bad dtype", "diffuse_step_csc");
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}
+
+extern "C" int vcy_gamma_weights(const void *S, const void *U, void *W, const double *pa, const double *pb, const double *pc,
+                                 const double *pd, const double *sa, const double *sb, int64_t C, int64_t G, int64_t ld, int mode,
+                                 double power, int dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(S && W && pa && pb && C > 0 && G > 0 && ld >= G && mode >= 0 && mode <= 3, "gamma_weights: bad arguments");
+    VCY_REQUIRE(mode == 2 || U, "gamma_weights: U needed");
+    VCY_REQUIRE(mode != 3 || (pc && pd && sa && sb), "gamma_weights: maxmin_double needs pc, pd, sa, sb");
+    const int blocks = grid_for(C * ld);
+    if (dtype == VCY_F32) hipLaunchKernelGGL(k_gamma_weights<float>, dim3(blocks), dim3(256), 0, as_stream(stream), (const float *)S, (const float *)U, (float *)W, pa, pb, pc, pd, sa, sb, C, (int)G, ld, mode, power);
+    else if (dtype == VCY_F64) hipLaunchKernelGGL(k_gamma_weights<double>, dim3(blocks), dim3(256), 0, as_stream(stream), (const double *)S, (const double *)U, (double *)W, pa, pb, pc, pd, sa, sb, C, (int)G, ld, mode, power);
+    else return fail(VCY_ERR_INVALID, "%s: bad dtype", "gamma_weights");
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}
+
+extern "C" int vcy_prepare_markov(const int64_t *indptr, const int32_t *indices, const double *pval, const double *embedding, int edim,
+                                  void *tr, int64_t n, double sigma_D, double sigma_W, int dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(indptr && indices && pval && embedding && tr && n > 0 && edim > 0 && edim <= 4 && sigma_D > 0 && sigma_W > 0, "prepare_markov: bad arguments");
+    if (dtype == VCY_F32) hipLaunchKernelGGL(k_prepare_markov<float>, dim3((unsigned)n), dim3(256), 0, as_stream(stream), indptr, indices, pval, embedding, edim, (float *)tr, (int)n, sigma_D, sigma_W);
+    else if (dtype == VCY_F64) hipLaunchKernelGGL(k_prepare_markov<double>, dim3((unsigned)n), dim3(256), 0, as_stream(stream), indptr, indices, pval, embedding, edim, (double *)tr, (int)n, sigma_D, sigma_W);
+    else return fail(VCY_ERR_INVALID, "%s: bad dtype", "prepare_markov");
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}

@@ -1,0 +1,170 @@
+"""Drop-in for the parts of ``velocyto/neighbors.py`` that ``VelocytoLoom`` uses
+(SURVEY.md section 2 row 3): ``knn_distance_matrix``, ``BalancedKNN``, ``knn_balance`` and its two
+greedy loops, ``connectivity_to_weights``, ``convolve_by_sparse_weights``.
+
+The exact kNN search (sklearn ``NearestNeighbors`` in the reference) is the HIP kernel
+``k_knn_search``; the greedy balancing loop (numba in the reference) is C++ on the host
+(``vcy_balance_knn_host``); pooling is ``k_knn_pool``.  Sparse-matrix *containers* stay scipy, as in
+the reference - they carry O(C*k) indices, not data-parallel work.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Any, Optional, Tuple
+
+import numpy as np
+import torch
+from scipy import sparse
+
+from . import ops
+from .ops import CellMatrix
+
+__all__ = ["knn_distance_matrix", "BalancedKNN", "knn_balance", "balance_knn_loop", "balance_knn_loop_constrained",
+           "connectivity_to_weights", "convolve_by_sparse_weights"]
+
+
+def _search_space(data: np.ndarray, metric: Optional[str]) -> Tuple[np.ndarray, bool]:
+    """Euclidean search space for a metric.  "correlation" = 1 - Pearson r: rows are centred and
+    scaled to unit norm, then |a-b|^2 = 2 (1 - r) orders identically (distance = |a-b|^2 / 2)."""
+    X = np.ascontiguousarray(data, dtype=np.float64)
+    if metric == "correlation":
+        X = X - X.mean(1, keepdims=True)
+        X = X / np.linalg.norm(X, axis=1, keepdims=True)
+        return X, True
+    if metric not in (None, "euclidean", "minkowski", "l2"):
+        raise NotImplementedError(f"metric={metric!r}: only euclidean and correlation are implemented")
+    return X, False
+
+
+def _kneighbors(data: np.ndarray, k: int, metric: Optional[str], include_self: bool) -> Tuple[np.ndarray, np.ndarray]:
+    X, corr = _search_space(data, metric)
+    idx, dist = ops.knn_search(X, k, include_self=include_self)
+    idx, dist = idx.cpu().numpy().astype(np.int64), dist.cpu().numpy()
+    if corr:
+        dist = dist * dist / 2.0
+    return dist, idx
+
+
+def knn_distance_matrix(data: np.ndarray, metric: str = None, k: int = 40, mode: str = "connectivity", n_jobs: int = 4
+                        ) -> sparse.csr_matrix:
+    """neighbors.py:363-376: kNN graph (query excluded), k entries per row, nearest first.
+    (The reference ignores `metric` unless it is "correlation", neighbors.py:369-376 - same here.)"""
+    dist, idx = _kneighbors(data, k, "correlation" if metric == "correlation" else None, include_self=False)
+    n = idx.shape[0]
+    vals = dist.ravel() if mode == "distance" else np.ones(n * k)
+    return sparse.csr_matrix((vals, idx.ravel(), np.arange(0, n * k + 1, k)), shape=(n, n))
+
+
+def balance_knn_loop(dsi: np.ndarray, dist: np.ndarray, lsi: np.ndarray, maxl: int, k: int, return_distance: bool) -> Tuple:
+    """neighbors.py:11-72 (numba in the reference, C++ here)."""
+    return ops.balance_knn_host(dsi, dist if return_distance else None, lsi, None, maxl, k)
+
+
+def balance_knn_loop_constrained(dsi: np.ndarray, dist: np.ndarray, lsi: np.ndarray, groups: np.ndarray, maxl: int, k: int,
+                                 return_distance: bool) -> Tuple:
+    """neighbors.py:75-140."""
+    return ops.balance_knn_host(dsi, dist if return_distance else None, lsi, groups, maxl, k)
+
+
+def knn_balance(dsi: np.ndarray, dist: np.ndarray = None, maxl: int = 200, k: int = 60, constraint: np.ndarray = None
+                ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """neighbors.py:143-183: in-degree l = bincount(dsi), processing order = reverse stable argsort of l."""
+    dsi = np.ascontiguousarray(dsi, dtype=np.int64)
+    l = np.bincount(dsi.flat[:], minlength=dsi.shape[0])
+    lsi = np.argsort(l, kind="mergesort")[::-1]
+    groups = None if constraint is None else np.asarray(constraint).astype("int64")
+    return ops.balance_knn_host(dsi, dist, lsi, groups, maxl, k)
+
+
+class BalancedKNN:
+    """neighbors.py:186-357: greedy in-degree-capped kNN graph with a scikit-learn-like API."""
+
+    def __init__(self, k: int = 50, sight_k: int = 100, maxl: int = 200, constraint: np.ndarray = None, mode: str = "distance",
+                 metric: str = "euclidean", n_jobs: int = 4) -> None:
+        self.k, self.sight_k, self.maxl, self.mode, self.metric, self.n_jobs = k, sight_k, maxl, mode, metric, n_jobs
+        self.dist_new = self.dsi_new = self.l = None
+        self.bknn = None
+        self.constraint = constraint
+
+    @property
+    def n_samples(self) -> int:
+        return self.data.shape[0]
+
+    def fit(self, data: np.ndarray, sight_k: int = None) -> Any:
+        """neighbors.py:226-244 (the search itself runs in kneighbors; there is no index to build)."""
+        self.data = data
+        self.fitdata = data
+        if sight_k is not None:
+            self.sight_k = sight_k
+        return self
+
+    def kneighbors(self, X: np.ndarray = None, maxl: int = None, mode: str = "distance") -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """neighbors.py:246-289: sight graph of sight_k+1 neighbours (query included, as sklearn's
+        kneighbors(data) returns it), then knn_balance."""
+        if X is not None:
+            self.data = X
+        if maxl is not None:
+            self.maxl = maxl
+        if self.data is not self.fitdata and not np.array_equal(self.data, self.fitdata):
+            raise NotImplementedError("BalancedKNN.kneighbors with query points different from the fitted data")
+        sight = min(int(self.sight_k) + 1, self.fitdata.shape[0])
+        logging.debug(f"First search the {self.sight_k} nearest neighbours for {self.n_samples}")
+        self.dist, self.dsi = _kneighbors(self.fitdata, sight, self.metric, include_self=True)
+        logging.debug(f"Using the initialization network to find a {self.k}-NN graph with maximum connectivity of {self.maxl}")
+        self.dist_new, self.dsi_new, self.l = knn_balance(self.dsi, self.dist, maxl=self.maxl, k=self.k, constraint=self.constraint)
+        if mode == "connectivity":
+            self.dist = np.ones_like(self.dsi)
+            self.dist[:, 0] = 0
+        return self.dist_new, self.dsi_new, self.l
+
+    def kneighbors_graph(self, X: np.ndarray = None, maxl: int = None, mode: str = "distance") -> sparse.csr_matrix:
+        """neighbors.py:291-322: CSR with k+1 stored entries per row (self first, distance 0 stored)."""
+        dist_new, dsi_new, l = self.kneighbors(X=X, maxl=maxl, mode=mode)
+        self.bknn = sparse.csr_matrix((np.ravel(dist_new), np.ravel(dsi_new),
+                                       np.arange(0, dist_new.shape[0] * dist_new.shape[1] + 1, dist_new.shape[1])),
+                                      (self.n_samples, self.n_samples))
+        return self.bknn
+
+    def smooth_data(self, data_to_smooth: np.ndarray, X: np.ndarray = None, maxl: int = None, mutual: bool = False,
+                    only_increase: bool = True) -> np.ndarray:
+        """neighbors.py:324-357."""
+        if self.bknn is None:
+            assert (X is None) and (maxl is None), "graph was already fit with different parameters"
+            self.kneighbors_graph(X=X, maxl=maxl, mode=self.mode)
+        connectivity = (self.bknn > 0).minimum((self.bknn > 0).T) if mutual else (self.bknn.T > 0)
+        connectivity = connectivity.tolil()
+        connectivity.setdiag(1)
+        w = connectivity_to_weights(connectivity)          # rows sum to 1; the reference uses its transpose on the right
+        if data_to_smooth.shape[1] == w.shape[0]:
+            result = convolve_by_sparse_weights(data_to_smooth, w)
+        elif data_to_smooth.shape[0] == w.shape[0]:
+            result = convolve_by_sparse_weights(data_to_smooth.T, w).T
+        else:
+            raise ValueError(f"Incorrect size of matrix, none of the axis correspond to the one of graph. {w.shape}")
+        return np.maximum(result, data_to_smooth) if only_increase else result
+
+
+def connectivity_to_weights(mknn: sparse.spmatrix, axis: int = 1) -> sparse.csr_matrix:
+    """neighbors.py:385-390: scale each row (axis=1) of a connectivity matrix to sum 1."""
+    if not sparse.isspmatrix_csr(mknn):
+        mknn = sparse.csr_matrix(mknn)
+    return mknn.multiply(1.0 / sparse.csr_matrix.sum(mknn, axis=axis)).tocsr()
+
+
+def _csr_parts(w: sparse.spmatrix):
+    w = sparse.csr_matrix(w)
+    return w.indptr.astype(np.int64), w.indices.astype(np.int32), np.ascontiguousarray(w.data, dtype=np.float64), w.shape
+
+
+def convolve_by_sparse_weights(data, w: sparse.spmatrix, dtype=None, as_device: bool = False):
+    """neighbors.py:416-423: ``data @ w.T`` for data (genes, cells) and a (cells, cells) weight matrix
+    whose rows sum to one.  Returns a Fortran-ordered (genes, cells) fp64 array like the reference
+    (or the device matrix when as_device=True)."""
+    indptr, indices, vals, shape = _csr_parts(w)
+    rowsum = np.asarray(sparse.csr_matrix(w).sum(1)).ravel()
+    assert np.allclose(rowsum, 1), "weight matrix need to sum to one over the columns"
+    D = CellMatrix.from_genes_major(data, dtype)
+    if shape != (D.C, D.C):
+        raise ValueError(f"weights {shape} do not match {D.C} cells")
+    out = ops.knn_pool(D, indptr, indices, vals)
+    return out if as_device else out.to_genes_major(order="F")

@@ -300,12 +300,19 @@ def fit_slope_from_moments(mom: torch.Tensor) -> torch.Tensor:
 
 
 def gene_quantiles(M: CellMatrix, qs: Sequence[float], M2: Optional[CellMatrix] = None, scale_a: Optional[torch.Tensor] = None,
-                   scale_b: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """np.percentile(M_or_Z, qs, axis=cells) -> (len(qs), G) float64 on device."""
+                   scale_b: Optional[torch.Tensor] = None, mask_src: Optional[CellMatrix] = None,
+                   mask_thr: Optional[torch.Tensor] = None, mask_mode: int = 0) -> torch.Tensor:
+    """np.percentile(M_or_Z, qs, axis=cells) -> (len(qs), G) float64 on device.
+    Z = M/scale_a + M2/scale_b when scales are given; mask_mode 1/2 restricts each gene to the cells
+    with mask_src > / <= mask_thr[g] (conditional percentiles)."""
     qs = np.ascontiguousarray(qs, dtype=np.float64).ravel()
-    out = torch.empty((len(qs), M.G), dtype=torch.float64, device=M.t.device)
-    ws = torch.empty(int(_lib.lib().vcy_quantile_workspace_bytes(M.C, M.G)) // (2 if M.code == F32 else 1), dtype=torch.uint8, device=M.t.device)
+    dev = M.t.device
+    out = torch.empty((len(qs), M.G), dtype=torch.float64, device=dev)
+    ws = torch.empty(int(_lib.lib().vcy_quantile_workspace_bytes(M.C, M.G)) // (2 if M.code == F32 else 1), dtype=torch.uint8, device=dev)
+    f64 = lambda t: None if t is None else t.to(device=dev, dtype=torch.float64).contiguous()
+    scale_a, scale_b, mask_thr = f64(scale_a), f64(scale_b), f64(mask_thr)
     _lib.check(_lib.lib().vcy_gene_quantiles(M.t.data_ptr(), None if M2 is None else M2.t.data_ptr(), _p(scale_a), _p(scale_b),
+                                             None if mask_src is None else mask_src.t.data_ptr(), _p(mask_thr), int(mask_mode),
                                              qs.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), len(qs), out.data_ptr(), ws.data_ptr(),
                                              M.C, M.G, M.ld, M.code, _stream()), "gene_quantiles")
     return out
@@ -349,3 +356,120 @@ def velocity_chain(Sx_sz: CellMatrix, Ux_sz: CellMatrix, gamma: torch.Tensor, q:
                                              float(dt_shift), float(dt_extrap), float(used_dt), int(assumption), int(clip), int(transform),
                                              float(psc), Sx_sz.code, _stream()), "velocity_chain")
     return {n: m for n, m in outs.items() if m is not None}
+
+
+# --------------------------------------------------------------------------- pre-step + E/F helpers
+def row_sums(M: CellMatrix) -> torch.Tensor:
+    """cell sizes: M.sum over genes per cell (S.sum(0) in the reference layout) -> (C,) fp64."""
+    out = torch.empty(M.C, dtype=torch.float64, device=M.t.device)
+    _lib.check(_lib.lib().vcy_row_sums(M.t.data_ptr(), out.data_ptr(), M.C, M.G, M.ld, M.code, _stream()), "row_sums")
+    return out
+
+
+def scale_log(M: CellMatrix, factor: Optional[torch.Tensor], want_sz: bool = True, want_norm: bool = True, pcount: float = 1.0,
+              fix_nonfinite: bool = False) -> Tuple[Optional[CellMatrix], Optional[CellMatrix]]:
+    """(factor[c] * M, log2(factor[c] * M + pcount)) -- analysis.py:549-551, 579-582."""
+    dev = M.t.device
+    sz = CellMatrix(torch.empty_like(M.t), M.G) if want_sz else None
+    nm = CellMatrix(torch.empty_like(M.t), M.G) if want_norm else None
+    factor = None if factor is None else factor.to(device=dev, dtype=torch.float64).contiguous()
+    _lib.check(_lib.lib().vcy_scale_log(M.t.data_ptr(), _p(factor), None if sz is None else sz.t.data_ptr(),
+                                        None if nm is None else nm.t.data_ptr(), M.C, M.G, M.ld, float(pcount), int(fix_nonfinite),
+                                        M.code, _stream()), "scale_log")
+    return sz, nm
+
+
+def delta_transform(hi_dim: CellMatrix, delta_S: CellMatrix, used_dt: float, mode: int, psc: float) -> Tuple[CellMatrix, Optional[CellMatrix]]:
+    """dmat (and e = log2(hi_dim + psc) for mode 3 = logratio) from a stored delta_S."""
+    assert hi_dim.t.shape == delta_S.t.shape and hi_dim.dtype == delta_S.dtype
+    dm = CellMatrix(torch.empty_like(hi_dim.t), hi_dim.G)
+    eo = CellMatrix(torch.empty_like(hi_dim.t), hi_dim.G) if mode == 3 else None
+    _lib.check(_lib.lib().vcy_delta_transform(hi_dim.t.data_ptr(), delta_S.t.data_ptr(), dm.t.data_ptr(), None if eo is None else eo.t.data_ptr(),
+                                              hi_dim.C, hi_dim.G, hi_dim.ld, float(used_dt), int(mode), float(psc), hi_dim.code, _stream()),
+               "delta_transform")
+    return dm, eo
+
+
+def corr_fixup(vals: torch.Tensor, ixs: torch.Tensor, cell0: int = 0, zero_self: bool = True, fix_nan: bool = True,
+               nan_to: float = 1.0) -> int:
+    """In place: zero the self pairs, NaN -> nan_to; returns the number of NaNs met (host sync)."""
+    ix = _as_i32(ixs, vals.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=vals.device)
+    _lib.check(_lib.lib().vcy_corr_fixup(vals.data_ptr(), ix.data_ptr(), cell0, vals.shape[0], vals.shape[1], int(zero_self), int(fix_nan),
+                                         float(nan_to), cnt.data_ptr(), _DT[vals.dtype], _stream()), "corr_fixup")
+    return int(cnt.item())
+
+
+def transition_prob(corr: torch.Tensor, ixs: torch.Tensor, embedding, sigma_corr: float, cell0: int = 0,
+                    want_tp: bool = True, want_wdiff: bool = True):
+    """(tp, wdiff, delta_embedding) in neighbour-list form -- see vcy_transition_prob."""
+    dev = corr.device
+    ix = _as_i32(ixs, dev)
+    emb = (torch.from_numpy(np.ascontiguousarray(embedding, dtype=np.float64)) if not isinstance(embedding, torch.Tensor) else embedding.double()).to(dev).contiguous()
+    C_out, n = corr.shape
+    tp = torch.empty_like(corr) if want_tp else None
+    wd = torch.empty_like(corr) if want_wdiff else None
+    de = torch.empty((C_out, emb.shape[1]), dtype=torch.float64, device=dev)
+    _lib.check(_lib.lib().vcy_transition_prob(corr.contiguous().data_ptr(), ix.data_ptr(), emb.data_ptr(), emb.shape[1], _p(tp), _p(wd),
+                                              de.data_ptr(), cell0, C_out, n, float(sigma_corr), _DT[corr.dtype], _stream()), "transition_prob")
+    return tp, wd, de
+
+
+def row_cosproj(A: CellMatrix, B: CellMatrix) -> torch.Tensor:
+    out = torch.empty(A.C, dtype=torch.float64, device=A.t.device)
+    _lib.check(_lib.lib().vcy_row_cosproj(A.t.data_ptr(), B.t.data_ptr(), out.data_ptr(), A.C, A.G, A.ld, A.code, _stream()), "row_cosproj")
+    return out
+
+
+def diffuse(x0, tr, n_steps: int, accumulate: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """n_steps of x <- x . tr on device.  tr: dense torch (n,n) f32/f64 or a scipy sparse matrix.
+    Returns (x_final, sum of the iterates if accumulate)."""
+    import scipy.sparse as sp
+    dev = require_gpu()
+    L = _lib.lib()
+    x = (torch.from_numpy(np.ascontiguousarray(x0, dtype=np.float64)) if not isinstance(x0, torch.Tensor) else x0.double()).to(dev).contiguous().clone()
+    n = x.numel()
+    y = torch.empty_like(x)
+    acc = torch.zeros_like(x) if accumulate else None
+    if sp.issparse(tr):
+        csc = sp.csc_matrix(tr)
+        csc.sort_indices()
+        colptr = torch.from_numpy(csc.indptr.astype(np.int64)).to(dev)
+        rowidx = torch.from_numpy(csc.indices.astype(np.int32)).to(dev)
+        val = torch.from_numpy(np.ascontiguousarray(csc.data, dtype=np.float64)).to(dev)
+        for _ in range(n_steps):
+            _lib.check(L.vcy_diffuse_step_csc(colptr.data_ptr(), rowidx.data_ptr(), val.data_ptr(), x.data_ptr(), y.data_ptr(), _p(acc), n, F64, _stream()), "diffuse_step_csc")
+            x, y = y, x
+    else:
+        T = tr.to(dev).contiguous()
+        assert T.shape == (n, n) and T.dtype in _DT
+        ws = torch.empty(int(L.vcy_diffuse_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        for _ in range(n_steps):
+            _lib.check(L.vcy_diffuse_step_dense(T.data_ptr(), x.data_ptr(), y.data_ptr(), _p(acc), ws.data_ptr(), n, _DT[T.dtype], _stream()), "diffuse_step_dense")
+            x, y = y, x
+    return x, acc
+
+
+def gamma_weights(S: CellMatrix, U: Optional[CellMatrix], mode: int, pa, pb, pc=None, pd=None, sa=None, sb=None, power: float = 15.0) -> CellMatrix:
+    """Dense W for the non-default fit_gammas weight modes (see vcy_gamma_weights)."""
+    dev = S.t.device
+    f64 = lambda t: None if t is None else t.to(device=dev, dtype=torch.float64).contiguous()
+    pa, pb, pc, pd, sa, sb = map(f64, (pa, pb, pc, pd, sa, sb))
+    W = CellMatrix(torch.empty_like(S.t), S.G)
+    _lib.check(_lib.lib().vcy_gamma_weights(S.t.data_ptr(), None if U is None else U.t.data_ptr(), W.t.data_ptr(), _p(pa), _p(pb), _p(pc), _p(pd),
+                                            _p(sa), _p(sb), S.C, S.G, S.ld, int(mode), float(power), S.code, _stream()), "gamma_weights")
+    return W
+
+
+def prepare_markov(indptr, indices, pval, embedding, sigma_D: float, sigma_W: float, dtype=torch.float64) -> torch.Tensor:
+    """Dense (n, n) Markov matrix on device from CSR transition probabilities (vcy_prepare_markov)."""
+    dev = require_gpu()
+    ip = torch.as_tensor(np.ascontiguousarray(indptr, dtype=np.int64)).to(dev) if not isinstance(indptr, torch.Tensor) else indptr.to(dev, torch.int64).contiguous()
+    ix = _as_i32(indices, dev)
+    pv = (torch.as_tensor(np.ascontiguousarray(pval, dtype=np.float64)) if not isinstance(pval, torch.Tensor) else pval.double()).to(dev).contiguous()
+    emb = (torch.from_numpy(np.ascontiguousarray(embedding, dtype=np.float64)) if not isinstance(embedding, torch.Tensor) else embedding.double()).to(dev).contiguous()
+    n = emb.shape[0]
+    tr = torch.empty((n, n), dtype=dtype, device=dev)
+    _lib.check(_lib.lib().vcy_prepare_markov(ip.data_ptr(), ix.data_ptr(), pv.data_ptr(), emb.data_ptr(), emb.shape[1], tr.data_ptr(), n,
+                                             float(sigma_D), float(sigma_W), _DT[dtype], _stream()), "prepare_markov")
+    return tr
