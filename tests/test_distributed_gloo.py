@@ -1,0 +1,100 @@
+"""World-size-2 (and 3, ragged) checks of the cell-sharding logic over torch.distributed `gloo` on CPU.
+
+The collectives of the N>1 path (velocyto_amd.distributed) are exercised with the CPU oracle standing
+in for the per-shard kernels: sharded stage B (all-reduce of per-gene moments) and stage D
+(all-gather of Sx shards, then of compact correlation rows) must reproduce the unsharded result.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, C, G, nr, q):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import velocyto_amd
+        from velocyto_amd import distributed as D
+        import oracle
+        rng = np.random.default_rng(7)                       # identical replicated inputs on every rank
+        Sx = rng.gamma(2.0, 1.0, (G, C))
+        Ux = rng.gamma(1.0, 1.0, (G, C)) * (rng.random((G, C)) < 0.7)
+        dmat = rng.normal(size=(G, C))
+        ixs = np.stack([rng.choice(C, nr, replace=False) for _ in range(C)])
+        c0, c1 = D.shard_bounds(C, world, rank)
+        assert D.world() == (rank, world)
+        # B: local moments over my cells -> all-reduce -> gamma
+        mom = torch.tensor(np.stack([(Sx[:, c0:c1] ** 2).sum(1), (Sx[:, c0:c1] * Ux[:, c0:c1]).sum(1), (Ux[:, c0:c1] ** 2).sum(1)]))
+        D.all_reduce_sum(mom)
+        gamma = np.maximum(0, mom[1].numpy() / mom[0].numpy()).astype(np.float32)
+        # D: all-gather the Sx shards (cells-major rows), correlations of my cells, all-gather the compact rows
+        Sx_loc = torch.tensor(np.ascontiguousarray(Sx.T[c0:c1]))
+        Sx_full = D.all_gather_rows(Sx_loc, C).numpy().T
+        corr_loc = oracle.coldeltacor_partial_compact(Sx_full, dmat, ixs, "sqrt", 1e-10, c0=c0, c1=c1)[c0:c1]
+        corr = D.all_gather_rows(torch.tensor(corr_loc), C)
+        out_buf = torch.empty((C, nr), dtype=torch.float64)
+        assert D.all_gather_rows(torch.tensor(corr_loc), C, out=out_buf) is out_buf and torch.equal(torch.nan_to_num(out_buf, nan=9.0), torch.nan_to_num(corr, nan=9.0))
+        if rank == 0:
+            q.put((gamma, corr.numpy(), Sx_full))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,C", [(2, 40), (2, 41), (3, 41)])
+def test_sharded_path_matches_unsharded(world, C, oracle):
+    G, nr = 50, 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, C, G, nr, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    gamma, corr, Sx_full = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(7)
+    Sx = rng.gamma(2.0, 1.0, (G, C))
+    Ux = rng.gamma(1.0, 1.0, (G, C)) * (rng.random((G, C)) < 0.7)
+    dmat = rng.normal(size=(G, C))
+    ixs = np.stack([rng.choice(C, nr, replace=False) for _ in range(C)])
+    np.testing.assert_array_equal(Sx_full, Sx)
+    np.testing.assert_allclose(gamma, oracle.fit_slope(Ux, Sx), rtol=1e-6)
+    ref = oracle.coldeltacor_partial_compact(Sx, dmat, ixs, "sqrt", 1e-10)
+    np.testing.assert_array_equal(np.isnan(corr), np.isnan(ref))
+    np.testing.assert_allclose(np.nan_to_num(corr), np.nan_to_num(ref), atol=1e-14)
+
+
+def test_shard_bounds_cover_and_balance():
+    sys.path.insert(0, ROOT)
+    import velocyto_amd
+    from velocyto_amd import distributed as D
+    for n in (1, 7, 8, 50000, 50001):
+        for w in (1, 2, 3, 8):
+            b = D.all_shard_bounds(n, w)
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [y - x for x, y in b]
+            assert max(sizes) - min(sizes) <= 1
+    assert D.world() == (0, 1)
+    t = torch.arange(6.0).reshape(3, 2)
+    assert D.all_gather_rows(t, 3) is t and D.all_reduce_sum(t) is t       # world size 1: no-ops
