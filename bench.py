@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass (else null)")
+    ap.add_argument("--slab", type=int, default=0, help="gene slab of the pooling kernel (0 = library default)")
     ap.add_argument("--order", choices=["natural", "embedding"], default="embedding",
                     help="schedule order of the cells in stage D (results are order-independent)")
     return ap.parse_args()
@@ -112,21 +113,6 @@ def sample_neighbors_device(embedding, n_neighbors, sampled_fraction, dev, seed=
     return torch.gather(idx, 1, sel).contiguous(), idx
 
 
-def embedding_order(embedding, dev):
-    """Morton order of the 2-d embedding: consecutive workgroups share neighbours (Infinity-Cache reuse)."""
-    e = embedding[:, :2].float()
-    q = ((e - e.min(0).values) / (e.max(0).values - e.min(0).values + 1e-30) * 65535).long()
-
-    def spread(v):
-        v = (v | (v << 8)) & 0x00FF00FF
-        v = (v | (v << 4)) & 0x0F0F0F0F
-        v = (v | (v << 2)) & 0x33333333
-        v = (v | (v << 1)) & 0x55555555
-        return v
-    code = spread(q[:, 0]) | (spread(q[:, 1]) << 1)
-    return torch.argsort(code).to(torch.int32)
-
-
 class Pipeline:
     def __init__(self, args, dev, rank, world):
         from velocyto_amd import ops, distributed
@@ -141,8 +127,9 @@ class Pipeline:
         self.c0, self.c1 = distributed.shard_bounds(C, world, rank)
         nloc = self.c1 - self.c0
         self.neigh_loc = self.neigh[self.c0:self.c1].contiguous()
-        order = embedding_order(emb[self.c0:self.c1], dev) if args.order == "embedding" else None
-        self.order = order
+        self.order = ops.morton_order(emb[self.c0:self.c1], 2) if args.order == "embedding" else None
+        # pooling schedule: Morton order over the leading PCs of the kNN space (locality sort, results unchanged)
+        self.pool_order = ops.morton_order(self.space[self.c0:self.c1], 3) if args.order == "embedding" else None
         # persistent outputs
         self.Sx_loc = ops.CellMatrix.empty(nloc, G, torch.float32)
         self.Ux_loc = ops.CellMatrix.empty(nloc, G, torch.float32)
@@ -167,8 +154,11 @@ class Pipeline:
         wrow = wrow / wrow.sum(1, keepdim=True)
         indices = torch.cat([torch.arange(c0, c1, device=self.dev, dtype=torch.int32)[:, None], idx], 1).contiguous()
         indptr = torch.arange(0, (nloc + 1) * (k + 1), k + 1, device=self.dev, dtype=torch.int64)
-        ops.knn_pool(self.S, indptr, indices, wrow.contiguous(), cell0=c0, C_out=nloc, out=self.Sx_loc, validate=False)
-        ops.knn_pool(self.U, indptr, indices, wrow.contiguous(), cell0=c0, C_out=nloc, out=self.Ux_loc, validate=False)
+        wrow = wrow.contiguous()
+        ops.knn_pool(self.S, indptr, indices, wrow, cell0=c0, C_out=nloc, out=self.Sx_loc, validate=False, order=self.pool_order,
+                     slab_genes=self.a.slab)
+        ops.knn_pool(self.U, indptr, indices, wrow, cell0=c0, C_out=nloc, out=self.Ux_loc, validate=False, order=self.pool_order,
+                     slab_genes=self.a.slab)
         ev[1].record()
         # ---- B: fit_slope (estimation.py:267-279); sharded: all-reduce of the per-gene moments
         mom = ops.fit_slope_moments(self.Ux_loc, self.Sx_loc)

@@ -101,9 +101,12 @@ int vcy_scatter_rows(const void *vals, const int32_t *ixs, void *rm, int64_t C_o
  * sum to one.  maximum != 0 additionally takes max(out[c,:], data[cell0+c,:]).
  * slab_genes: genes per pass (0 = default); the launch walks gene slabs so that one slab of
  * all cells (C * slab * 4 B) stays resident in the 256 MiB Infinity Cache while it is
- * gathered k times.                                                                      */
+ * gathered k times.  order (optional, NULL = natural): permutation of 0..C_out-1, the order in
+ * which cells are scheduled within a slab; a locality-sorted order (cells close in the kNN space
+ * next to each other) lets co-resident workgroups share neighbour rows in the per-XCD L2.
+ * Results do not depend on it.                                                              */
 int vcy_knn_pool(const void *data, void *out, const int64_t *indptr, const int32_t *indices, const void *w,
-                 int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int maximum,
+                 const int32_t *order, int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int maximum,
                  int64_t slab_genes, int dtype, vcy_stream stream);
 
 /* Exact Euclidean kNN in a low-dimensional space (what sklearn NearestNeighbors provides to

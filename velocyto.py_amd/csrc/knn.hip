@@ -9,10 +9,14 @@
 //   phase 1  fp32 squared distances to all C candidates, lanes over candidates reading the
 //            feature-major (P, C) copy of the space (coalesced), 8 accumulators per lane;
 //            the (8, C) distance rows go to a workspace that stays L2-resident for phase 2.
-//   phase 2  per query: MSB-first radix select on the 64-bit key (sortable distance bits << 32
-//            | candidate index) -> exactly Ksel = k + margin smallest keys, ties by index,
-//            deterministic; gather them, recompute their distances exactly in fp64, bitonic-
-//            sort (fp64 distance, index) in LDS and emit the first k.
+//   phase 2  per query: find a threshold T with count(row <= T) >= Ksel = k + margin:
+//            fast path - every thread kept the two smallest distances of its strided slice in
+//            phase 1; the Ksel-th smallest of those 512 local minima bounds the true Ksel-th
+//            from above and is tight (one 512-element bitonic sort in LDS, no atomics on the
+//            row); fallback - MSB-first radix select on the 64-bit key (sortable distance bits
+//            << 32 | index) giving exactly Ksel keys.  Then gather the candidates <= T,
+//            recompute their distances exactly in fp64, bitonic-sort (fp64 distance, index) in
+//            LDS and emit the first k.  Both paths are deterministic, ties by index.
 // The fp32 pass only has to get the candidate SET right (margin of 8 near-ties); order and
 // returned distances are fp64, matching the reference's fp64 search up to exact ties (which
 // sklearn orders arbitrarily and this kernel orders by index; with include_self the query is an
@@ -41,6 +45,7 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
     int *si = reinterpret_cast<int *>(sd + nsort);                    // [nsort] indices
     float *xq = reinterpret_cast<float *>(si + nsort);                // [QB][P]
     __shared__ unsigned hist[256];
+    __shared__ float cand[512];
     __shared__ unsigned long long s_prefix;
     __shared__ unsigned s_rank, s_count;
     const int tid = threadIdx.x;
@@ -54,6 +59,9 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
     __syncthreads();
     // ---- phase 1: distances
     float *wrow = ws + (int64_t)qb0 * C;
+    float m0[KNN_QB], m1[KNN_QB];       // two smallest distances this thread has seen, per query
+#pragma unroll
+    for (int qq = 0; qq < KNN_QB; ++qq) { m0[qq] = INFINITY; m1[qq] = INFINITY; }
     for (int j = tid; j < C; j += 256) {
         float acc[KNN_QB];
 #pragma unroll
@@ -72,6 +80,10 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
                 float v = acc[qq];
                 if (!include_self && (int64_t)j == q0 + qb0 + qq) v = INFINITY;   // query excluded (kneighbors_graph(X=None))
                 wrow[(int64_t)qq * C + j] = v;
+                if (v < m1[qq]) {
+                    if (v < m0[qq]) { m1[qq] = m0[qq]; m0[qq] = v; }
+                    else m1[qq] = v;
+                }
             }
         }
     }
@@ -81,6 +93,42 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
         const float *row = wrow + (int64_t)qq * C;
         const int64_t qcell = q0 + qb0 + qq;
         unsigned long long prefix = 0;
+        bool have_threshold = false;
+        if (ksel <= 512) {
+            // ---- fast path: threshold from the 512 per-thread local minima
+            float mm0 = m0[0], mm1 = m1[0];
+#pragma unroll
+            for (int t = 1; t < KNN_QB; ++t) { if (qq == t) { mm0 = m0[t]; mm1 = m1[t]; } }
+            cand[2 * tid] = mm0;
+            cand[2 * tid + 1] = mm1;
+            __syncthreads();
+            for (int size = 2; size <= 512; size <<= 1) {
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    const int lo = 2 * tid - (tid & (stride - 1)), hi = lo + stride;
+                    const bool up = ((lo & size) == 0);
+                    const float a = cand[lo], b = cand[hi];
+                    if ((a > b) == up) { cand[lo] = b; cand[hi] = a; }
+                    __syncthreads();
+                }
+            }
+            const float T = cand[ksel - 1];
+            __syncthreads();
+            if (T < INFINITY) {
+                if (tid == 0) s_count = 0;
+                for (int t = tid; t < nsort; t += 256) { sd[t] = INFINITY; si[t] = 0x7fffffff; }
+                __syncthreads();
+                for (int j = tid; j < C; j += 256) {
+                    if (row[j] <= T) {
+                        const unsigned pos = atomicAdd(&s_count, 1u);
+                        if (pos < (unsigned)nsort) si[pos] = j;
+                    }
+                }
+                __syncthreads();
+                have_threshold = s_count <= (unsigned)nsort;   // >= ksel by construction
+                __syncthreads();
+            }
+        }
+        if (!have_threshold) {
         unsigned rank = (unsigned)(ksel - 1);
         for (int pass = 0; pass < 8; ++pass) {
             const int shift = 8 * (7 - pass);
@@ -129,7 +177,9 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
             }
         }
         __syncthreads();
-        for (int t = tid; t < ksel; t += 256) {
+        }   // fallback
+        const int ncand = have_threshold ? (int)s_count : ksel;
+        for (int t = tid; t < ncand; t += 256) {
             const int j = si[t];
             double d2 = 0.0;
             const double *a = x64 + qcell * P, *b = x64 + (int64_t)j * P;
@@ -181,7 +231,8 @@ extern "C" int vcy_knn_search(const float *xt, const double *x64, int32_t *idx, 
     if (ksel > avail) ksel = avail;
     if (ksel > KNN_MAXSEL)
         return fail(VCY_ERR_UNSUPPORTED, "%s: k=%lld exceeds the in-LDS selection limit (%lld)", "knn_search", (long long)k, (long long)(KNN_MAXSEL - KNN_MARGIN));
-    int nsort = 2;
+    int nsort = 128;                        // room for the candidates <= threshold (>= ksel of them)
+    while (nsort < 4 * ksel && nsort < KNN_MAXSEL) nsort <<= 1;
     while (nsort < ksel) nsort <<= 1;
     const size_t lds = (size_t)nsort * (sizeof(double) + sizeof(int)) + (size_t)KNN_QB * P * sizeof(float);
     VCY_REQUIRE(lds <= 150 * 1024, "knn_search: feature dimension too large for LDS");

@@ -15,13 +15,16 @@ namespace vcy {
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_knn_pool(const T *__restrict__ data, T *__restrict__ out, const int64_t *__restrict__ indptr,
-                                                   const int32_t *__restrict__ indices, const T *__restrict__ w, int G, int64_t ld,
+                                                   const int32_t *__restrict__ indices, const T *__restrict__ w,
+                                                   const int32_t *__restrict__ order, int G, int64_t ld,
                                                    int64_t cell0, int C_out, int slab, int maximum)
 {
     using V = typename Vec<T>::type;
     constexpr int N = Vec<T>::N;
     const int64_t b = blockIdx.x;
-    const int s = (int)(b / C_out), cl = (int)(b % C_out);   // slab-major block order
+    const int s = (int)(b / C_out);                          // slab-major block order
+    const int cl = order ? order[b % C_out] : (int)(b % C_out);   // schedule position -> cell (locality-sorted orders
+                                                                  // make co-resident blocks share neighbours in L2)
     const int g0 = s * slab, g1 = min(G, g0 + slab);
     const int64_t p0 = indptr[cl], p1 = indptr[cl + 1];
     const int nvec = (g1 - g0) / N;                        // slab and ld are multiples of N; tail handled below
@@ -75,8 +78,8 @@ __global__ __launch_bounds__(256) void k_knn_pool(const T *__restrict__ data, T 
 using namespace vcy;
 
 extern "C" int vcy_knn_pool(const void *data, void *out, const int64_t *indptr, const int32_t *indices, const void *w,
-                            int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int maximum, int64_t slab_genes,
-                            int dtype, vcy_stream stream)
+                            const int32_t *order, int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int maximum,
+                            int64_t slab_genes, int dtype, vcy_stream stream)
 {
     VCY_REQUIRE(data && out && indptr && indices && w, "knn_pool: null pointer");
     VCY_REQUIRE(C > 0 && G > 0 && ld >= G && C_out > 0 && cell0 >= 0 && cell0 + C_out <= C, "knn_pool: bad shape");
@@ -94,10 +97,10 @@ extern "C" int vcy_knn_pool(const void *data, void *out, const int64_t *indptr, 
     hipStream_t st = as_stream(stream);
     if (dtype == VCY_F32)
         hipLaunchKernelGGL(k_knn_pool<float>, dim3((unsigned)blocks), dim3(threads), 0, st, (const float *)data, (float *)out, indptr,
-                           indices, (const float *)w, (int)G, ld, cell0, (int)C_out, (int)slab, maximum);
+                           indices, (const float *)w, order, (int)G, ld, cell0, (int)C_out, (int)slab, maximum);
     else
         hipLaunchKernelGGL(k_knn_pool<double>, dim3((unsigned)blocks), dim3(threads), 0, st, (const double *)data, (double *)out, indptr,
-                           indices, (const double *)w, (int)G, ld, cell0, (int)C_out, (int)slab, maximum);
+                           indices, (const double *)w, order, (int)G, ld, cell0, (int)C_out, (int)slab, maximum);
     VCY_LAUNCH_CHECK();
     return VCY_OK;
 }

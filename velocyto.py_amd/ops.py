@@ -200,7 +200,7 @@ def scatter_rows(vals: torch.Tensor, ixs, ncols: int, rm: Optional[torch.Tensor]
 # --------------------------------------------------------------------------- stage A
 def knn_pool(data: CellMatrix, indptr, indices, weights, maximum: bool = False, cell0: int = 0,
              C_out: Optional[int] = None, slab_genes: int = 0, out: Optional[CellMatrix] = None,
-             validate: bool = True) -> CellMatrix:
+             validate: bool = True, order: Optional[torch.Tensor] = None) -> CellMatrix:
     """out[c,:] = sum_p w[p] data[indices[p],:] over CSR row c (neighbors.py:416-423 on device)."""
     dev = data.t.device
     C_out = data.C - cell0 if C_out is None else C_out
@@ -212,7 +212,10 @@ def knn_pool(data: CellMatrix, indptr, indices, weights, maximum: bool = False, 
         raise ValueError("neighbour index out of range")
     if out is None:
         out = CellMatrix.empty(C_out, data.G, data.dtype)
-    _lib.check(_lib.lib().vcy_knn_pool(data.t.data_ptr(), out.t.data_ptr(), ip.data_ptr(), ix.data_ptr(), w.data_ptr(), data.C,
+    if order is not None:
+        order = order.to(device=dev, dtype=torch.int32).contiguous()
+        assert order.numel() == C_out
+    _lib.check(_lib.lib().vcy_knn_pool(data.t.data_ptr(), out.t.data_ptr(), ip.data_ptr(), ix.data_ptr(), w.data_ptr(), _p(order), data.C,
                                        data.G, data.ld, cell0, C_out, int(maximum), int(slab_genes), data.code, _stream()), "knn_pool")
     return out
 
@@ -473,3 +476,19 @@ def prepare_markov(indptr, indices, pval, embedding, sigma_D: float, sigma_W: fl
     _lib.check(_lib.lib().vcy_prepare_markov(ip.data_ptr(), ix.data_ptr(), pv.data_ptr(), emb.data_ptr(), emb.shape[1], tr.data_ptr(), n,
                                              float(sigma_D), float(sigma_W), _DT[dtype], _stream()), "prepare_markov")
     return tr
+
+
+def morton_order(points, dims: int = 2) -> torch.Tensor:
+    """Z-order (Morton) permutation of the rows of `points` over their first `dims` (2 or 3) coordinates:
+    a cheap locality sort used only to SCHEDULE cells (kernels give identical results in any order)."""
+    dev = require_gpu()
+    p = (torch.from_numpy(np.ascontiguousarray(points, dtype=np.float64)) if not isinstance(points, torch.Tensor) else points).to(dev)
+    p = p[:, :dims].double()
+    lo, hi = p.min(0).values, p.max(0).values
+    bits = 16 if dims == 2 else 10
+    q = ((p - lo) / (hi - lo + 1e-300) * (2 ** bits - 1)).long()
+    code = torch.zeros(p.shape[0], dtype=torch.int64, device=dev)
+    for b in range(bits):
+        for d in range(dims):
+            code |= ((q[:, d] >> b) & 1) << (b * dims + d)
+    return torch.argsort(code).to(torch.int32)
