@@ -116,8 +116,9 @@ int vcy_knn_pool(const void *data, void *out, const int64_t *indptr, const int32
  * For queries q0..q0+Q-1 writes the k nearest (the query itself excluded when include_self == 0,
  * an ordinary distance-0 candidate otherwise), nearest first, ties by index: idx (Q,k) int32,
  * dist (Q,k) fp64.
- * workspace: vcy_knn_workspace_bytes(C, Q) bytes.                                        */
-size_t vcy_knn_workspace_bytes(int64_t C, int64_t Q);
+ * Any k < C: candidate lists up to ~4k entries are sorted in LDS, larger ones in the workspace.
+ * workspace: vcy_knn_workspace_bytes(C, Q, k) bytes.                                     */
+size_t vcy_knn_workspace_bytes(int64_t C, int64_t Q, int64_t k);
 int vcy_knn_search(const float *xt, const double *x64, int32_t *idx, double *dist, void *workspace,
                    int64_t C, int64_t P, int64_t ldx, int64_t q0, int64_t Q, int64_t k, int include_self,
                    vcy_stream stream);

@@ -185,8 +185,14 @@ def test_knn_search_blocks_and_limits(ops, oracle):
     np.testing.assert_allclose(dist.cpu().numpy(), od, atol=1e-12)
     i2, d2 = ops.knn_search(space, 30, q0=700, Q=33)
     assert np.array_equal(i2.cpu().numpy(), oi[700:733])
-    with pytest.raises(NotImplementedError):
-        ops.knn_search(rng.normal(size=(6000, 2)), 5000)
+    # large k (candidate lists sorted in the global workspace instead of LDS), e.g. n_neighbors = C/5 defaults
+    emb = rng.normal(size=(6000, 2))
+    i3, d3 = ops.knn_search(emb, 5000, q0=100, Q=19)
+    od, oi = oracle.knn_search(emb, 5000)
+    assert np.array_equal(i3.cpu().numpy(), oi[100:119])
+    np.testing.assert_allclose(d3.cpu().numpy(), od[100:119], atol=1e-12)
+    with pytest.raises(ValueError):
+        ops.knn_search(emb, 6000)
 
 
 def test_fit_slope_golden(ops, golden):

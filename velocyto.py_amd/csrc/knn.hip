@@ -36,14 +36,27 @@ __device__ __forceinline__ uint32_t f32_key(float f)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// LARGE = false: candidate arrays (fp64 distance, index)[nsort] live in LDS (k <= ~4k);
+// LARGE = true : they live in a per-workgroup slice of the global workspace (any k < C), same code.
+template <bool LARGE>
 __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt, const double *__restrict__ x64, int32_t *__restrict__ idx_out,
-                                                     double *__restrict__ dist_out, float *__restrict__ ws, int C, int P, int64_t ldx,
-                                                     int64_t q0, int Q, int k, int ksel, int nsort, int include_self)
+                                                     double *__restrict__ dist_out, float *__restrict__ ws, char *__restrict__ ws_sort, int C, int P,
+                                                     int64_t ldx, int64_t q0, int Q, int k, int ksel, int nsort, int include_self)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *sd = reinterpret_cast<double *>(smem);                    // [nsort] fp64 distances
-    int *si = reinterpret_cast<int *>(sd + nsort);                    // [nsort] indices
-    float *xq = reinterpret_cast<float *>(si + nsort);                // [QB][P]
+    double *sd;
+    int *si;
+    float *xq;
+    if (LARGE) {
+        char *mine = ws_sort + (size_t)blockIdx.x * (size_t)nsort * (sizeof(double) + sizeof(int));
+        sd = reinterpret_cast<double *>(mine);
+        si = reinterpret_cast<int *>(sd + nsort);
+        xq = reinterpret_cast<float *>(smem);
+    } else {
+        sd = reinterpret_cast<double *>(smem);                        // [nsort] fp64 distances
+        si = reinterpret_cast<int *>(sd + nsort);                     // [nsort] indices
+        xq = reinterpret_cast<float *>(si + nsort);                   // [QB][P]
+    }
     __shared__ unsigned hist[256];
     __shared__ float cand[512];
     __shared__ unsigned long long s_prefix;
@@ -214,10 +227,26 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
 
 using namespace vcy;
 
-extern "C" size_t vcy_knn_workspace_bytes(int64_t C, int64_t Q)
+static int knn_plan(int64_t C, int64_t k, int include_self, int64_t *ksel_out, int *nsort_out, bool *large_out)
+{
+    const int64_t avail = include_self ? C : C - 1;
+    int64_t ksel = k + KNN_MARGIN;
+    if (ksel > avail) ksel = avail;
+    int nsort = 128;                        // room for the candidates <= threshold (>= ksel of them)
+    while (nsort < 4 * ksel && nsort < KNN_MAXSEL) nsort <<= 1;
+    while (nsort < ksel) nsort <<= 1;
+    *ksel_out = ksel; *nsort_out = nsort; *large_out = nsort > KNN_MAXSEL;
+    return 0;
+}
+
+extern "C" size_t vcy_knn_workspace_bytes(int64_t C, int64_t Q, int64_t k)
 {
     const int64_t qpad = (Q + KNN_QB - 1) / KNN_QB * KNN_QB;
-    return (size_t)qpad * (size_t)C * sizeof(float);
+    size_t bytes = (size_t)qpad * (size_t)C * sizeof(float);
+    int64_t ksel; int nsort; bool large;
+    knn_plan(C, k, 1, &ksel, &nsort, &large);
+    if (large) bytes += (size_t)(qpad / KNN_QB) * (size_t)nsort * (sizeof(double) + sizeof(int)) + 256;
+    return bytes;
 }
 
 extern "C" int vcy_knn_search(const float *xt, const double *x64, int32_t *idx, double *dist, void *workspace, int64_t C, int64_t P,
@@ -227,19 +256,22 @@ extern "C" int vcy_knn_search(const float *xt, const double *x64, int32_t *idx, 
     VCY_REQUIRE(C > 1 && P > 0 && ldx >= C && Q > 0 && q0 >= 0 && q0 + Q <= C, "knn_search: bad shape");
     const int64_t avail = include_self ? C : C - 1;
     VCY_REQUIRE(k > 0 && k <= avail, "knn_search: k exceeds the number of candidates");
-    int64_t ksel = k + KNN_MARGIN;
-    if (ksel > avail) ksel = avail;
-    if (ksel > KNN_MAXSEL)
-        return fail(VCY_ERR_UNSUPPORTED, "%s: k=%lld exceeds the in-LDS selection limit (%lld)", "knn_search", (long long)k, (long long)(KNN_MAXSEL - KNN_MARGIN));
-    int nsort = 128;                        // room for the candidates <= threshold (>= ksel of them)
-    while (nsort < 4 * ksel && nsort < KNN_MAXSEL) nsort <<= 1;
-    while (nsort < ksel) nsort <<= 1;
-    const size_t lds = (size_t)nsort * (sizeof(double) + sizeof(int)) + (size_t)KNN_QB * P * sizeof(float);
-    VCY_REQUIRE(lds <= 150 * 1024, "knn_search: feature dimension too large for LDS");
-    VCY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_knn_search), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t ksel; int nsort; bool large;
+    knn_plan(C, k, include_self, &ksel, &nsort, &large);
+    const int64_t qpad = (Q + KNN_QB - 1) / KNN_QB * KNN_QB;
+    char *ws_sort = (char *)workspace + (((size_t)qpad * (size_t)C * sizeof(float) + 255) & ~(size_t)255);
     const unsigned blocks = (unsigned)((Q + KNN_QB - 1) / KNN_QB);
-    hipLaunchKernelGGL(k_knn_search, dim3(blocks), dim3(256), lds, as_stream(stream), xt, x64, idx, dist, (float *)workspace, (int)C, (int)P,
-                       ldx, q0, (int)Q, (int)k, (int)ksel, nsort, include_self);
+    const size_t lds = (large ? 0 : (size_t)nsort * (sizeof(double) + sizeof(int))) + (size_t)KNN_QB * P * sizeof(float);
+    VCY_REQUIRE(lds <= 150 * 1024, "knn_search: feature dimension too large for LDS");
+    if (large) {
+        VCY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_knn_search<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_knn_search<true>, dim3(blocks), dim3(256), lds, as_stream(stream), xt, x64, idx, dist, (float *)workspace, ws_sort, (int)C,
+                           (int)P, ldx, q0, (int)Q, (int)k, (int)ksel, nsort, include_self);
+    } else {
+        VCY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_knn_search<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_knn_search<false>, dim3(blocks), dim3(256), lds, as_stream(stream), xt, x64, idx, dist, (float *)workspace, ws_sort, (int)C,
+                           (int)P, ldx, q0, (int)Q, (int)k, (int)ksel, nsort, include_self);
+    }
     VCY_LAUNCH_CHECK();
     return VCY_OK;
 }

@@ -235,7 +235,7 @@ def knn_search(space, k: int, include_self: bool = False, q0: int = 0, Q: Option
     dist = torch.empty((Q, k), dtype=torch.float64, device=dev)
     L = _lib.lib()
     qb = min(Q, query_block)
-    ws = torch.empty(int(L.vcy_knn_workspace_bytes(C, qb)), dtype=torch.uint8, device=dev)
+    ws = torch.empty(int(L.vcy_knn_workspace_bytes(C, qb, k)), dtype=torch.uint8, device=dev)
     for s in range(0, Q, qb):
         n = min(qb, Q - s)
         _lib.check(L.vcy_knn_search(xt.data_ptr(), x64.data_ptr(), idx[s:s + n].data_ptr(), dist[s:s + n].data_ptr(), ws.data_ptr(),
