@@ -13,6 +13,7 @@
 // per cell and parked in LDS.  Algorithmic bytes per cell = (nrndm + 2) * G * sizeof(T)
 // + nrndm * (4 + sizeof(T)).  ~14 VALU lane-ops + 1 transcendental per 4 B loaded keeps the
 // VALU at ~1/3 of its rate when HBM runs at 6 TB/s, so the kernel is HBM-bound by design.
+#include <stdlib.h>
 #include "common.h"
 
 namespace vcy {
@@ -34,6 +35,8 @@ template <typename T, int TR, int RULES> __device__ __forceinline__ T xform(T t,
     if (TR == VCY_LINEAR) return t;
     const T a = fabs(t) + psc;
     const T s = (TR == VCY_SQRT) ? fast_sqrt<T>(a) : fast_log10<T>(a);
+    if (TR == VCY_SQRT && RULES == VCY_RULES_PARTIAL)        // hot variant: one v_bfi (copysign) + one compare/select
+        return (fabs(t) < T(1e-16)) ? T(0) : copysign(s, t);
     T r;
     if (TR == VCY_LOG10 && RULES == VCY_RULES_PARTIAL) r = (t >= T(0)) ? s : -s;
     else r = (t > T(0)) ? s : -s;
@@ -169,6 +172,238 @@ __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// Grouped partial kernel: the same numbers as k_cdc_partial, but a workgroup owns GC cells that are
+// adjacent in the schedule order (Morton order of the embedding => near each other) and walks the
+// UNION of their neighbour lists, so a neighbour row shared by several cells of the group is read
+// from HBM once and correlated against each of them out of LDS.  At 50k cells / nrndm 250 a group
+// of 8 shares each row 3.5x on average (tools/neighbor_overlap.py), which moves the kernel from the
+// HBM roofline to the VALU/transcendental one.
+//   1. (neighbour, member, slot) keys of the group are bitonic-sorted in LDS; equal neighbours form
+//      segments (row r -> pairs seg[r]..seg[r+1]).
+//   2. genes are walked in chunks of NV*64 vectors; e[c_m], d[c_m] of all members are staged in LDS.
+//   3. wave w takes rows r = w, w+nwaves, ...: loads the row chunk ONCE into registers, then for each
+//      pair of the segment accumulates the three raw moments against member m's LDS copy, reduces
+//      over the wave and adds into acc[pair] (owned by that wave: deterministic, no atomics).
+constexpr int GRP_MAX_NV = 6;
+
+template <typename T, int TR, int RULES, int GC>
+__global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restrict__ e, const T *__restrict__ d,
+                                                               const int32_t *__restrict__ ixs, T *__restrict__ out,
+                                                               const int32_t *__restrict__ order, int G, int64_t ld, int64_t cell0,
+                                                               int64_t d_row0, int C_out, int nrndm, int npad, T psc)
+{
+    using V = typename Vec<T>::type;
+    constexpr int N = Vec<T>::N;
+    constexpr int NV = GRP_MAX_NV;
+    constexpr int GCHUNK = NV * 64 * N;                         // genes per chunk
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int maxpairs = GC * nrndm;
+    T *ec = reinterpret_cast<T *>(smem);                        // [GC][GCHUNK]
+    T *dc = ec + GC * GCHUNK;                                   // [GC][GCHUNK]
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(dc + GC * GCHUNK);   // [npad]
+    T *acc = reinterpret_cast<T *>(keys + npad);                // [3 * maxpairs]
+    int *seg = reinterpret_cast<int *>(acc + 3 * ((maxpairs + 1) & ~1));   // [maxpairs + 2]
+    double *part = reinterpret_cast<double *>(seg + ((maxpairs + 3) & ~1)); // [64] per-wave d-moment partials
+    // (no static __shared__: statics would precede the dynamic region and break its 16-byte alignment)
+    double *s_sb = part + 64, *s_sbb = s_sb + GC;               // [GC] each
+    int *s_cells = reinterpret_cast<int *>(s_sbb + GC);         // [GC]
+    int *s_wavetot = s_cells + GC;                              // [16]
+    int &s_U = s_wavetot[16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int g0cell = blockIdx.x * GC;
+    const int gcount = min(GC, C_out - g0cell);
+    const int npairs = gcount * nrndm;
+    if (tid < GC) s_cells[tid] = tid < gcount ? (order ? order[g0cell + tid] : g0cell + tid) : 0;
+    __syncthreads();
+    // ---- 1. keys = (neighbour << 16) | (member << 12) | slot, sorted
+    for (int t = tid; t < npad; t += blockDim.x) {
+        unsigned long long key = ~0ull;
+        if (t < npairs) {
+            const int m = t / nrndm, n = t - m * nrndm;
+            const unsigned i = (unsigned)ixs[(int64_t)s_cells[m] * nrndm + n];
+            key = ((unsigned long long)i << 16) | ((unsigned long long)m << 12) | (unsigned)n;
+        }
+        keys[t] = key;
+    }
+    __syncthreads();
+    for (int size = 2; size <= npad; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < npad / 2; t += blockDim.x) {
+                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    // segment heads -> seg[] via a block-wide exclusive scan (each thread owns a contiguous run)
+    {
+        const int per = (npad + blockDim.x - 1) / blockDim.x;
+        const int t0 = tid * per, t1 = min(npairs, t0 + per);
+        int cnt = 0;
+        for (int t = t0; t < t1; ++t) cnt += (t == 0 || (keys[t] >> 16) != (keys[t - 1] >> 16)) ? 1 : 0;
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+        if (lane == 63) s_wavetot[wave] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += s_wavetot[w];
+        int rank = base + incl - cnt;
+        for (int t = t0; t < t1; ++t)
+            if (t == 0 || (keys[t] >> 16) != (keys[t - 1] >> 16)) seg[rank++] = t;
+        if (tid == blockDim.x - 1) { s_U = base + incl; }
+        __syncthreads();
+        if (tid == 0) seg[s_U] = npairs;
+    }
+    for (int t = tid; t < 3 * npairs; t += blockDim.x) acc[t] = T(0);
+    if (tid < 64) part[tid] = 0.0;
+    __syncthreads();
+    const int U = s_U;
+    // staging roles: wave w stages member (w % GC), interleaved with the other waves of that member
+    const int sm = wave % GC, sh = wave / GC, snh = max(1, nwaves / GC);
+    double psb = 0.0, psbb = 0.0;
+
+    for (int g0 = 0; g0 < G; g0 += GCHUNK) {
+        const int gl = min(GCHUNK, G - g0);
+        const int nvec = (gl + N - 1) / N;                       // last vector may be partial: rows are zero-padded to ld
+        const bool ragged = (gl % N) != 0;
+        __syncthreads();
+        if (sh < snh && sm < gcount) {
+            const int64_t c = cell0 + s_cells[sm];
+            const T *er = e + c * ld + g0, *dr = d + (c - d_row0) * ld + g0;
+            for (int v = sh * 64 + lane; v < nvec; v += 64 * snh) {
+                V ev = reinterpret_cast<const V *>(er)[v];
+                V dv = reinterpret_cast<const V *>(dr)[v];
+                T *dp = reinterpret_cast<T *>(&dv);
+                T *ep = reinterpret_cast<T *>(&ev);
+                if (ragged && v == nvec - 1) {
+#pragma unroll
+                    for (int k = 0; k < N; ++k) if (k >= gl - v * N) { dp[k] = T(0); ep[k] = T(0); }
+                }
+                reinterpret_cast<V *>(ec + sm * GCHUNK)[v] = ev;
+                reinterpret_cast<V *>(dc + sm * GCHUNK)[v] = dv;
+#pragma unroll
+                for (int k = 0; k < N; ++k) { psb += (double)dp[k]; psbb += (double)dp[k] * (double)dp[k]; }
+            }
+        }
+        __syncthreads();
+        // rows of this wave, software-pipelined: the next row's chunk is in flight (registers xb) while the
+        // pairs of the current row (xa) are evaluated -- without it every wave sits out a full HBM latency per row
+        auto load_row = [&](V (&x)[NV], int r) {
+            const int i = (int)(keys[seg[r]] >> 16);
+            const T *row = e + (int64_t)i * ld + g0;
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int v = lane + 64 * u;
+                if (v < nvec) x[u] = reinterpret_cast<const V *>(row)[v];
+            }
+        };
+        // pair evaluation.  FULLCHUNK (all NV vectors valid, no ragged tail) is branch-free so that the
+        // compiler batches the 2*NV ds_read_b128 ahead of the arithmetic instead of exposing one LDS
+        // latency per vector; two pairs of a row are evaluated together (independent chains -> ILP for
+        // the DPP reductions and the LDS accumulator updates).
+        auto pair_moments = [&](const V (&x)[NV], int m, bool full, T &tA, T &tAA, T &tAb) {
+            const T *em = ec + m * GCHUNK, *bm = dc + m * GCHUNK;
+            T sA[N], sAA[N], sAb[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) { sA[k] = T(0); sAA[k] = T(0); sAb[k] = T(0); }
+            if (full) {
+                constexpr int HB = 2;                            // LDS reads batched: 2*HB b128 in flight per batch
+#pragma unroll
+                for (int h = 0; h < NV / HB; ++h) {
+                    V ecv[HB], dcv[HB];
+#pragma unroll
+                    for (int u = 0; u < HB; ++u) {
+                        ecv[u] = reinterpret_cast<const V *>(em)[lane + 64 * (h * HB + u)];
+                        dcv[u] = reinterpret_cast<const V *>(bm)[lane + 64 * (h * HB + u)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < HB; ++u) {
+                        const T *xp = reinterpret_cast<const T *>(&x[h * HB + u]);
+                        const T *ep = reinterpret_cast<const T *>(&ecv[u]);
+                        const T *bp = reinterpret_cast<const T *>(&dcv[u]);
+#pragma unroll
+                        for (int k = 0; k < N; ++k) {
+                            const T a = xform<T, TR, RULES>(xp[k] - ep[k], psc);
+                            sA[k] += a;
+                            sAA[k] = fma(a, a, sAA[k]);
+                            sAb[k] = fma(a, bp[k], sAb[k]);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const int v = lane + 64 * u;
+                    if (v < nvec) {
+                        const V ecv = reinterpret_cast<const V *>(em)[v];
+                        const V dcv = reinterpret_cast<const V *>(bm)[v];
+                        const T *xp = reinterpret_cast<const T *>(&x[u]);
+                        const T *ep = reinterpret_cast<const T *>(&ecv);
+                        const T *bp = reinterpret_cast<const T *>(&dcv);
+                        const int valid = (ragged && v == nvec - 1) ? (gl - v * N) : N;
+#pragma unroll
+                        for (int k = 0; k < N; ++k) {
+                            T a = xform<T, TR, RULES>(xp[k] - ep[k], psc);
+                            if (k >= valid) a = T(0);
+                            sA[k] += a;
+                            sAA[k] = fma(a, a, sAA[k]);
+                            sAb[k] = fma(a, bp[k], sAb[k]);
+                        }
+                    }
+                }
+            }
+            tA = sA[0]; tAA = sAA[0]; tAb = sAb[0];
+#pragma unroll
+            for (int k = 1; k < N; ++k) { tA += sA[k]; tAA += sAA[k]; tAb += sAb[k]; }
+        };
+        const bool fullchunk = (gl == GCHUNK);
+        auto eval_row = [&](const V (&x)[NV], int r) {
+            const int p0 = seg[r], p1 = seg[r + 1];
+            for (int p = p0; p < p1; ++p) {
+                const int m0 = (int)((keys[p] >> 12) & 15);
+                T a0, b0, c0;
+                pair_moments(x, m0, fullchunk, a0, b0, c0);
+                a0 = wave_sum(a0); b0 = wave_sum(b0); c0 = wave_sum(c0);
+                if (lane == 0) { acc[3 * p] += a0; acc[3 * p + 1] += b0; acc[3 * p + 2] += c0; }
+            }
+        };
+        {
+            V xa[NV], xb[NV];
+            int r0 = wave;
+            if (r0 < U) load_row(xa, r0);
+            while (r0 < U) {
+                const int r1 = r0 + nwaves;
+                if (r1 < U) load_row(xb, r1);
+                eval_row(xa, r0);
+                if (r1 >= U) break;
+                r0 = r1 + nwaves;
+                if (r0 < U) load_row(xa, r0);
+                eval_row(xb, r1);
+            }
+        }
+    }
+    psb = wave_sum(psb); psbb = wave_sum(psbb);
+    if (lane == 0) { part[2 * wave] = psb; part[2 * wave + 1] = psbb; }
+    __syncthreads();
+    if (tid < gcount) {
+        double a = 0.0, b = 0.0;
+        for (int h = 0; h < snh; ++h) { const int w = tid + h * GC; if (w < nwaves) { a += part[2 * w]; b += part[2 * w + 1]; } }
+        s_sb[tid] = a; s_sbb[tid] = b;
+    }
+    __syncthreads();
+    for (int p = tid; p < npairs; p += blockDim.x) {
+        const unsigned long long key = keys[p];
+        const int m = (int)((key >> 12) & 15), n = (int)(key & 4095);
+        out[(int64_t)s_cells[m] * nrndm + n] = pearson_from_moments<T>((double)acc[3 * p], (double)acc[3 * p + 1], (double)acc[3 * p + 2],
+                                                                     s_sb[m], s_sbb[m], (double)G);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Full kernel: every (c, i) pair.  C^2 * G transform evaluations -> VALU/transcendental-bound, so
 // the job is to load each element once per tile and keep the inner loop register-resident:
 // a 256-thread block owns a TC x TI = 16 x 64 tile of pairs and walks genes GK = 32 at a time;
@@ -280,11 +515,31 @@ static int query_device()
     return VCY_OK;
 }
 
+static int g_group_pref = -1;    // -1 auto, 0 never, >0 group size (env VCY_CDC_GROUP, read once)
+
 template <typename T, int TR, int RULES>
 static int launch_partial(const void *e, const void *d, const int32_t *ixs, void *out, const int32_t *order, int64_t G,
                           int64_t ld, int64_t cell0, int64_t C_out, int64_t d_row0, int64_t nrndm, double psc, hipStream_t st)
 {
     constexpr int N = Vec<T>::N;
+    {   // grouped variant: cells adjacent in the schedule order share neighbour rows out of LDS
+        constexpr int GC = 8;
+        if (g_group_pref < 0) { const char *ev = getenv("VCY_CDC_GROUP"); g_group_pref = ev ? atoi(ev) : GC; }
+        const int64_t maxpairs = GC * nrndm;
+        int npad = 2;
+        while (npad < maxpairs) npad <<= 1;
+        const size_t lds_g = (size_t)2 * GC * GRP_MAX_NV * 64 * N * sizeof(T) + (size_t)npad * 8 + sizeof(T) * 3 * ((maxpairs + 1) & ~1) +
+                             sizeof(int) * ((maxpairs + 3) & ~1) + (64 + 2 * GC) * sizeof(double) + (GC + 17) * sizeof(int) + 16;
+        if (g_group_pref == GC && nrndm <= 4095 && nrndm >= 8 && C_out >= 4 * GC && lds_g <= (size_t)(g_lds_budget > 155648 ? 155648 : g_lds_budget)) {
+            auto kern = k_cdc_partial_grouped<T, TR, RULES, GC>;
+            VCY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
+            const unsigned groups = (unsigned)((C_out + GC - 1) / GC);
+            hipLaunchKernelGGL(kern, dim3(groups), dim3(1024), lds_g, st, (const T *)e, (const T *)d, ixs, (T *)out, order, (int)G, ld, cell0, d_row0,
+                               (int)C_out, (int)nrndm, npad, (T)psc);
+            VCY_LAUNCH_CHECK();
+            return VCY_OK;
+        }
+    }
     const int quantum = 64 * N;  // one wave-instruction worth of elements
     const size_t fixed = sizeof(T) * 3 * ((nrndm + 1) & ~1) + 32 * sizeof(double);
     // budget: stay under 150 KiB so one workgroup (16 waves) owns a CU; fewest chunks that fit
