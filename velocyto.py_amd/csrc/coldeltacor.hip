@@ -62,7 +62,7 @@ template <typename T, int TR, int RULES>
 __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, const T *__restrict__ d,
                                                        const int32_t *__restrict__ ixs, T *__restrict__ out,
                                                        const int32_t *__restrict__ order, int G, int64_t ld,
-                                                       int64_t cell0, int64_t d_row0, int nrndm, int gchunk, T psc)
+                                                       int64_t cell0, int64_t d_row0, int C_out, int nrndm, int gchunk, T psc)
 {
     using V = typename Vec<T>::type;
     constexpr int N = Vec<T>::N;
@@ -74,7 +74,10 @@ __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, c
     double *red = reinterpret_cast<double *>(acc + 3 * ((nrndm + 1) & ~1));  // [32] block-reduce scratch (8-byte aligned)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    const int cl = order ? order[blockIdx.x] : (int)blockIdx.x;  // local output row
+    const int per_x = (C_out + 7) / 8;                            // XCD-aware schedule (see k_cdc_partial_grouped)
+    const int pos = ((int)blockIdx.x & 7) * per_x + ((int)blockIdx.x >> 3);
+    if (pos >= C_out) return;
+    const int cl = order ? order[pos] : pos;                      // local output row
     const int64_t c = cell0 + cl;
     const T *erow_c = e + c * ld;
     const T *drow_c = d + (c - d_row0) * ld;
@@ -211,7 +214,12 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
     int &s_U = s_wavetot[16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    const int g0cell = blockIdx.x * GC;
+    // XCD-aware schedule: workgroup b runs on XCD b % 8 (observed; speed only) -> XCD x owns the contiguous
+    // range of groups [x*per, (x+1)*per), so groups that share neighbour rows share one L2
+    const int ngroups = (C_out + GC - 1) / GC, per = (ngroups + 7) / 8;
+    const int gpos = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (gpos >= ngroups) return;
+    const int g0cell = gpos * GC;
     const int gcount = min(GC, C_out - g0cell);
     const int npairs = gcount * nrndm;
     if (tid < GC) s_cells[tid] = tid < gcount ? (order ? order[g0cell + tid] : g0cell + tid) : 0;
@@ -533,7 +541,7 @@ static int launch_partial(const void *e, const void *d, const int32_t *ixs, void
         if (g_group_pref == GC && nrndm <= 4095 && nrndm >= 8 && C_out >= 4 * GC && lds_g <= (size_t)(g_lds_budget > 155648 ? 155648 : g_lds_budget)) {
             auto kern = k_cdc_partial_grouped<T, TR, RULES, GC>;
             VCY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
-            const unsigned groups = (unsigned)((C_out + GC - 1) / GC);
+            const unsigned groups = (unsigned)(((C_out + GC - 1) / GC + 7) / 8 * 8);
             hipLaunchKernelGGL(kern, dim3(groups), dim3(1024), lds_g, st, (const T *)e, (const T *)d, ixs, (T *)out, order, (int)G, ld, cell0, d_row0,
                                (int)C_out, (int)nrndm, npad, (T)psc);
             VCY_LAUNCH_CHECK();
@@ -554,8 +562,8 @@ static int launch_partial(const void *e, const void *d, const int32_t *ixs, void
     auto kern = k_cdc_partial<T, TR, RULES>;
     VCY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int threads = (nrndm >= 16) ? 1024 : (nrndm >= 8 ? 512 : 256);
-    hipLaunchKernelGGL(kern, dim3((unsigned)C_out), dim3(threads), lds, st, (const T *)e, (const T *)d, ixs, (T *)out, order,
-                       (int)G, ld, cell0, d_row0, (int)nrndm, (int)gchunk, (T)psc);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((C_out + 7) / 8 * 8)), dim3(threads), lds, st, (const T *)e, (const T *)d, ixs, (T *)out, order,
+                       (int)G, ld, cell0, d_row0, (int)C_out, (int)nrndm, (int)gchunk, (T)psc);
     VCY_LAUNCH_CHECK();
     return VCY_OK;
 }

@@ -21,10 +21,15 @@ __global__ __launch_bounds__(256) void k_knn_pool(const T *__restrict__ data, T 
 {
     using V = typename Vec<T>::type;
     constexpr int N = Vec<T>::N;
+    // slab-major block order; inside a slab the schedule is XCD-aware: workgroup b lands on XCD b % 8
+    // (observed dispatch rule, used for speed only), so XCD x is given the contiguous schedule range
+    // [x*per, (x+1)*per): neighbouring cells - which share neighbours - hit the SAME per-XCD L2.
+    const int per = (C_out + 7) / 8, nblk = per * 8;
     const int64_t b = blockIdx.x;
-    const int s = (int)(b / C_out);                          // slab-major block order
-    const int cl = order ? order[b % C_out] : (int)(b % C_out);   // schedule position -> cell (locality-sorted orders
-                                                                  // make co-resident blocks share neighbours in L2)
+    const int s = (int)(b / nblk), bi = (int)(b % nblk);
+    const int pos = (bi & 7) * per + (bi >> 3);
+    if (pos >= C_out) return;
+    const int cl = order ? order[pos] : pos;                 // schedule position -> cell
     const int g0 = s * slab, g1 = min(G, g0 + slab);
     const int64_t p0 = indptr[cl], p1 = indptr[cl + 1];
     const int nvec = (g1 - g0) / N;                        // slab and ld are multiples of N; tail handled below
@@ -92,7 +97,7 @@ extern "C" int vcy_knn_pool(const void *data, void *out, const int64_t *indptr, 
     if (slab > G) slab = (G + N - 1) / N * N;
     const int64_t nslab = (G + slab - 1) / slab;
     const int threads = slab / N >= 256 ? 256 : (slab / N >= 128 ? 128 : 64);
-    const int64_t blocks = nslab * C_out;
+    const int64_t blocks = nslab * ((C_out + 7) / 8 * 8);
     VCY_REQUIRE(blocks < (1LL << 31), "knn_pool: grid too large");
     hipStream_t st = as_stream(stream);
     if (dtype == VCY_F32)
