@@ -95,6 +95,7 @@ def synth(C, G, P, dev, seed=20180811):
     # pcs: top-P principal components of log2(S_sz + 1) (perform_PCA is upstream of the path; randomised SVD here)
     L = torch.log2(S[:, :G] + 1.0)
     L -= L.mean(0, keepdim=True)
+    torch.manual_seed(seed)             # svd_lowrank draws its sketch from the global RNG: keep every rank's pcs identical
     Uu, Ss, _ = torch.svd_lowrank(L, q=P, niter=2)
     pcs = (Uu * Ss).double().contiguous()
     del L
@@ -304,7 +305,7 @@ def main():
                                  "L2-miss traffic of the same launch (profiles/r01b_*). The kernel is now VALU/transcendental-"
                                  "bound: 9.8 VALU instr + 1 v_sqrt_f32 per pair-gene, 46 % VALU issue utilisation."},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:     # reported on rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(pipe, a)
         print(json.dumps(res))
     if world > 1:
