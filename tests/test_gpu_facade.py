@@ -212,7 +212,6 @@ def test_facade_randomized_control_is_statistical(vcy, golden):
     vlm.estimate_transition_prob(hidim="Sx_sz", embed="ts", transform="sqrt", n_neighbors=40, knn_random=True, sampled_fraction=0.5)
     dr = vlm.delta_S_rndm
     np.testing.assert_allclose(np.sort(np.abs(dr), 1), np.sort(np.abs(vlm.delta_S), 1), rtol=1e-6)   # per-gene permutation up to sign
-    assert 0.3 < np.mean(np.sign(dr[dr != 0]) != np.sign(vlm.delta_S[dr != 0])) < 0.7 or True
     nz = vlm.embedding_knn.toarray() > 0
     cr = vlm.corrcoef_random
     assert abs(np.mean(cr[nz])) < abs(np.mean(vlm.corrcoef[nz])) + 0.05        # negative control carries less signal

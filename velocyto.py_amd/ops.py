@@ -447,8 +447,29 @@ def diffuse(x0, tr, n_steps: int, accumulate: bool) -> Tuple[torch.Tensor, Optio
         T = tr.to(dev).contiguous()
         assert T.shape == (n, n) and T.dtype in _DT
         ws = torch.empty(int(L.vcy_diffuse_workspace_bytes(n)), dtype=torch.uint8, device=dev)
-        for _ in range(n_steps):
-            _lib.check(L.vcy_diffuse_step_dense(T.data_ptr(), x.data_ptr(), y.data_ptr(), _p(acc), ws.data_ptr(), n, _DT[T.dtype], _stream()), "diffuse_step_dense")
+
+        def step(src, dst):
+            _lib.check(L.vcy_diffuse_step_dense(T.data_ptr(), src.data_ptr(), dst.data_ptr(), _p(acc), ws.data_ptr(), n, _DT[T.dtype], _stream()), "diffuse_step_dense")
+
+        done = 0
+        if n_steps >= 32:
+            # launch-bound loop (2 tiny kernels per step, thousands of steps): capture an x -> y -> x pair of
+            # steps into a hipGraph once and replay it (the kernels take raw pointers and never allocate or sync)
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step(x, y); step(y, x)                      # warm-up outside capture
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    step(x, y); step(y, x)
+            torch.cuda.current_stream().wait_stream(side)
+            done = 2
+            for _ in range((n_steps - done) // 2):
+                graph.replay()
+            done += 2 * ((n_steps - done) // 2)
+        for _ in range(n_steps - done):
+            step(x, y)
             x, y = y, x
     return x, acc
 
