@@ -29,6 +29,7 @@ namespace vcy {
 constexpr int KNN_QB = 8;
 constexpr int KNN_MAXSEL = 4096;
 constexpr int KNN_MARGIN = 8;
+constexpr int KNN_NC = 2;          // candidates per thread per pass of the distance loop
 
 __device__ __forceinline__ uint32_t f32_key(float f)
 {
@@ -75,27 +76,40 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
     float m0[KNN_QB], m1[KNN_QB];       // two smallest distances this thread has seen, per query
 #pragma unroll
     for (int qq = 0; qq < KNN_QB; ++qq) { m0[qq] = INFINITY; m1[qq] = INFINITY; }
-    for (int j = tid; j < C; j += 256) {
-        float acc[KNN_QB];
+    // KNN_NC candidates (j, j + 256, ...) per thread and iteration: the LDS reads of the 8 query coordinates are
+    // shared by all of them, and KNN_NC independent global loads are in flight per feature
+    for (int j = tid; j < C; j += 256 * KNN_NC) {
+        float acc[KNN_NC][KNN_QB];
 #pragma unroll
-        for (int qq = 0; qq < KNN_QB; ++qq) acc[qq] = 0.f;
+        for (int c = 0; c < KNN_NC; ++c)
+#pragma unroll
+            for (int qq = 0; qq < KNN_QB; ++qq) acc[c][qq] = 0.f;
         for (int p = 0; p < P; ++p) {
-            const float xv = xt[(int64_t)p * ldx + j];
+            float xv[KNN_NC];
+#pragma unroll
+            for (int c = 0; c < KNN_NC; ++c) xv[c] = (j + 256 * c < C) ? xt[(int64_t)p * ldx + j + 256 * c] : 0.f;
 #pragma unroll
             for (int qq = 0; qq < KNN_QB; ++qq) {
-                const float df = xq[qq * P + p] - xv;
-                acc[qq] = fmaf(df, df, acc[qq]);
+                const float qv = xq[qq * P + p];
+#pragma unroll
+                for (int c = 0; c < KNN_NC; ++c) { const float df = qv - xv[c]; acc[c][qq] = fmaf(df, df, acc[c][qq]); }
             }
         }
 #pragma unroll
-        for (int qq = 0; qq < KNN_QB; ++qq) {
-            if (qq < nq) {
-                float v = acc[qq];
-                if (!include_self && (int64_t)j == q0 + qb0 + qq) v = INFINITY;   // query excluded (kneighbors_graph(X=None))
-                wrow[(int64_t)qq * C + j] = v;
-                if (v < m1[qq]) {
-                    if (v < m0[qq]) { m1[qq] = m0[qq]; m0[qq] = v; }
-                    else m1[qq] = v;
+        for (int c = 0; c < KNN_NC; ++c) {
+            const int jc = j + 256 * c;
+            if (jc < C) {
+#pragma unroll
+                for (int qq = 0; qq < KNN_QB; ++qq) {
+                    if (qq < nq) {
+                        float v = acc[c][qq];
+                        if (!include_self && (int64_t)jc == q0 + qb0 + qq) v = INFINITY;   // query excluded (kneighbors_graph(X=None))
+                        wrow[(int64_t)qq * C + jc] = v;
+                        if (v < m1[qq]) {
+                            if (v < m0[qq]) { m1[qq] = m0[qq]; m0[qq] = v; }
+                            else m1[qq] = v;
+                        }
+                    }
                 }
             }
         }
