@@ -34,19 +34,39 @@ template <typename T> __device__ __forceinline__ T dmat_of(T D, int transform, T
     return D > T(0) ? f : (D < T(0) ? -f : T(0) * f);
 }
 
+// thread = one 16-byte gene vector, fixed for the thread's lifetime (gamma, q, eps live in registers);
+// blockIdx.y = block of cells walked with 4 rows of loads in flight.  Lanes map to adjacent gene
+// vectors, so every load/store instruction covers one contiguous 1 KiB row segment.
+constexpr int VEL_CB = 64;
+
 template <typename T> __global__ __launch_bounds__(256) void k_velocity_chain(VelArgs a)
 {
     using V = typename Vec<T>::type;
     constexpr int N = Vec<T>::N;
     const int nvec = (int)(a.ld / N);
-    const int64_t total = a.C * (int64_t)nvec;
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nvec) return;
     const T *Sx = (const T *)a.Sx, *Ux = (const T *)a.Ux;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t c = t / nvec;
-        const int v = (int)(t - c * nvec);
+    T gm[N], qq[N];
+    double eps[N];
+    bool live[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int g = v * N + k;
+        live[k] = g < a.G;
+        gm[k] = live[k] ? (T)a.gamma[g] : T(0);
+        qq[k] = (live[k] && a.q) ? (T)a.q[g] : T(0);
+        eps[k] = (live[k] && a.eps_thr) ? a.eps_thr[g] : -1.0;
+    }
+    float egt32[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k)   // the reference forms exp(-gammas*dt) and (1 - egt) in FLOAT32 (gammas is a float32 array
+        egt32[k] = (a.assumption == 1 && live[k]) ? expf(-(a.gamma[v * N + k] * (float)a.dt_shift)) : 0.f;   // and numpy keeps float32)
+    const int64_t per = (a.C + VEL_CB - 1) / VEL_CB;
+    const int64_t c0 = blockIdx.y * per, c1 = c0 + per < a.C ? c0 + per : a.C;
+
+    auto one = [&](int64_t c, const V &sv, const V &uv) {
         const int64_t o = c * a.ld + (int64_t)v * N;
-        const V sv = *reinterpret_cast<const V *>(Sx + o);
-        const V uv = *reinterpret_cast<const V *>(Ux + o);
         const T *sp = reinterpret_cast<const T *>(&sv);
         const T *up = reinterpret_cast<const T *>(&uv);
         V o_up, o_vel, o_ds, o_st, o_dm;
@@ -54,24 +74,18 @@ template <typename T> __global__ __launch_bounds__(256) void k_velocity_chain(Ve
           *pt = reinterpret_cast<T *>(&o_st), *pm = reinterpret_cast<T *>(&o_dm);
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            const int g = v * N + k;
             T upred = T(0), vel = T(0), ds = T(0), st = T(0), dm = T(0);
-            if (g < a.G) {
-                const T gm = (T)a.gamma[g];
-                const T qq = a.q ? (T)a.q[g] : T(0);
+            if (live[k]) {
                 const T s = sp[k], u = up[k];
-                upred = gm * s + qq;                               // analysis.py:1346
+                upred = gm[k] * s + qq[k];                         // analysis.py:1346
                 vel = u - upred;                                   // :1369
-                if (a.eps_thr && fabs((double)vel) < a.eps_thr[g]) vel = T(0);   // :1377-1379
+                if (eps[k] >= 0.0 && fabs((double)vel) < eps[k]) vel = T(0);   // :1377-1379
                 if (a.assumption == 0) ds = (T)a.dt_shift * vel;   // :1399
                 else {                                             // :1403-1406
-                    T uo = u - qq;
+                    T uo = u - qq[k];
                     uo = uo < T(0) ? T(0) : uo;
-                    // the reference forms exp(-gammas*dt) and (1 - egt) in FLOAT32 (gammas is a float32
-                    // array and numpy keeps float32 for array*python-scalar) before mixing with fp64 data
-                    const float egt32 = expf(-(a.gamma[g] * (float)a.dt_shift));
-                    const T egt = (T)egt32, omegt = (T)(1.0f - egt32);
-                    ds = s * egt + omegt * uo / gm - s;
+                    const T egt = (T)egt32[k], omegt = (T)(1.0f - egt32[k]);
+                    ds = s * egt + omegt * uo / gm[k] - s;
                 }
                 st = s + (T)a.dt_extrap * ds;                      // :1429
                 if (a.clip) st = st < T(0) ? T(0) : st;            // :1431
@@ -85,7 +99,19 @@ template <typename T> __global__ __launch_bounds__(256) void k_velocity_chain(Ve
         if (a.delta_S) *reinterpret_cast<V *>((T *)a.delta_S + o) = o_ds;
         if (a.Sx_t) *reinterpret_cast<V *>((T *)a.Sx_t + o) = o_st;
         if (a.dmat) *reinterpret_cast<V *>((T *)a.dmat + o) = o_dm;
+    };
+    int64_t c = c0;
+    for (; c + 3 < c1; c += 4) {
+        V sv[4], uv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            sv[u] = reinterpret_cast<const V *>(Sx + (c + u) * a.ld)[v];
+            uv[u] = reinterpret_cast<const V *>(Ux + (c + u) * a.ld)[v];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(c + u, sv[u], uv[u]);
     }
+    for (; c < c1; ++c) one(c, reinterpret_cast<const V *>(Sx + c * a.ld)[v], reinterpret_cast<const V *>(Ux + c * a.ld)[v]);
 }
 }  // namespace vcy
 
@@ -105,11 +131,10 @@ extern "C" int vcy_velocity_chain(const void *Sx_sz, const void *Ux_sz, const fl
     VelArgs a{Sx_sz, Ux_sz, gamma, q, eps_thr, Upred, velocity, delta_S, Sx_sz_t, dmat, C, ld, (int)G,
               dt_shift, dt_extrap, used_dt, psc, assumption, clip, transform};
     const int N = dtype == VCY_F32 ? 4 : 2;
-    const int64_t total = C * (ld / N);
-    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    const dim3 grid((unsigned)((ld / N + 255) / 256), VEL_CB);
     hipStream_t st = as_stream(stream);
-    if (dtype == VCY_F32) hipLaunchKernelGGL(k_velocity_chain<float>, dim3(blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_velocity_chain<double>, dim3(blocks), dim3(256), 0, st, a);
+    if (dtype == VCY_F32) hipLaunchKernelGGL(k_velocity_chain<float>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_velocity_chain<double>, grid, dim3(256), 0, st, a);
     VCY_LAUNCH_CHECK();
     return VCY_OK;
 }
