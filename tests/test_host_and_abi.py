@@ -72,3 +72,49 @@ def test_balance_knn_host_padding(lib, golden):
     assert np.array_equal(i, g["nd_dsi_new"]) and np.array_equal(l, g["nd_l"]) and np.array_equal(d, g["nd_dist_new"])
     with pytest.raises(AssertionError):
         ops.balance_knn_host(dsi[:, :5], None, lsi, None, maxl=14, k=9)
+
+
+def test_missing_library_fails_loudly(lib, monkeypatch, tmp_path):
+    """No silent fallback: with the .so absent every entry point raises."""
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        lib.lib()
+
+
+def test_gpu_required_message():
+    import torch
+    from velocyto_amd import ops
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.require_gpu()
+    with pytest.raises(RuntimeError):
+        ops.CellMatrix.from_genes_major(np.zeros((3, 4)))
+
+
+def test_balance_knn_properties_hypothesis(lib):
+    """Invariants of the greedy balancing (neighbors.py:11-72) on random sight graphs: in-degree cap, no
+    self neighbours besides column 0 / padding, neighbours taken in sight order, l consistent with dsi_new."""
+    from hypothesis import given, settings, strategies as st
+    from velocyto_amd import ops
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(5, 40), st.integers(1, 6), st.integers(1, 8), st.integers(0, 2 ** 31 - 1))
+    def check(n, k, maxl, seed):
+        rng = np.random.default_rng(seed)
+        k = min(k, n - 2)
+        K = int(rng.integers(k + 1, n + 1))                          # sight (incl. self) between k+1 and n
+        dsi = np.stack([np.concatenate([[i], rng.permutation(np.delete(np.arange(n), i))[:K - 1]]) for i in range(n)])
+        dist = np.sort(rng.random((n, K)), 1)
+        dist[:, 0] = 0
+        lsi = np.argsort(np.bincount(dsi.ravel(), minlength=n), kind="mergesort")[::-1]
+        d, i, l = ops.balance_knn_host(dsi, dist, lsi, None, maxl, k)
+        assert i.shape == (n, k + 1) and np.all(i[:, 0] == np.arange(n))
+        real = i[:, 1:] != np.arange(n)[:, None]
+        assert l.max(initial=0) <= maxl and l.sum() == real.sum()
+        assert np.array_equal(np.bincount(i[:, 1:][real], minlength=n), l)
+        for r in range(n):                                           # neighbours keep their sight order
+            pos = [int(np.where(dsi[r] == m)[0][0]) for m in i[r, 1:][real[r]]]
+            assert pos == sorted(pos)
+    check()
