@@ -160,10 +160,8 @@ class Pipeline:
         indices = torch.cat([torch.arange(c0, c1, device=self.dev, dtype=torch.int32)[:, None], idx], 1).contiguous()
         indptr = torch.arange(0, (nloc + 1) * (k + 1), k + 1, device=self.dev, dtype=torch.int64)
         wrow = wrow.contiguous()
-        ops.knn_pool(self.S, indptr, indices, wrow, cell0=c0, C_out=nloc, out=self.Sx_loc, validate=False, order=self.pool_order,
-                     slab_genes=self.a.slab)
-        ops.knn_pool(self.U, indptr, indices, wrow, cell0=c0, C_out=nloc, out=self.Ux_loc, validate=False, order=self.pool_order,
-                     slab_genes=self.a.slab)
+        ops.knn_pool2(self.S, self.U, indptr, indices, wrow, cell0=c0, C_out=nloc, out=self.Sx_loc, out2=self.Ux_loc, validate=False,
+                      order=self.pool_order, slab_genes=self.a.slab)
         ev[1].record()
         # ---- B: fit_slope (estimation.py:267-279); sharded: all-reduce of the per-gene moments
         mom = ops.fit_slope_moments(self.Ux_loc, self.Sx_loc)

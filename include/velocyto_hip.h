@@ -109,6 +109,12 @@ int vcy_knn_pool(const void *data, void *out, const int64_t *indptr, const int32
                  const int32_t *order, int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int maximum,
                  int64_t slab_genes, int dtype, vcy_stream stream);
 
+/* Same, pooling TWO matrices that share the weights in one launch (spliced and unspliced,
+ * analysis.py:1012-1013): indices/weights are read once and twice as many gathers are in flight.  */
+int vcy_knn_pool2(const void *data, void *out, const void *data2, void *out2, const int64_t *indptr,
+                  const int32_t *indices, const void *w, const int32_t *order, int64_t C, int64_t G, int64_t ld,
+                  int64_t cell0, int64_t C_out, int maximum, int64_t slab_genes, int dtype, vcy_stream stream);
+
 /* Exact Euclidean kNN in a low-dimensional space (what sklearn NearestNeighbors provides to
  * neighbors.knn_distance_matrix :363-376, BalancedKNN.fit/kneighbors :239-243,282 and
  * analysis.py:1547-1549).  xt: (P, ldx) TRANSPOSED coordinates (feature-major) of all C

@@ -43,7 +43,7 @@ _LAZY_DENSE = frozenset(["corrcoef", "corrcoef_random", "transition_prob", "tran
 class VelocytoLoom:
     """Device-resident counterpart of velocyto.VelocytoLoom (analysis.py:26-94).
 
-    ``VelocytoLoom(loom_filepath)`` reads a .loom file (needs loompy or h5py);
+    ``VelocytoLoom(loom_filepath)`` reads a .loom file (HDF5 via loom_io: h5py if present, else ctypes-bound libhdf5);
     ``VelocytoLoom.from_arrays(S, U, A=None, ca=None, ra=None)`` starts from in-memory layers."""
 
     def __init__(self, loom_filepath: str = None, dtype=None) -> None:
@@ -269,8 +269,7 @@ class VelocytoLoom:
         w = sparse.csr_matrix(w)
         assert np.allclose(np.asarray(w.sum(1)).ravel(), 1), "weight matrix need to sum to one over the columns"   # neighbors.py:422
         indptr, indices, vals = w.indptr.astype(np.int64), w.indices.astype(np.int32), np.ascontiguousarray(w.data, dtype=np.float64)
-        Sx = ops.knn_pool(self.dev(s_name), indptr, indices, vals, maximum=maximum)
-        Ux = ops.knn_pool(self.dev(u_name), indptr, indices, vals, maximum=maximum)
+        Sx, Ux = ops.knn_pool2(self.dev(s_name), self.dev(u_name), indptr, indices, vals, maximum=maximum)
         self._set_dev("Sx", Sx)
         self._set_dev("Ux", Ux)
         self._set_dev("Sx_sz", Sx.clone())                        # :1022-1023 separate copies for backwards compatibility

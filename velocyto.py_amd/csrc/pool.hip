@@ -13,8 +13,9 @@
 
 namespace vcy {
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_knn_pool(const T *__restrict__ data, T *__restrict__ out, const int64_t *__restrict__ indptr,
+template <typename T, bool DUAL>
+__global__ __launch_bounds__(256) void k_knn_pool(const T *__restrict__ data, T *__restrict__ out, const T *__restrict__ data2,
+                                                   T *__restrict__ out2, const int64_t *__restrict__ indptr,
                                                    const int32_t *__restrict__ indices, const T *__restrict__ w,
                                                    const int32_t *__restrict__ order, int G, int64_t ld,
                                                    int64_t cell0, int C_out, int slab, int maximum)
@@ -34,64 +35,87 @@ __global__ __launch_bounds__(256) void k_knn_pool(const T *__restrict__ data, T 
     const int64_t p0 = indptr[cl], p1 = indptr[cl + 1];
     const int nvec = (g1 - g0) / N;                        // slab and ld are multiples of N; tail handled below
     for (int v = threadIdx.x; v < nvec; v += blockDim.x) {
-        T acc[N];
+        T acc[N], acc2[N];
 #pragma unroll
-        for (int k = 0; k < N; ++k) acc[k] = T(0);
+        for (int k = 0; k < N; ++k) { acc[k] = T(0); acc2[k] = T(0); }
         int64_t p = p0;
-        for (; p + 3 < p1; p += 4) {                       // 4 gathers in flight
-            V x[4]; T ww[4];
+        for (; p + 3 < p1; p += 4) {                       // 4 (DUAL: 8) gathers in flight
+            V x[4], y[4]; T ww[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                x[u] = reinterpret_cast<const V *>(data + (int64_t)indices[p + u] * ld + g0)[v];
+                const int64_t ro = (int64_t)indices[p + u] * ld + g0;
+                x[u] = reinterpret_cast<const V *>(data + ro)[v];
+                if (DUAL) y[u] = reinterpret_cast<const V *>(data2 + ro)[v];
                 ww[u] = w[p + u];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const T *xp = reinterpret_cast<const T *>(&x[u]);
+                const T *yp = reinterpret_cast<const T *>(&y[u]);
 #pragma unroll
-                for (int k = 0; k < N; ++k) acc[k] = fma(ww[u], xp[k], acc[k]);
+                for (int k = 0; k < N; ++k) { acc[k] = fma(ww[u], xp[k], acc[k]); if (DUAL) acc2[k] = fma(ww[u], yp[k], acc2[k]); }
             }
         }
         for (; p < p1; ++p) {
-            const V xv = reinterpret_cast<const V *>(data + (int64_t)indices[p] * ld + g0)[v];
+            const int64_t ro = (int64_t)indices[p] * ld + g0;
+            const V xv = reinterpret_cast<const V *>(data + ro)[v];
+            V yv;
+            if (DUAL) yv = reinterpret_cast<const V *>(data2 + ro)[v];
             const T wv = w[p];
             const T *xp = reinterpret_cast<const T *>(&xv);
+            const T *yp = reinterpret_cast<const T *>(&yv);
 #pragma unroll
-            for (int k = 0; k < N; ++k) acc[k] = fma(wv, xp[k], acc[k]);
+            for (int k = 0; k < N; ++k) { acc[k] = fma(wv, xp[k], acc[k]); if (DUAL) acc2[k] = fma(wv, yp[k], acc2[k]); }
         }
         if (maximum) {
-            const V sv = reinterpret_cast<const V *>(data + (cell0 + cl) * ld + g0)[v];
+            const int64_t ro = (cell0 + cl) * ld + g0;
+            const V sv = reinterpret_cast<const V *>(data + ro)[v];
             const T *sp = reinterpret_cast<const T *>(&sv);
 #pragma unroll
             for (int k = 0; k < N; ++k) acc[k] = acc[k] > sp[k] ? acc[k] : sp[k];
-        }
-        V o;
-        T *op = reinterpret_cast<T *>(&o);
+            if (DUAL) {
+                const V tv = reinterpret_cast<const V *>(data2 + ro)[v];
+                const T *tp = reinterpret_cast<const T *>(&tv);
 #pragma unroll
-        for (int k = 0; k < N; ++k) op[k] = acc[k];
+                for (int k = 0; k < N; ++k) acc2[k] = acc2[k] > tp[k] ? acc2[k] : tp[k];
+            }
+        }
+        V o, o2;
+        T *op = reinterpret_cast<T *>(&o), *op2 = reinterpret_cast<T *>(&o2);
+#pragma unroll
+        for (int k = 0; k < N; ++k) { op[k] = acc[k]; op2[k] = acc2[k]; }
         reinterpret_cast<V *>(out + (int64_t)cl * ld + g0)[v] = o;
+        if (DUAL) reinterpret_cast<V *>(out2 + (int64_t)cl * ld + g0)[v] = o2;
     }
     for (int g = g0 + nvec * N + threadIdx.x; g < g1; g += blockDim.x) {   // < N tail genes of the last slab
-        T a = T(0);
-        for (int64_t p = p0; p < p1; ++p) a = fma(w[p], data[(int64_t)indices[p] * ld + g], a);
-        if (maximum) { const T sv = data[(cell0 + cl) * ld + g]; a = a > sv ? a : sv; }
+        T a = T(0), a2 = T(0);
+        for (int64_t p = p0; p < p1; ++p) {
+            a = fma(w[p], data[(int64_t)indices[p] * ld + g], a);
+            if (DUAL) a2 = fma(w[p], data2[(int64_t)indices[p] * ld + g], a2);
+        }
+        if (maximum) {
+            const T sv = data[(cell0 + cl) * ld + g]; a = a > sv ? a : sv;
+            if (DUAL) { const T tv = data2[(cell0 + cl) * ld + g]; a2 = a2 > tv ? a2 : tv; }
+        }
         out[(int64_t)cl * ld + g] = a;
+        if (DUAL) out2[(int64_t)cl * ld + g] = a2;
     }
 }
 }  // namespace vcy
 
 using namespace vcy;
 
-extern "C" int vcy_knn_pool(const void *data, void *out, const int64_t *indptr, const int32_t *indices, const void *w,
-                            const int32_t *order, int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int maximum,
-                            int64_t slab_genes, int dtype, vcy_stream stream)
+static int knn_pool_impl(const void *data, void *out, const void *data2, void *out2, const int64_t *indptr, const int32_t *indices,
+                         const void *w, const int32_t *order, int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int maximum,
+                         int64_t slab_genes, int dtype, vcy_stream stream)
 {
     VCY_REQUIRE(data && out && indptr && indices && w, "knn_pool: null pointer");
+    VCY_REQUIRE((data2 == nullptr) == (out2 == nullptr), "knn_pool: data2/out2 go together");
     VCY_REQUIRE(C > 0 && G > 0 && ld >= G && C_out > 0 && cell0 >= 0 && cell0 + C_out <= C, "knn_pool: bad shape");
     VCY_REQUIRE(dtype == VCY_F32 || dtype == VCY_F64, "knn_pool: bad dtype");
     const int N = dtype == VCY_F32 ? 4 : 2;
     VCY_REQUIRE(ld % N == 0, "knn_pool: ld must keep rows 16-byte aligned");
-    VCY_REQUIRE(data != out, "knn_pool: in-place pooling is not supported");
+    VCY_REQUIRE(data != out && (data2 == nullptr || data2 != out2), "knn_pool: in-place pooling is not supported");
     int64_t slab = slab_genes > 0 ? slab_genes : 512;
     slab = (slab + N - 1) / N * N;
     if (slab > G) slab = (G + N - 1) / N * N;
@@ -100,12 +124,27 @@ extern "C" int vcy_knn_pool(const void *data, void *out, const int64_t *indptr, 
     const int64_t blocks = nslab * ((C_out + 7) / 8 * 8);
     VCY_REQUIRE(blocks < (1LL << 31), "knn_pool: grid too large");
     hipStream_t st = as_stream(stream);
-    if (dtype == VCY_F32)
-        hipLaunchKernelGGL(k_knn_pool<float>, dim3((unsigned)blocks), dim3(threads), 0, st, (const float *)data, (float *)out, indptr,
-                           indices, (const float *)w, order, (int)G, ld, cell0, (int)C_out, (int)slab, maximum);
-    else
-        hipLaunchKernelGGL(k_knn_pool<double>, dim3((unsigned)blocks), dim3(threads), 0, st, (const double *)data, (double *)out, indptr,
-                           indices, (const double *)w, order, (int)G, ld, cell0, (int)C_out, (int)slab, maximum);
+#define VCY_POOL(T, DUAL)                                                                                                          \
+    hipLaunchKernelGGL((k_knn_pool<T, DUAL>), dim3((unsigned)blocks), dim3(threads), 0, st, (const T *)data, (T *)out, (const T *)data2, \
+                       (T *)out2, indptr, indices, (const T *)w, order, (int)G, ld, cell0, (int)C_out, (int)slab, maximum)
+    if (dtype == VCY_F32) { if (data2) VCY_POOL(float, true); else VCY_POOL(float, false); }
+    else { if (data2) VCY_POOL(double, true); else VCY_POOL(double, false); }
+#undef VCY_POOL
     VCY_LAUNCH_CHECK();
     return VCY_OK;
+}
+
+extern "C" int vcy_knn_pool(const void *data, void *out, const int64_t *indptr, const int32_t *indices, const void *w,
+                            const int32_t *order, int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int maximum,
+                            int64_t slab_genes, int dtype, vcy_stream stream)
+{
+    return knn_pool_impl(data, out, nullptr, nullptr, indptr, indices, w, order, C, G, ld, cell0, C_out, maximum, slab_genes, dtype, stream);
+}
+
+extern "C" int vcy_knn_pool2(const void *data, void *out, const void *data2, void *out2, const int64_t *indptr, const int32_t *indices,
+                             const void *w, const int32_t *order, int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out,
+                             int maximum, int64_t slab_genes, int dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(data2 && out2, "knn_pool2: null pointer");
+    return knn_pool_impl(data, out, data2, out2, indptr, indices, w, order, C, G, ld, cell0, C_out, maximum, slab_genes, dtype, stream);
 }

@@ -220,6 +220,30 @@ def knn_pool(data: CellMatrix, indptr, indices, weights, maximum: bool = False, 
     return out
 
 
+def knn_pool2(data: CellMatrix, data2: CellMatrix, indptr, indices, weights, maximum: bool = False, cell0: int = 0,
+              C_out: Optional[int] = None, slab_genes: int = 0, out: Optional[CellMatrix] = None, out2: Optional[CellMatrix] = None,
+              validate: bool = True, order: Optional[torch.Tensor] = None) -> Tuple[CellMatrix, CellMatrix]:
+    """Pool two matrices that share the weights (S and U of knn_imputation) in one launch."""
+    dev = data.t.device
+    assert data.t.shape == data2.t.shape and data.dtype == data2.dtype and data.G == data2.G
+    C_out = data.C - cell0 if C_out is None else C_out
+    ip = (indptr if isinstance(indptr, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(indptr).astype(np.int64))).to(device=dev, dtype=torch.int64).contiguous()
+    ix = _as_i32(indices, dev)
+    w = (weights if isinstance(weights, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(weights))).to(device=dev, dtype=data.dtype).contiguous()
+    assert ip.numel() == C_out + 1 and ix.numel() == w.numel()
+    if validate and ix.numel() and (int(ix.min()) < 0 or int(ix.max()) >= data.C):
+        raise ValueError("neighbour index out of range")
+    out = CellMatrix.empty(C_out, data.G, data.dtype) if out is None else out
+    out2 = CellMatrix.empty(C_out, data.G, data.dtype) if out2 is None else out2
+    if order is not None:
+        order = order.to(device=dev, dtype=torch.int32).contiguous()
+        assert order.numel() == C_out
+    _lib.check(_lib.lib().vcy_knn_pool2(data.t.data_ptr(), out.t.data_ptr(), data2.t.data_ptr(), out2.t.data_ptr(), ip.data_ptr(), ix.data_ptr(),
+                                        w.data_ptr(), _p(order), data.C, data.G, data.ld, cell0, C_out, int(maximum), int(slab_genes), data.code,
+                                        _stream()), "knn_pool2")
+    return out, out2
+
+
 def knn_search(space, k: int, include_self: bool = False, q0: int = 0, Q: Optional[int] = None,
                query_block: int = 8192) -> Tuple[torch.Tensor, torch.Tensor]:
     """Exact Euclidean kNN of rows q0..q0+Q of `space` (C, P) among all C rows.
