@@ -138,9 +138,10 @@ class Pipeline:
         # persistent outputs
         self.Sx_loc = ops.CellMatrix.empty(nloc, G, torch.float32)
         self.Ux_loc = ops.CellMatrix.empty(nloc, G, torch.float32)
-        self.Sx_full = self.Sx_loc if world == 1 else ops.CellMatrix.empty(C, G, torch.float32)
+        self.collect = world > 1 or distributed.FORCE
+        self.Sx_full = ops.CellMatrix.empty(C, G, torch.float32) if self.collect else self.Sx_loc
         self.corr_loc = torch.empty((nloc, self.nrndm), dtype=torch.float32, device=dev)
-        self.corr = self.corr_loc if world == 1 else torch.empty((C, self.nrndm), dtype=torch.float32, device=dev)
+        self.corr = torch.empty((C, self.nrndm), dtype=torch.float32, device=dev) if self.collect else self.corr_loc
         self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(10)]
         self.stage_ms = np.zeros(5)
         self.d_ms = []
@@ -172,13 +173,13 @@ class Pipeline:
         dmat = ops.velocity_chain(self.Sx_loc, self.Ux_loc, gamma, None, want=("dmat",), transform=ops.SQRT, psc=1e-10)["dmat"]
         ev[3].record()
         # ---- D: colDeltaCorSqrtpartial; sharded: every rank needs all of e = Sx_sz
-        if self.world > 1:
+        if self.collect:
             self.D.all_gather_rows(self.Sx_loc.t, C, out=self.Sx_full.t)
         ev[4].record()
         ops.coldeltacor_partial(self.Sx_full, dmat, self.neigh_loc, ops.SQRT, ops.RULES_PARTIAL, 1e-10, cell0=c0,
                                 d_row0=c0, order=self.order, out=self.corr_loc, validate=False)
         ev[5].record()
-        if self.world > 1:
+        if self.collect:
             self.D.all_gather_rows(self.corr_loc, C, out=self.corr)
         ev[6].record()
         if timed:
@@ -244,8 +245,11 @@ def main():
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("VCY_FORCE_COLLECTIVES", "0") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
     import velocyto_amd  # noqa: F401
     from velocyto_amd import _lib
@@ -256,7 +260,7 @@ def main():
         pipe.step()
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
     barrier()
@@ -306,7 +310,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:     # reported on rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(pipe, a)
         print(json.dumps(res))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

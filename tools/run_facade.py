@@ -1,0 +1,34 @@
+"""Time the VelocytoLoom facade method by method on a synthetic dataset (default: BASELINE cfg2, 10k x 20k)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import velocyto_amd as vcy
+from velocyto_amd import ops
+import bench
+
+C, G = int(os.environ.get("C", 10000)), int(os.environ.get("G", 20000))
+dev = ops.require_gpu()
+S, U, pcs = bench.synth(C, G, 30, dev)
+t_all = time.perf_counter()
+
+def timed(name, fn, *a, **k):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    r = fn(*a, **k)
+    torch.cuda.synchronize()
+    print(f"{name:32s} {1e3*(time.perf_counter()-t0):10.1f} ms", flush=True)
+    return r
+
+vlm = vcy.analysis.VelocytoLoom.from_arrays(S, U)       # device matrices go in as they are
+vlm.pcs = pcs.cpu().numpy(); vlm.ts = vlm.pcs[:, :2].copy()
+timed("normalize", vlm.normalize, "both")
+timed("knn_imputation(k=30)", vlm.knn_imputation, k=30, n_pca_dims=30)
+timed("knn_imputation(balanced)", vlm.knn_imputation, k=30, n_pca_dims=30, balanced=True, b_sight=240, b_maxl=120)
+timed("fit_gammas(default)", vlm.fit_gammas)
+timed("fit_gammas(plain)", vlm.fit_gammas, fit_offset=False, weighted=False)
+timed("predict_U", vlm.predict_U); timed("calculate_velocity", vlm.calculate_velocity)
+timed("calculate_shift", vlm.calculate_shift); timed("extrapolate_cell_at_t", vlm.extrapolate_cell_at_t)
+timed("estimate_transition_prob", vlm.estimate_transition_prob, hidim="Sx_sz", embed="ts", n_neighbors=500, sampled_fraction=0.5)
+timed("calculate_embedding_shift", vlm.calculate_embedding_shift)
+timed("prepare_markov", vlm.prepare_markov, 2.0, 4.0)
+timed("run_markov(2500)", vlm.run_markov)
+print("total", time.perf_counter() - t_all, "s;  delta_embedding[:2] =", vlm.delta_embedding[:2])

@@ -22,6 +22,17 @@ import torch
 import torch.distributed as dist
 
 
+import os
+
+# VCY_FORCE_COLLECTIVES=1 issues the collectives even at world size 1 (single-GPU smoke test of the RCCL path)
+FORCE = os.environ.get("VCY_FORCE_COLLECTIVES", "0") == "1"
+
+
+def active() -> bool:
+    """True when the exchange steps must be issued (more than one rank, or forced for testing)."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE)
+
+
 def world() -> Tuple[int, int]:
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -40,8 +51,7 @@ def all_shard_bounds(n: int, world_size: int) -> List[Tuple[int, int]]:
 
 
 def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
-    _, ws = world()
-    if ws > 1:
+    if active():
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
@@ -51,7 +61,7 @@ def all_gather_rows(local: torch.Tensor, n_total: int, out: Optional[torch.Tenso
     Equal shards use one all_gather_into_tensor straight into `out`; ragged shards pad to the
     largest shard and trim."""
     rank, ws = world()
-    if ws == 1:
+    if not active():
         if out is None:
             return local
         out.copy_(local)
