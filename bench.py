@@ -4,9 +4,10 @@
 Workload (BASELINE.json configs[2], SURVEY.md section 8d "cfg3"): synthetic 50 000 cells x 30 000 genes,
 k = 30 kNN in a 30-d PCA space, estimate_transition_prob(transform="sqrt", n_neighbors=500,
 sampled_fraction=0.5) => nrndm = 250.  One timed "step" = one pass of the path over the whole
-dataset, inputs (S_sz, U_sz, pcs, sampled embedding neighbours) already resident in HBM:
+dataset, inputs (count layers + size factors, pcs, sampled embedding neighbours) already resident in HBM:
 
-  A  knn_imputation : exact kNN search in pcs + connectivity weights + pooling of S_sz and U_sz
+  A  knn_imputation : exact kNN search in pcs + connectivity weights + pooling of S_sz and U_sz (gathered from the
+                      resident uint16 count layers and per-cell size factors: S_sz = factor * counts)
   B  fit_slope      : per-gene gamma = max(0, <Sx,Ux>/<Sx,Sx>)
   C  velocity chain : predict_U -> velocity -> delta_S -> signed-sqrt dmat (fused)
   D  colDeltaCorSqrtpartial on the sampled embedding neighbours (the dominant kernel)
@@ -62,14 +63,15 @@ def parse():
     return ap.parse_args()
 
 
-def synth(C, G, P, dev, seed=20180811):
-    """Seeded synthetic counts with velocity structure, generated on the device in cell blocks and
-    size-normalised (the a1 pre-step, not in the metric).  Returns cells-major f32 (C, ld) tensors."""
+def synth_counts(C, G, P, dev, seed=20180811):
+    """Seeded synthetic loom-like dataset generated on the device in cell blocks: uint16 spliced/unspliced COUNT
+    matrices (cells-major), the per-cell size factors of the a1 pre-step (analysis.py:535-582; not in the metric)
+    and `pcs`.  Returns (cS, cU, fS, fU, pcs)."""
     from velocyto_amd import ops
     gen = torch.Generator(device=dev).manual_seed(seed)
     ld = ops.padded_ld(G)
-    S = torch.zeros((C, ld), dtype=torch.float32, device=dev)
-    U = torch.zeros((C, ld), dtype=torch.float32, device=dev)
+    S = torch.zeros((C, ld), dtype=torch.int16, device=dev)
+    U = torch.zeros((C, ld), dtype=torch.int16, device=dev)
     alpha = torch.exp(torch.randn(G, generator=gen, device=dev))
     gamma = torch.exp(-0.5 + 0.5 * torch.randn(G, generator=gen, device=dev))
     t_on = torch.rand(G, generator=gen, device=dev) * 0.7
@@ -78,6 +80,8 @@ def synth(C, G, P, dev, seed=20180811):
     branch = (torch.rand(C, generator=gen, device=dev) < 0.5).float()
     branch_gene = (torch.rand(G, generator=gen, device=dev) < 0.3).float()
     size = torch.exp(0.3 * torch.randn(C, generator=gen, device=dev))
+    sumS = torch.zeros(C, dtype=torch.float64, device=dev)
+    sumU = torch.zeros(C, dtype=torch.float64, device=dev)
     blk = 4096
     for s in range(0, C, blk):
         tt = t[s:s + blk, None]
@@ -86,20 +90,33 @@ def synth(C, G, P, dev, seed=20180811):
         u = alpha[None, :] * (1 - torch.exp(-4.0 * tau)) * gate
         sp = (alpha / gamma)[None, :] * (1 - torch.exp(-2.0 * gamma[None, :] * tau)) * gate
         sz = size[s:s + blk, None]
-        U[s:s + blk, :G] = torch.poisson(0.3 * sz * u, generator=gen)
-        S[s:s + blk, :G] = torch.poisson(sz * sp, generator=gen)
-    # a1 pre-step (analysis.py:535-582): size normalisation
-    for M in (S, U):
-        cs = M.sum(1)
-        M.mul_((cs.mean() / cs.clamp(min=1.0))[:, None])
+        cu = torch.poisson(0.3 * sz * u, generator=gen).clamp_(max=65535)
+        cs = torch.poisson(sz * sp, generator=gen).clamp_(max=65535)
+        sumU[s:s + blk], sumS[s:s + blk] = cu.sum(1).double(), cs.sum(1).double()
+        U[s:s + blk, :G] = cu.to(torch.int32).to(torch.int16)          # uint16 bit pattern
+        S[s:s + blk, :G] = cs.to(torch.int32).to(torch.int16)
+    fS = sumS.mean() / sumS.clamp(min=1.0)                              # avg_size / cell_size
+    fU = sumU.mean() / sumU.clamp(min=1.0)
+    cS, cU = ops.CountMatrix(S, G), ops.CountMatrix(U, G)
     # pcs: top-P principal components of log2(S_sz + 1) (perform_PCA is upstream of the path; randomised SVD here)
-    L = torch.log2(S[:, :G] + 1.0)
+    L = torch.empty((C, G), dtype=torch.float32, device=dev)
+    for s in range(0, C, blk):
+        L[s:s + blk] = torch.log2((S[s:s + blk, :G].to(torch.int32) & 0xFFFF).float() * fS[s:s + blk, None].float() + 1.0)
     L -= L.mean(0, keepdim=True)
     torch.manual_seed(seed)             # svd_lowrank draws its sketch from the global RNG: keep every rank's pcs identical
     Uu, Ss, _ = torch.svd_lowrank(L, q=P, niter=2)
     pcs = (Uu * Ss).double().contiguous()
     del L
-    return ops.CellMatrix(S, G), ops.CellMatrix(U, G), pcs
+    return cS, cU, fS, fU, pcs
+
+
+def synth(C, G, P, dev, seed=20180811):
+    """The same dataset as size-normalised f32 matrices S_sz, U_sz (cells-major) + pcs."""
+    cS, cU, fS, fU, pcs = synth_counts(C, G, P, dev, seed)
+    S, U = cS.to_float(torch.float32), cU.to_float(torch.float32)
+    S.t.mul_(fS[:, None].float())
+    U.t.mul_(fU[:, None].float())
+    return S, U, pcs
 
 
 def sample_neighbors_device(embedding, n_neighbors, sampled_fraction, dev, seed=15071990):
@@ -124,7 +141,8 @@ class Pipeline:
         self.ops, self.D = ops, distributed
         self.a, self.dev, self.rank, self.world = args, dev, rank, world
         C, G = args.cells, args.genes
-        self.S, self.U, self.pcs = synth(C, G, args.pca_dims, dev)
+        # resident inputs: the loom's uint16 count layers + per-cell size factors (S_sz = fS * S is never materialised)
+        self.cS, self.cU, self.fS, self.fU, self.pcs = synth_counts(C, G, args.pca_dims, dev)
         self.space = self.pcs[:, :args.pca_dims].contiguous()
         emb = self.pcs[:, :2].contiguous()
         self.neigh, _ = sample_neighbors_device(emb, args.n_neighbors, args.sampled_fraction, dev)
@@ -161,8 +179,8 @@ class Pipeline:
         indices = torch.cat([torch.arange(c0, c1, device=self.dev, dtype=torch.int32)[:, None], idx], 1).contiguous()
         indptr = torch.arange(0, (nloc + 1) * (k + 1), k + 1, device=self.dev, dtype=torch.int64)
         wrow = wrow.contiguous()
-        ops.knn_pool2(self.S, self.U, indptr, indices, wrow, cell0=c0, C_out=nloc, out=self.Sx_loc, out2=self.Ux_loc, validate=False,
-                      order=self.pool_order, slab_genes=self.a.slab)
+        ops.knn_pool_counts(self.cS, self.cU, self.fS, self.fU, indptr, indices, wrow, dtype=torch.float32, cell0=c0, C_out=nloc,
+                            out=self.Sx_loc, out2=self.Ux_loc, validate=False, order=self.pool_order, slab_genes=self.a.slab)
         ev[1].record()
         # ---- B: fit_slope (estimation.py:267-279); sharded: all-reduce of the per-gene moments
         mom = ops.fit_slope_moments(self.Ux_loc, self.Sx_loc)
@@ -197,8 +215,9 @@ def cpu_baseline(pipe, args):
     Cs = min(args.cpu_cells, args.cells)
     G = args.genes
     cores = os.cpu_count() or 1
-    S = pipe.S.t[:Cs, :G].double().cpu().numpy().T.copy()     # (G, Cs) reference layout
-    U = pipe.U.t[:Cs, :G].double().cpu().numpy().T.copy()
+    cnt = lambda cm: (cm.t[:Cs, :G].to(torch.int32) & 0xFFFF).double()
+    S = (cnt(pipe.cS) * pipe.fS[:Cs, None]).cpu().numpy().T.copy()     # S_sz in the reference's (G, Cs) layout
+    U = (cnt(pipe.cU) * pipe.fU[:Cs, None]).cpu().numpy().T.copy()
     space = pipe.space[:Cs].cpu().numpy()
     rng = np.random.default_rng(0)
     nr = min(pipe.nrndm, Cs - 1)
@@ -293,6 +312,7 @@ def main():
                                    f"{a.pca_dims} PCs) -> fit_slope -> velocity chain -> colDeltaCorSqrtpartial(nrndm={nr}, "
                                    f"n_neighbors={a.n_neighbors}, sampled_fraction={a.sampled_fraction}, psc=1e-10)",
                        "cells": C, "genes": G, "k": a.k, "nrndm": nr,
+                       "inputs": "uint16 spliced/unspliced count layers + per-cell size factors (S_sz = factor*counts), pcs, sampled neighbours",
                        "parallelism": "single GPU" if world == 1 else f"cells sharded over {world} GPUs (RCCL all-reduce of fit "
                                       "moments, all-gather of Sx shards and of correlation rows)",
                        "stage_ms": {"A_knn_imputation": stage[0], "B_fit_slope": stage[1], "C_velocity_chain": stage[2],

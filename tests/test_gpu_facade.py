@@ -66,6 +66,18 @@ def test_facade_normalize_impute(vcy, golden, dtype):
     w = vlm.knn_smoothing_w
     vlm.knn_imputation_precomputed(w)
     close(vlm.Sx, g["bal_Sx"], rt, at)
+    # the runs above gathered from the uint16 count layers (loom dtype); float layers / hand-set S_sz take the float kernel
+    assert set(vlm._counts) == {"S", "U"} and set(vlm._sz_scale) == {"S_sz", "U_sz"}
+    vlm.S_sz = g["S_sz"]
+    assert "S_sz" not in vlm._sz_scale
+    vlm.knn_imputation_precomputed(w)
+    close(vlm.Sx, g["bal_Sx"], rt, at)
+    vf = vcy.analysis.VelocytoLoom.from_arrays(g["S"].astype(float), g["U"].astype(float), dtype=dtype)
+    assert vf._counts == {}
+    vf.normalize("both"); vf.pcs = g["pcs"]
+    vf.knn_imputation(k=12, n_pca_dims=10, size_norm=False, n_jobs=1)
+    vlm.knn_imputation(k=12, n_pca_dims=10, size_norm=False, n_jobs=1)
+    close(vlm.Sx, vf.Sx, rt, at)
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])

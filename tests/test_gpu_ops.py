@@ -161,6 +161,46 @@ def test_knn_pool_golden(ops, golden, dtype):
     np.testing.assert_array_equal(part, mx[:, 50:120])
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_knn_pool_counts(ops, oracle, golden, dtype):
+    """Pooling gathered from the uint16 count layers + per-cell size factors == pooling of the normalised floats."""
+    from scipy import sparse
+    g = golden("pipeline")
+    S, U = g["S"], g["U"]                                   # uint16 (G, C) like a loom
+    assert ops.CountMatrix.representable(S) and not ops.CountMatrix.representable(S.astype(float))
+    C = S.shape[1]
+    fS, fU = S.sum(0).mean() / S.sum(0), U.sum(0).mean() / U.sum(0)
+    knn = oracle.knn_graph(g["pcs"][:, :10], 12)
+    w = oracle.connectivity_to_weights(knn)
+    w.sort_indices()
+    cS, cU = ops.CountMatrix.from_genes_major(S), ops.CountMatrix.from_genes_major(U)
+    assert cS.ld % 64 == 0 and int(cS.t[:, cS.G:].abs().sum()) == 0
+    np.testing.assert_array_equal(cS.to_float("float64").to_genes_major(), S.astype(float))
+    rt = 1e-12 if dtype == "float64" else 3e-6
+    for slab in (0, 8, 24):
+        Sx, Ux = ops.knn_pool_counts(cS, cU, fS, fU, w.indptr, w.indices, w.data, dtype=dtype, slab_genes=slab)
+        np.testing.assert_allclose(Sx.to_genes_major(), g["Sx"], rtol=rt, atol=rt)
+        np.testing.assert_allclose(Ux.to_genes_major(), g["Ux"], rtol=rt, atol=rt)
+        assert float(Sx.t[:, Sx.G:].abs().sum()) == 0.0
+    Sx1 = ops.knn_pool_counts(cS, None, fS, None, w.indptr, w.indices, w.data, dtype=dtype)
+    np.testing.assert_allclose(Sx1.to_genes_major(), g["Sx"], rtol=rt, atol=rt)
+    # maximum=True with diag=2 (golden max_*) and a row block with an order
+    conn = (knn > 0).astype(float).tolil()
+    conn.setdiag(2.0)
+    w2 = sparse.csr_matrix(oracle.connectivity_to_weights(conn.tocsr(), diag=2.0))
+    w2.sort_indices()
+    Sx, Ux = ops.knn_pool_counts(cS, cU, fS, fU, w2.indptr, w2.indices, w2.data, dtype=dtype, maximum=True)
+    np.testing.assert_allclose(Sx.to_genes_major(), g["max_Sx"], rtol=rt, atol=rt)
+    np.testing.assert_allclose(Ux.to_genes_major(), g["max_Ux"], rtol=rt, atol=rt)
+    lo, hi = 40, 123
+    part = ops.knn_pool_counts(cS, None, fS, None, w2.indptr[lo:hi + 1] - w2.indptr[lo], w2.indices[w2.indptr[lo]:w2.indptr[hi]],
+                               w2.data[w2.indptr[lo]:w2.indptr[hi]], dtype=dtype, maximum=True, cell0=lo, C_out=hi - lo,
+                               order=torch.randperm(hi - lo).to(torch.int32))
+    np.testing.assert_array_equal(part.to_genes_major(), Sx.to_genes_major()[:, lo:hi])
+    big = np.array([[70000, 1]], dtype=np.int64)
+    assert not ops.CountMatrix.representable(big)
+
+
 @pytest.mark.parametrize("include_self", [False, True])
 def test_knn_search_vs_oracle(ops, oracle, golden, include_self):
     g = golden("neighbors")

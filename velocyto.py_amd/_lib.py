@@ -35,6 +35,8 @@ SIGNATURES = {
     "vcy_scatter_rows": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]),
     "vcy_knn_pool": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_vp]),
     "vcy_knn_pool2": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_vp]),
+    "vcy_knn_pool_counts": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
+                                    c_int, c_i64, c_int, c_vp]),
     "vcy_knn_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "vcy_knn_search": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_vp]),
     "vcy_balance_knn_host": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp]),

@@ -96,6 +96,17 @@ class VelocytoLoom:
         if name in _MATRIX_ATTRS:
             self._host.pop(name, None)
             self._dev[name] = value if isinstance(value, CellMatrix) else CellMatrix.from_genes_major(np.asarray(value), self._dtype)
+            st = self.__dict__
+            if name in ("S", "U"):
+                # loom layers are uint16 molecule counts: keep them as such on the device too, so that pooling can
+                # gather 2-byte elements (S_sz = norm_factor * S is applied on the fly, ops.knn_pool_counts)
+                counts = st.setdefault("_counts", {})
+                counts.pop(name, None)
+                st.setdefault("_sz_scale", {}).pop(name + "_sz", None)
+                if isinstance(value, np.ndarray) and ops.CountMatrix.representable(value):
+                    counts[name] = ops.CountMatrix.from_genes_major(value)
+            elif name in ("S_sz", "U_sz"):
+                st.setdefault("_sz_scale", {}).pop(name, None)       # assigned by hand: no longer factor * counts
         else:
             object.__setattr__(self, name, value)
 
@@ -149,6 +160,7 @@ class VelocytoLoom:
             fac, self.norm_factor = None, 1
         sz, nm = ops.scale_log(S, fac, True, log, pcount)
         self._set_dev("S_sz", sz)
+        self.__dict__.setdefault("_sz_scale", {})["S_sz"] = fac if fac is not None else torch.ones(S.C, dtype=torch.float64, device=S.t.device)
         if log:
             self._set_dev("S_norm", nm)
 
@@ -169,6 +181,11 @@ class VelocytoLoom:
             fac, self.Unorm_factor = None, 1
         sz, nm = ops.scale_log(U, fac, True, log, pcount, fix_nonfinite=True)
         self._set_dev("U_sz", sz)
+        scale = fac if fac is not None else torch.ones(U.C, dtype=torch.float64, device=U.t.device)
+        if bool(torch.isfinite(scale).all()):                         # (cells without unspliced counts: float path keeps the :580 fix-up)
+            self.__dict__.setdefault("_sz_scale", {})["U_sz"] = scale
+        else:
+            self.__dict__.setdefault("_sz_scale", {}).pop("U_sz", None)
         if log:
             self._set_dev("U_norm", nm)
 
@@ -269,7 +286,13 @@ class VelocytoLoom:
         w = sparse.csr_matrix(w)
         assert np.allclose(np.asarray(w.sum(1)).ravel(), 1), "weight matrix need to sum to one over the columns"   # neighbors.py:422
         indptr, indices, vals = w.indptr.astype(np.int64), w.indices.astype(np.int32), np.ascontiguousarray(w.data, dtype=np.float64)
-        Sx, Ux = ops.knn_pool2(self.dev(s_name), self.dev(u_name), indptr, indices, vals, maximum=maximum)
+        counts, scale = self.__dict__.get("_counts", {}), self.__dict__.get("_sz_scale", {})
+        if "S" in counts and "U" in counts and ((s_name, u_name) == ("S", "U") or
+                                                ((s_name, u_name) == ("S_sz", "U_sz") and "S_sz" in scale and "U_sz" in scale)):
+            sS, sU = (None, None) if s_name == "S" else (scale["S_sz"], scale["U_sz"])
+            Sx, Ux = ops.knn_pool_counts(counts["S"], counts["U"], sS, sU, indptr, indices, vals, dtype=self._dtype, maximum=maximum)
+        else:
+            Sx, Ux = ops.knn_pool2(self.dev(s_name), self.dev(u_name), indptr, indices, vals, maximum=maximum)
         self._set_dev("Sx", Sx)
         self._set_dev("Ux", Ux)
         self._set_dev("Sx_sz", Sx.clone())                        # :1022-1023 separate copies for backwards compatibility

@@ -105,6 +105,88 @@ __global__ __launch_bounds__(256) void k_knn_pool(const T *__restrict__ data, T 
 
 using namespace vcy;
 
+// ---------------------------------------------------------------------------------------------
+// Count-matrix variant.  The loom layers are uint16 molecule counts (velocyto/constants.py:11) and the
+// size-normalised matrices are just  S_sz[c,:] = norm_factor[c] * S[c,:]  (analysis.py:546-549, 573-579), so
+// the pooled matrices can be gathered straight from the 2-byte counts,
+//     out[c,:] = sum_p (w[p] * scale[indices[p]]) * counts[indices[p],:],
+// which halves the bytes every gather moves through L2/HBM.  Thread = 8 genes (one 16-byte load of uint16).
+struct alignas(16) U16x8 { unsigned short v[8]; };
+
+template <typename T, bool DUAL>
+__global__ __launch_bounds__(256) void k_knn_pool_counts(const unsigned short *__restrict__ cS, const unsigned short *__restrict__ cU,
+                                                          const double *__restrict__ scaleS, const double *__restrict__ scaleU,
+                                                          T *__restrict__ out, T *__restrict__ out2, const int64_t *__restrict__ indptr,
+                                                          const int32_t *__restrict__ indices, const T *__restrict__ w,
+                                                          const int32_t *__restrict__ order, int G, int64_t ld16, int64_t ld_out,
+                                                          int64_t cell0, int C_out, int slab, int maximum)
+{
+    const int per = (C_out + 7) / 8, nblk = per * 8;          // XCD-aware slab-major schedule, as in k_knn_pool
+    const int64_t b = blockIdx.x;
+    const int s = (int)(b / nblk), bi = (int)(b % nblk);
+    const int pos = (bi & 7) * per + (bi >> 3);
+    if (pos >= C_out) return;
+    const int cl = order ? order[pos] : pos;
+    const int g0 = s * slab, g1 = min(G, g0 + slab);
+    const int64_t p0 = indptr[cl], p1 = indptr[cl + 1];
+    const int nvec = (g1 - g0 + 7) / 8;                       // rows are zero-padded to ld16 (multiple of 8)
+    for (int v = threadIdx.x; v < nvec; v += blockDim.x) {
+        T acc[8], acc2[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { acc[k] = T(0); acc2[k] = T(0); }
+        int64_t p = p0;
+        for (; p + 3 < p1; p += 4) {
+            U16x8 x[4], y[4]; T ws[4], wu[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = indices[p + u];
+                const int64_t ro = (int64_t)j * ld16 + g0;
+                x[u] = reinterpret_cast<const U16x8 *>(cS + ro)[v];
+                if (DUAL) y[u] = reinterpret_cast<const U16x8 *>(cU + ro)[v];
+                const T wp = w[p + u];
+                ws[u] = wp * (T)scaleS[j];
+                if (DUAL) wu[u] = wp * (T)scaleU[j];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    acc[k] = fma(ws[u], (T)x[u].v[k], acc[k]);
+                    if (DUAL) acc2[k] = fma(wu[u], (T)y[u].v[k], acc2[k]);
+                }
+        }
+        for (; p < p1; ++p) {
+            const int j = indices[p];
+            const int64_t ro = (int64_t)j * ld16 + g0;
+            const U16x8 xv = reinterpret_cast<const U16x8 *>(cS + ro)[v];
+            U16x8 yv;
+            if (DUAL) yv = reinterpret_cast<const U16x8 *>(cU + ro)[v];
+            const T wp = w[p], wsv = wp * (T)scaleS[j], wuv = DUAL ? wp * (T)scaleU[j] : T(0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { acc[k] = fma(wsv, (T)xv.v[k], acc[k]); if (DUAL) acc2[k] = fma(wuv, (T)yv.v[k], acc2[k]); }
+        }
+        if (maximum) {
+            const int64_t ro = (cell0 + cl) * ld16 + g0;
+            const U16x8 sv = reinterpret_cast<const U16x8 *>(cS + ro)[v];
+            const T fs = (T)scaleS[cell0 + cl];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const T o = fs * (T)sv.v[k]; acc[k] = acc[k] > o ? acc[k] : o; }
+            if (DUAL) {
+                const U16x8 tv = reinterpret_cast<const U16x8 *>(cU + ro)[v];
+                const T fu = (T)scaleU[cell0 + cl];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const T o = fu * (T)tv.v[k]; acc2[k] = acc2[k] > o ? acc2[k] : o; }
+            }
+        }
+        T *o1 = out + (int64_t)cl * ld_out + g0 + v * 8;
+        T *o2 = DUAL ? out2 + (int64_t)cl * ld_out + g0 + v * 8 : nullptr;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (g0 + v * 8 + k < ld_out) { o1[k] = (g0 + v * 8 + k < G) ? acc[k] : T(0); if (DUAL) o2[k] = (g0 + v * 8 + k < G) ? acc2[k] : T(0); }
+        }
+    }
+}
+
 static int knn_pool_impl(const void *data, void *out, const void *data2, void *out2, const int64_t *indptr, const int32_t *indices,
                          const void *w, const int32_t *order, int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int maximum,
                          int64_t slab_genes, int dtype, vcy_stream stream)
@@ -147,4 +229,33 @@ extern "C" int vcy_knn_pool2(const void *data, void *out, const void *data2, voi
 {
     VCY_REQUIRE(data2 && out2, "knn_pool2: null pointer");
     return knn_pool_impl(data, out, data2, out2, indptr, indices, w, order, C, G, ld, cell0, C_out, maximum, slab_genes, dtype, stream);
+}
+
+extern "C" int vcy_knn_pool_counts(const void *countsS, const void *countsU, const double *scaleS, const double *scaleU, void *out,
+                                   void *out2, const int64_t *indptr, const int32_t *indices, const void *w, const int32_t *order,
+                                   int64_t C, int64_t G, int64_t ld16, int64_t ld_out, int64_t cell0, int64_t C_out, int maximum,
+                                   int64_t slab_genes, int dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(countsS && scaleS && out && indptr && indices && w, "knn_pool_counts: null pointer");
+    VCY_REQUIRE((countsU == nullptr) == (out2 == nullptr) && (countsU == nullptr) == (scaleU == nullptr), "knn_pool_counts: countsU/scaleU/out2 go together");
+    VCY_REQUIRE(C > 0 && G > 0 && ld16 >= G && ld_out >= G && C_out > 0 && cell0 >= 0 && cell0 + C_out <= C, "knn_pool_counts: bad shape");
+    VCY_REQUIRE(ld16 % 8 == 0 && ((uintptr_t)countsS % 16) == 0 && ((uintptr_t)countsU % 16) == 0, "knn_pool_counts: count rows must be 16-byte aligned (ld16 % 8 == 0)");
+    VCY_REQUIRE(dtype == VCY_F32 || dtype == VCY_F64, "knn_pool_counts: bad dtype");
+    int64_t slab = slab_genes > 0 ? slab_genes : 1024;
+    slab = (slab + 7) / 8 * 8;
+    if (slab > G) slab = (G + 7) / 8 * 8;
+    const int64_t nslab = (G + slab - 1) / slab;
+    const int threads = slab / 8 >= 256 ? 256 : (slab / 8 >= 128 ? 128 : 64);
+    const int64_t blocks = nslab * ((C_out + 7) / 8 * 8);
+    VCY_REQUIRE(blocks < (1LL << 31), "knn_pool_counts: grid too large");
+    hipStream_t st = as_stream(stream);
+#define VCY_POOLC(T, DUAL)                                                                                                                   \
+    hipLaunchKernelGGL((k_knn_pool_counts<T, DUAL>), dim3((unsigned)blocks), dim3(threads), 0, st, (const unsigned short *)countsS,              \
+                       (const unsigned short *)countsU, scaleS, scaleU, (T *)out, (T *)out2, indptr, indices, (const T *)w, order, (int)G, ld16, \
+                       ld_out, cell0, (int)C_out, (int)slab, maximum)
+    if (dtype == VCY_F32) { if (countsU) VCY_POOLC(float, true); else VCY_POOLC(float, false); }
+    else { if (countsU) VCY_POOLC(double, true); else VCY_POOLC(double, false); }
+#undef VCY_POOLC
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
 }

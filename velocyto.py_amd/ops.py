@@ -141,6 +141,56 @@ class CellMatrix:
         return self.t[:, : self.G].to("cpu").numpy().astype(dtype, copy=False)
 
 
+class CountMatrix:
+    """A (C cells, G genes) uint16 molecule-count matrix on the device (the loom layers as stored,
+    velocyto/constants.py:11), cells-major, rows padded with zeros to ld16 (multiple of 64).  Stored in an
+    int16 tensor (same bits; torch's uint16 support is partial)."""
+
+    __slots__ = ("t", "G")
+
+    def __init__(self, t: torch.Tensor, G: int):
+        assert t.dim() == 2 and t.is_contiguous() and t.is_cuda and t.dtype == torch.int16 and t.shape[1] >= G and t.shape[1] % 8 == 0
+        self.t, self.G = t, int(G)
+
+    C = property(lambda self: int(self.t.shape[0]))
+    ld = property(lambda self: int(self.t.shape[1]))
+
+    @staticmethod
+    def representable(a: np.ndarray) -> bool:
+        a = np.asarray(a)
+        if a.dtype == np.uint16 or a.dtype == np.uint8:
+            return True
+        if a.dtype.kind in "iu":
+            return a.size == 0 or (a.min() >= 0 and a.max() <= 65535)
+        return False
+
+    @classmethod
+    def from_genes_major(cls, a: np.ndarray) -> "CountMatrix":
+        """(G, C) integer counts (0..65535) -> device (C, ld16) uint16 through the tiled transpose kernel."""
+        dev = require_gpu()
+        a = np.ascontiguousarray(np.asarray(a).astype(np.uint16, copy=False))
+        G, C = a.shape
+        src = torch.from_numpy(a.view(np.int16)).to(dev)
+        out = torch.empty((C, padded_ld(G)), dtype=torch.int16, device=dev)
+        _lib.check(_lib.lib().vcy_transpose(src.data_ptr(), out.data_ptr(), G, C, C, out.shape[1], 2, 2, _stream()), "transpose(u16)")
+        return cls(out, G)
+
+    @classmethod
+    def from_cells_major_tensor(cls, t: torch.Tensor, G: int) -> "CountMatrix":
+        """(C, >=G) float/int device tensor holding integer counts -> padded uint16 copy."""
+        C = t.shape[0]
+        out = torch.zeros((C, padded_ld(G)), dtype=torch.int16, device=t.device)
+        out[:, :G] = t[:, :G].to(torch.int32).to(torch.int16)       # wraps 32768..65535 onto the same 16 bits
+        return cls(out, G)
+
+    def to_float(self, dtype=None) -> CellMatrix:
+        """float copy (counts as they are), cells-major."""
+        dt = resolve_dtype(dtype)
+        out = CellMatrix(torch.zeros((self.C, padded_ld(self.G)), dtype=dt, device=self.t.device), self.G)
+        out.t[:, : self.ld] = (self.t.to(torch.int32) & 0xFFFF).to(dt)[:, : out.ld]
+        return out
+
+
 def _as_i32(ixs, dev) -> torch.Tensor:
     if isinstance(ixs, torch.Tensor):
         return ixs.to(device=dev, dtype=torch.int32).contiguous()
@@ -242,6 +292,40 @@ def knn_pool2(data: CellMatrix, data2: CellMatrix, indptr, indices, weights, max
                                         w.data_ptr(), _p(order), data.C, data.G, data.ld, cell0, C_out, int(maximum), int(slab_genes), data.code,
                                         _stream()), "knn_pool2")
     return out, out2
+
+
+def knn_pool_counts(cS: CountMatrix, cU: Optional[CountMatrix], scaleS, scaleU, indptr, indices, weights, dtype=None,
+                    maximum: bool = False, cell0: int = 0, C_out: Optional[int] = None, slab_genes: int = 0,
+                    out: Optional[CellMatrix] = None, out2: Optional[CellMatrix] = None, order: Optional[torch.Tensor] = None,
+                    validate: bool = True):
+    """Pooled Sx (and Ux) gathered straight from the uint16 count matrices with per-cell size factors
+    (vcy_knn_pool_counts): out[c,:] = sum_p w[p] * scale[idx[p]] * counts[idx[p],:]."""
+    dev = cS.t.device
+    dt = resolve_dtype(dtype)
+    C_out = cS.C - cell0 if C_out is None else C_out
+    ip = (indptr if isinstance(indptr, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(indptr).astype(np.int64))).to(device=dev, dtype=torch.int64).contiguous()
+    ix = _as_i32(indices, dev)
+    w = (weights if isinstance(weights, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(weights))).to(device=dev, dtype=dt).contiguous()
+    f64 = lambda t: None if t is None else (t if isinstance(t, torch.Tensor) else torch.as_tensor(np.asarray(t, dtype=np.float64))).to(device=dev, dtype=torch.float64).contiguous()
+    sS = f64(scaleS) if scaleS is not None else torch.ones(cS.C, dtype=torch.float64, device=dev)
+    sU = None
+    if cU is not None:
+        assert cU.t.shape == cS.t.shape and cU.G == cS.G
+        sU = f64(scaleU) if scaleU is not None else torch.ones(cS.C, dtype=torch.float64, device=dev)
+    assert ip.numel() == C_out + 1 and ix.numel() == w.numel() and sS.numel() == cS.C
+    if validate and ix.numel() and (int(ix.min()) < 0 or int(ix.max()) >= cS.C):
+        raise ValueError("neighbour index out of range")
+    out = CellMatrix.empty(C_out, cS.G, dt) if out is None else out
+    if cU is not None:
+        out2 = CellMatrix.empty(C_out, cS.G, dt) if out2 is None else out2
+    if order is not None:
+        order = order.to(device=dev, dtype=torch.int32).contiguous()
+        assert order.numel() == C_out
+    _lib.check(_lib.lib().vcy_knn_pool_counts(cS.t.data_ptr(), None if cU is None else cU.t.data_ptr(), sS.data_ptr(), _p(sU), out.t.data_ptr(),
+                                              None if cU is None else out2.t.data_ptr(), ip.data_ptr(), ix.data_ptr(), w.data_ptr(), _p(order),
+                                              cS.C, cS.G, cS.ld, out.ld, cell0, C_out, int(maximum), int(slab_genes), out.code, _stream()),
+               "knn_pool_counts")
+    return (out, out2) if cU is not None else out
 
 
 def knn_search(space, k: int, include_self: bool = False, q0: int = 0, Q: Optional[int] = None,
