@@ -58,6 +58,8 @@ def parse():
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass; the default workload "
                          "uses the figure recorded in profiles/r01c_bench_50kx30k_pmc.csv, other workloads report null")
     ap.add_argument("--slab", type=int, default=0, help="gene slab of the pooling kernel (0 = library default)")
+    ap.add_argument("--exchange", choices=["halo", "allgather"], default="halo",
+                    help="N > 1: how ranks obtain the rows of e = Sx_sz their neighbour lists reference")
     ap.add_argument("--order", choices=["natural", "embedding"], default="embedding",
                     help="schedule order of the cells in stage D (results are order-independent)")
     return ap.parse_args()
@@ -143,6 +145,14 @@ class Pipeline:
         C, G = args.cells, args.genes
         # resident inputs: the loom's uint16 count layers + per-cell size factors (S_sz = fS * S is never materialised)
         self.cS, self.cU, self.fS, self.fU, self.pcs = synth_counts(C, G, args.pca_dims, dev)
+        self.collect = world > 1 or distributed.FORCE
+        if self.collect:
+            # cell-sharded run: relabel the cells in Morton order of the embedding so that a rank's contiguous block
+            # of cells is spatially coherent and most sampled neighbours are rank-local (dataset preprocessing, untimed)
+            perm = ops.morton_order(self.pcs[:, :2].contiguous(), 2).long()
+            self.cS = ops.CountMatrix(self.cS.t.index_select(0, perm).contiguous(), G)
+            self.cU = ops.CountMatrix(self.cU.t.index_select(0, perm).contiguous(), G)
+            self.fS, self.fU, self.pcs = self.fS[perm].contiguous(), self.fU[perm].contiguous(), self.pcs[perm].contiguous()
         self.space = self.pcs[:, :args.pca_dims].contiguous()
         emb = self.pcs[:, :2].contiguous()
         self.neigh, _ = sample_neighbors_device(emb, args.n_neighbors, args.sampled_fraction, dev)
@@ -156,8 +166,13 @@ class Pipeline:
         # persistent outputs
         self.Sx_loc = ops.CellMatrix.empty(nloc, G, torch.float32)
         self.Ux_loc = ops.CellMatrix.empty(nloc, G, torch.float32)
-        self.collect = world > 1 or distributed.FORCE
-        self.Sx_full = ops.CellMatrix.empty(C, G, torch.float32) if self.collect else self.Sx_loc
+        self.Sx_full = ops.CellMatrix(torch.zeros((C, ops.padded_ld(G)), dtype=torch.float32, device=dev), G) if self.collect else self.Sx_loc
+        self.plan = None
+        if self.collect and args.exchange == "halo":
+            need = torch.zeros(C, dtype=torch.bool, device=dev)
+            need[self.neigh_loc.reshape(-1).long()] = True
+            need[self.c0:self.c1] = True
+            self.plan = distributed.HaloPlan(need, C)
         self.corr_loc = torch.empty((nloc, self.nrndm), dtype=torch.float32, device=dev)
         self.corr = torch.empty((C, self.nrndm), dtype=torch.float32, device=dev) if self.collect else self.corr_loc
         self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(10)]
@@ -191,7 +206,9 @@ class Pipeline:
         dmat = ops.velocity_chain(self.Sx_loc, self.Ux_loc, gamma, None, want=("dmat",), transform=ops.SQRT, psc=1e-10)["dmat"]
         ev[3].record()
         # ---- D: colDeltaCorSqrtpartial; sharded: every rank needs all of e = Sx_sz
-        if self.collect:
+        if self.plan is not None:
+            self.plan.exchange(self.Sx_loc.t, self.Sx_full.t)          # halo rows only (all_to_all_single)
+        elif self.collect:
             self.D.all_gather_rows(self.Sx_loc.t, C, out=self.Sx_full.t)
         ev[4].record()
         ops.coldeltacor_partial(self.Sx_full, dmat, self.neigh_loc, ops.SQRT, ops.RULES_PARTIAL, 1e-10, cell0=c0,
@@ -313,8 +330,10 @@ def main():
                                    f"n_neighbors={a.n_neighbors}, sampled_fraction={a.sampled_fraction}, psc=1e-10)",
                        "cells": C, "genes": G, "k": a.k, "nrndm": nr,
                        "inputs": "uint16 spliced/unspliced count layers + per-cell size factors (S_sz = factor*counts), pcs, sampled neighbours",
-                       "parallelism": "single GPU" if world == 1 else f"cells sharded over {world} GPUs (RCCL all-reduce of fit "
-                                      "moments, all-gather of Sx shards and of correlation rows)",
+                       "parallelism": "single GPU" if world == 1 else f"cells sharded over {world} GPUs in embedding (Morton) order; RCCL "
+                                      "all-reduce of fit moments, " + (f"halo exchange of Sx rows (all_to_all, {pipe.plan.n_recv} of {C} rows "
+                                      "received by rank 0)" if pipe.plan is not None else "all-gather of Sx shards") +
+                                      ", all-gather of correlation rows",
                        "stage_ms": {"A_knn_imputation": stage[0], "B_fit_slope": stage[1], "C_velocity_chain": stage[2],
                                     "D_exchange": stage[3], "D_coldeltacor": stage[4]},
                        "cell_order_D": a.order},
@@ -330,10 +349,12 @@ def main():
         }
         if not a.no_cpu_baseline and world == 1:     # reported on rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(pipe, a)
-        print(json.dumps(res))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:                                    # the ONE JSON line, last thing on stdout (after RCCL's own teardown chatter)
+        sys.stdout.flush()
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

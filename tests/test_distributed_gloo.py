@@ -53,6 +53,21 @@ def _worker(rank, world, port, C, G, nr, q):
         corr = D.all_gather_rows(torch.tensor(corr_loc), C)
         out_buf = torch.empty((C, nr), dtype=torch.float64)
         assert D.all_gather_rows(torch.tensor(corr_loc), C, out=out_buf) is out_buf and torch.equal(torch.nan_to_num(out_buf, nan=9.0), torch.nan_to_num(corr, nan=9.0))
+        # halo exchange: only the rows my neighbour lists reference travel; results must not change
+        need = torch.zeros(C, dtype=torch.bool)
+        need[torch.as_tensor(ixs[c0:c1].ravel())] = True
+        need[c0:c1] = True
+        plan = D.HaloPlan(need, C)
+        full2 = torch.full((C, G), float("nan"), dtype=torch.float64)
+        plan.exchange(Sx_loc, full2)
+        got = full2.numpy()
+        assert np.array_equal(got[need.numpy()], Sx.T[need.numpy()]), "halo rows differ"
+        assert np.isnan(got[~need.numpy()]).all(), "rows nobody asked for must stay untouched"
+        assert plan.n_recv == int(need.sum()) - (c1 - c0)
+        plan.exchange(Sx_loc * 2.0, full2)                                   # plan is reusable
+        assert np.array_equal(full2.numpy()[need.numpy()], 2.0 * Sx.T[need.numpy()])
+        corr_h = oracle.coldeltacor_partial_compact(np.nan_to_num(full2.numpy().T / 2.0), dmat, ixs, "sqrt", 1e-10, c0=c0, c1=c1)[c0:c1]
+        assert np.array_equal(np.nan_to_num(corr_h, nan=9.0), np.nan_to_num(corr_loc, nan=9.0))
         if rank == 0:
             q.put((gamma, corr.numpy(), Sx_full))
     finally:

@@ -8,11 +8,16 @@ cells-major matrices).  Exchange steps of the hot path:
   A  pooling     none   -- S_sz/U_sz are replicated inputs (any cell can be a neighbour)
   B  fit_slope   all-reduce(sum) of the per-gene moments, 3*G fp64 (720 KB at 30k genes)
   C  velocity    none   -- row-local
-  D  colDeltaCor all-gather of the Sx_sz shards (every rank needs all of `e`), then the
-                 all-gather of the compact correlation rows (C x nrndm) for whoever wants them whole
-
-xGMI is point-to-point (7 links per GPU): the big all-gather moves 1/world of the matrix over
-each link once, so it is issued as ONE collective on the full shard (largest possible message).
+  D  colDeltaCor every rank needs the rows of `e` = Sx_sz that its cells' sampled neighbours live in.
+                 Two exchanges are provided:
+                   * HaloPlan (default when cells are sharded in embedding order): neighbours are near in the
+                     embedding, so a spatially coherent shard needs only a HALO of remote rows; each rank sends
+                     exactly the rows another rank's neighbour lists reference - one all_to_all_single with
+                     uneven splits per pass (xGMI is point-to-point: every pair of GPUs has its own link, an
+                     all-to-all keeps all 7 links busy with 1/10th of the all-gather volume);
+                   * all_gather_rows: the whole matrix to everybody, ONE collective on the full shard
+                     (largest possible message; xGMI rings are per-link bound).
+                 Then the all-gather of the compact correlation rows (C x nrndm) for whoever wants them whole.
 """
 from __future__ import annotations
 
@@ -83,3 +88,62 @@ def all_gather_rows(local: torch.Tensor, n_total: int, out: Optional[torch.Tenso
     for (a, b), p in zip(bounds, pieces):
         out[a:b] = p[: b - a]
     return out
+
+
+class HaloPlan:
+    """Exchange of exactly the remote rows a rank needs (built once per neighbour graph, reused every pass).
+
+    `need` is this rank's boolean mask over all n_total rows (rows its local work references).  All masks are
+    all-gathered once; from them both sides of every (src -> dst) transfer derive the same ascending row list,
+    so no indices travel in the data path.  exchange() packs the rows to send, runs ONE all_to_all_single with
+    uneven splits and scatters what arrives into a full-height buffer at the rows' global positions (so kernels
+    keep indexing rows by global cell id); rows nobody asked for are simply never written."""
+
+    def __init__(self, need: torch.Tensor, n_total: int, group=None):
+        self.rank, self.ws = world()
+        self.n, self.group = int(n_total), group
+        dev = need.device
+        bounds = all_shard_bounds(self.n, self.ws)
+        self.c0, self.c1 = bounds[self.rank]
+        need = need.to(torch.uint8).contiguous()
+        assert need.numel() == self.n
+        if active():
+            masks = torch.empty((self.ws, self.n), dtype=torch.uint8, device=dev)
+            dist.all_gather_into_tensor(masks, need, group=group) if dist.get_backend(group) != "gloo" else \
+                dist.all_gather(list(masks.unbind(0)), need, group=group)
+        else:
+            masks = need[None, :]
+        masks = masks.bool()
+        send_idx, self.send_splits, recv_idx, self.recv_splits = [], [], [], []
+        for peer, (a, b) in enumerate(bounds):
+            if peer == self.rank:
+                self.send_splits.append(0)
+                self.recv_splits.append(0)
+                continue
+            mine_for_peer = torch.nonzero(masks[peer, self.c0:self.c1], as_tuple=False).ravel()          # local row numbers, ascending
+            theirs_for_me = torch.nonzero(masks[self.rank, a:b], as_tuple=False).ravel() + a             # global row numbers, ascending
+            send_idx.append(mine_for_peer)
+            recv_idx.append(theirs_for_me)
+            self.send_splits.append(int(mine_for_peer.numel()))
+            self.recv_splits.append(int(theirs_for_me.numel()))
+        cat = lambda xs: torch.cat(xs) if xs else torch.empty(0, dtype=torch.int64, device=dev)
+        self.send_idx, self.recv_idx = cat(send_idx), cat(recv_idx)
+        self.n_send, self.n_recv = int(self.send_idx.numel()), int(self.recv_idx.numel())
+        self._send = self._recv = None
+
+    def exchange(self, local: torch.Tensor, out_full: torch.Tensor) -> torch.Tensor:
+        """local: (c1-c0, ld) rows this rank owns; out_full: (n_total, ld).  Afterwards out_full holds the
+        rank's own rows and every remote row its mask asked for."""
+        assert local.shape[0] == self.c1 - self.c0 and out_full.shape[0] == self.n and local.shape[1:] == out_full.shape[1:]
+        out_full[self.c0:self.c1].copy_(local)
+        if not active() or self.ws == 1:
+            return out_full
+        tail = tuple(local.shape[1:])
+        if self._send is None or self._send.dtype != local.dtype or tuple(self._send.shape[1:]) != tail:
+            self._send = torch.empty((self.n_send,) + tail, dtype=local.dtype, device=local.device)
+            self._recv = torch.empty((self.n_recv,) + tail, dtype=local.dtype, device=local.device)
+        torch.index_select(local, 0, self.send_idx, out=self._send)
+        dist.all_to_all_single(self._recv, self._send, output_split_sizes=self.recv_splits, input_split_sizes=self.send_splits,
+                               group=self.group)
+        out_full.index_copy_(0, self.recv_idx, self._recv)
+        return out_full
