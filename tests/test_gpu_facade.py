@@ -320,3 +320,36 @@ def test_diffusion_module_api(vcy, golden):
     assert len(traj) == 4
     with pytest.raises(NotImplementedError):
         d.diffuse(g["diffuse_p0"], tr, mode="trajectory")
+
+
+def test_facade_duplicate_cells_nan_policy(vcy, oracle, caplog):
+    """Identical cells give zero-variance correlation columns: NaN in the kernel, fixed up to 1 with a warning in the
+    knn_random branch (analysis.py:1604-1607) and kept (off the diagonal) in the full branch (:1666)."""
+    import logging
+    rng = np.random.default_rng(5)
+    G, C = 60, 50
+    Sx = rng.gamma(2.0, 1.0, (G, C))
+    Sx[:, 1] = Sx[:, 0]                                    # cells 0 and 1 identical after imputation
+    Ux = rng.gamma(1.0, 1.0, (G, C))
+    emb = rng.normal(size=(C, 2))
+    emb[1] = emb[0] + 1e-3                                 # and next to each other: 1 is certainly sampled for 0
+    vlm = vcy.analysis.VelocytoLoom.from_arrays(Sx, Ux, dtype="float64")
+    vlm.Sx_sz, vlm.Ux_sz, vlm.ts = Sx, Ux, emb
+    vlm.gammas, vlm.q = np.full(G, 0.3, np.float32), np.zeros(G, np.float32)
+    vlm.predict_U(); vlm.calculate_velocity(); vlm.calculate_shift(); vlm.extrapolate_cell_at_t()
+    with caplog.at_level(logging.WARNING):
+        vlm.estimate_transition_prob(hidim="Sx_sz", embed="ts", n_neighbors=20, sampled_fraction=1.0, calculate_randomized=False)
+    assert any("Nans encountered" in r.message for r in caplog.records)
+    cc = vlm.corrcoef
+    assert cc[0, 1] == 1.0 and cc[1, 0] == 1.0 and not np.isnan(cc).any() and np.all(np.diag(cc) == 0)
+    ref, _ = oracle.estimate_transition_prob(Sx, vlm.delta_S, emb, n_neighbors=20, sampled_fraction=1.0)
+    np.testing.assert_allclose(cc, ref, atol=1e-9)
+    vlm.estimate_transition_prob(hidim="Sx_sz", embed="ts", n_neighbors=20, knn_random=False, calculate_randomized=False)
+    full = vlm.corrcoef
+    assert np.isnan(full[0, 1]) and np.isnan(full[1, 0]) and np.all(np.diag(full) == 0)
+    with pytest.raises(NotImplementedError):
+        vlm.estimate_transition_prob(hidim="Sx_sz", embed="ts", transform="cube")
+    with pytest.raises(ValueError):
+        vlm.estimate_transition_prob(hidim="Sx_sz", embed="ts", n_sight=5, n_neighbors=6)
+    with pytest.raises(AttributeError):
+        vcy.analysis.VelocytoLoom.from_arrays(Sx, Ux).Sx       # not computed yet
