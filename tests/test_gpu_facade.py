@@ -353,3 +353,50 @@ def test_facade_duplicate_cells_nan_policy(vcy, oracle, caplog):
         vlm.estimate_transition_prob(hidim="Sx_sz", embed="ts", n_sight=5, n_neighbors=6)
     with pytest.raises(AttributeError):
         vcy.analysis.VelocytoLoom.from_arrays(Sx, Ux).Sx       # not computed yet
+
+
+def test_facade_less_travelled_options(vcy, golden, oracle):
+    """normalize("imputed"/size=False/target_size), knn_imputation(pca_space=False), predict_U without offset / on Sx,
+    fit_gammas on raw or non-imputed data, calculate_velocity/extrapolate for which_S="Sx"."""
+    g = golden("pipeline")
+    S, U = g["S"].astype(float), g["U"].astype(float)
+    vlm = vcy.analysis.VelocytoLoom.from_arrays(g["S"], g["U"], dtype="float64")
+    vlm.normalize("both", size=True, log=True, target_size=(1000.0, 500.0), pcount=2)
+    np.testing.assert_allclose(vlm.S_sz, S * (1000.0 / S.sum(0)), rtol=1e-12)
+    np.testing.assert_allclose(vlm.U_sz, U * (500.0 / U.sum(0)), rtol=1e-12)
+    np.testing.assert_allclose(vlm.S_norm, np.log2(vlm.S_sz + 2), rtol=1e-12)
+    vlm.normalize("S", size=False, log=False)
+    np.testing.assert_array_equal(vlm.S_sz, S)
+    vlm.normalize("S")
+    vlm.normalize("U", use_S_size_for_U=True)                # U scaled by the SPLICED cell sizes (analysis.py:556-560)
+    np.testing.assert_allclose(vlm.U_sz, U * (S.sum(0).mean() / S.sum(0)), rtol=1e-12)
+    vlm.normalize("both")
+    # kNN in gene space (pca_space=False): neighbours of S_norm.T rows
+    vlm.knn_imputation(k=8, pca_space=False, n_jobs=1)
+    _, _, Sx_o, Ux_o = oracle.knn_imputation(g["S_sz"], g["U_sz"], g["S_norm"].T, k=8)
+    np.testing.assert_allclose(vlm.Sx, Sx_o, rtol=1e-11, atol=1e-11)
+    # imputed normalisation
+    vlm.normalize("imputed", size=True, log=True)
+    np.testing.assert_allclose(vlm.Sx_sz, vlm.Sx * (vlm.Sx.sum(0).mean() / vlm.Sx.sum(0)), rtol=1e-12)
+    np.testing.assert_allclose(vlm.Ux_norm, np.log2(vlm.Ux_sz + 1), rtol=1e-12)
+    # fits on other data selections
+    vlm.fit_gammas(use_imputed_data=False, fit_offset=False, weighted=False)
+    np.testing.assert_allclose(vlm.gammas, np.nan_to_num(oracle.fit_slope(g["U_sz"], g["S_sz"])), rtol=2e-6)
+    vlm.fit_gammas(use_size_norm=False, fit_offset=False, weighted=False)
+    np.testing.assert_allclose(vlm.gammas, np.nan_to_num(oracle.fit_slope(vlm.Ux, vlm.Sx)), rtol=2e-6)
+    # chain on Sx / without offset
+    vlm.predict_U(which_S="Sx", which_offset=None)
+    np.testing.assert_allclose(vlm.Upred, vlm.gammas[:, None] * vlm.Sx, rtol=1e-12)
+    vlm.calculate_velocity()
+    np.testing.assert_allclose(vlm.velocity, vlm.Ux - vlm.Upred, rtol=1e-12, atol=1e-12)
+    vlm.calculate_shift(delta_t=0.5)
+    vlm.extrapolate_cell_at_t(delta_t=2.0, clip=False)
+    np.testing.assert_allclose(vlm.Sx_t, vlm.Sx + 2.0 * 0.5 * vlm.velocity, rtol=1e-12, atol=1e-12)
+    assert not hasattr(vlm, "used_delta_t")                 # only set when clip=True (reference quirk, analysis.py:1430-1432)
+    with pytest.raises(NotImplementedError):
+        vlm.calculate_velocity(kind="other")
+    with pytest.raises(NotImplementedError):
+        vlm.calculate_shift(assumption="other")
+    vlm.pcs = g["pcs"]
+    with pytest.raises(ValueError):
+        vlm.knn_imputation(k=5, group_constraint=np.zeros(vlm.S.shape[1]))
