@@ -55,3 +55,40 @@ def test_velocytoloom_from_loom_file(loom_io, tmp_path):
     assert vlm.loom_filepath == path and np.array_equal(vlm.S, S) and np.array_equal(vlm.U, U) and vlm.A.sum() == 0
     np.testing.assert_array_equal(vlm.initial_cell_size, S.sum(0))
     assert list(vlm.ca) == ["CellID"] and list(vlm.ra) == ["Gene"]
+
+
+def test_hdf5_flat_dump_load(loom_io, tmp_path):
+    import pickle, zlib
+    rng = np.random.default_rng(2)
+    d = {"Sx": rng.normal(size=(7, 9)), "gammas": rng.random(7).astype(np.float32), "ix": np.arange(5, dtype=np.int64),
+         "flag": np.array([True, False, True]), "scalar": np.float64(3.5),
+         "&ca": np.frombuffer(zlib.compress(pickle.dumps({"CellID": list(range(9))}, protocol=2), 9), dtype=np.uint8)}
+    path = str(tmp_path / "ck.hdf5")
+    loom_io.hdf5_dump(path, d)
+    back = loom_io.hdf5_load(path)
+    assert set(back) == set(d)
+    np.testing.assert_array_equal(back["Sx"], d["Sx"])
+    assert back["gammas"].dtype == np.float32 and back["ix"].dtype == np.int64
+    np.testing.assert_array_equal(back["flag"], [1, 0, 1])
+    assert back["scalar"].shape == (1,) and back["scalar"][0] == 3.5
+    assert pickle.loads(zlib.decompress(back["&ca"].tobytes())) == {"CellID": list(range(9))}
+
+
+@pytest.mark.gpu
+def test_velocytoloom_checkpoint_roundtrip(loom_io, tmp_path):
+    import velocyto_amd
+    from velocyto_amd.analysis import load_velocyto_hdf5
+    rng = np.random.default_rng(3)
+    G, C = 30, 48
+    vlm = velocyto_amd.analysis.VelocytoLoom.from_arrays(rng.poisson(3, (G, C)).astype(np.uint16), rng.poisson(1, (G, C)).astype(np.uint16), dtype="float64")
+    vlm.normalize("both"); vlm.pcs = rng.normal(size=(C, 5)); vlm.knn_imputation(k=5, n_jobs=1); vlm.fit_gammas(fit_offset=False, weighted=False)
+    path = str(tmp_path / "vlm.hdf5")
+    vlm.to_hdf5(path)
+    v2 = load_velocyto_hdf5(path, dtype="float64")
+    for name in ("S", "U", "S_sz", "Sx", "Ux_sz"):
+        np.testing.assert_array_equal(getattr(v2, name), getattr(vlm, name))
+    np.testing.assert_array_equal(v2.gammas, vlm.gammas)
+    assert (v2.knn != vlm.knn).nnz == 0 and list(v2.ca) == list(vlm.ca)
+    v2.predict_U(); v2.calculate_velocity()                      # the restored object keeps working on the device
+    vlm.predict_U(); vlm.calculate_velocity()
+    np.testing.assert_array_equal(v2.velocity, vlm.velocity)

@@ -566,7 +566,24 @@ class VelocytoLoom:
 
     # ------------------------------------------------------------------ bookkeeping kept from the reference
     def to_hdf5(self, filename: str, **kwargs) -> None:
-        raise NotImplementedError("HDF5 checkpointing needs h5py (absent in this image); SURVEY.md section 8f rank 4")
+        """analysis.py:76-94 + serialization.dump_hdf5 (serialization.py:44-92): checkpoint of the whole object.
+        Every ndarray attribute (device matrices are downloaded) becomes a dataset under its name, everything else is
+        pickled (protocol 2) + zlib-compressed into a uint8 dataset called "&name" - the reference's container format
+        (written uncompressed here; `load_velocyto_hdf5` reads both)."""
+        import pickle
+        import zlib
+        from .loom_io import hdf5_dump
+        out = {}
+        for name in self._dev:
+            out[name] = np.ascontiguousarray(getattr(self, name))
+        for name, val in self.__dict__.items():
+            if name.startswith("_") or isinstance(val, torch.Tensor):
+                continue                                              # device-side caches are rebuilt on demand
+            if isinstance(val, np.ndarray) and val.dtype.kind in "fiub":
+                out[name] = val
+            else:
+                out["&" + name] = np.frombuffer(zlib.compress(pickle.dumps(val, protocol=2), 9), dtype=np.uint8)
+        hdf5_dump(filename, out)
 
 
 def _fill_diagonal_zero(m: torch.Tensor) -> None:
@@ -592,3 +609,18 @@ def _permute_rows_nsign(dS: CellMatrix, seed: int) -> CellMatrix:
 def gaussian_kernel(X: np.ndarray, mu: float = 0, sigma: float = 1) -> np.ndarray:
     """analysis.py:2449-2451."""
     return np.exp(-(X - mu)**2 / (2 * sigma**2)) / np.sqrt(2 * np.pi * sigma**2)
+
+
+def load_velocyto_hdf5(filename: str, dtype=None) -> VelocytoLoom:
+    """analysis.py:2454-2470 + serialization.load_hdf5 (serialization.py:95-115): rebuild a VelocytoLoom from a
+    checkpoint written by `to_hdf5` (or by the reference's dump_hdf5: same layout)."""
+    import pickle
+    import zlib
+    from .loom_io import hdf5_load
+    vlm = VelocytoLoom(None, dtype=dtype)
+    for name, arr in hdf5_load(filename).items():
+        if name.startswith("&"):
+            setattr(vlm, name[1:], pickle.loads(zlib.decompress(np.asarray(arr, dtype=np.uint8).tobytes())))
+        else:
+            setattr(vlm, name, arr)
+    return vlm

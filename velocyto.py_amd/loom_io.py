@@ -203,3 +203,54 @@ def write_loom(path: str, layers: Dict[str, np.ndarray], col_attrs: Optional[Dic
             L.H5Gclose(g)
     finally:
         L.H5Fclose(f)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Flat HDF5 dump / load of a dict of arrays: the container format of velocyto/serialization.py:44-115
+# (every ndarray attribute -> a dataset under its name; anything else -> pickle + zlib -> uint8 dataset "&name").
+def hdf5_dump(path: str, arrays: Dict[str, np.ndarray]) -> None:
+    L = _lib()
+    f = _check(L.H5Fcreate(path.encode(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT), f"create {path}")
+    try:
+        for name, arr in arrays.items():
+            arr = np.asarray(arr)
+            if arr.dtype.kind in ("U", "O"):
+                arr = np.char.encode(arr.astype(str), "utf-8")
+            if arr.dtype == np.bool_:
+                arr = arr.astype(np.uint8)
+            arr = np.ascontiguousarray(arr)
+            nd = max(arr.ndim, 1)
+            shape = arr.shape if arr.ndim else (1,)
+            dims = (hsize_t * nd)(*shape)
+            sp = L.H5Screate_simple(nd, dims, None)
+            if arr.dtype.kind == "S":
+                tp = L.H5Tcopy(L._c_s1)
+                L.H5Tset_size(tp, max(arr.dtype.itemsize, 1))
+            elif arr.dtype in _NP2H5:
+                tp = L._native[_NP2H5[arr.dtype]]
+            else:
+                raise TypeError(f"{name}: dtype {arr.dtype} cannot be stored")
+            d = _check(L.H5Dcreate2(f, name.encode(), tp, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT), f"create {name}")
+            if arr.size:
+                _check(L.H5Dwrite(d, tp, H5S_ALL, H5S_ALL, H5P_DEFAULT, arr.ctypes.data), f"write {name}")
+            L.H5Dclose(d)
+            L.H5Sclose(sp)
+            if arr.dtype.kind == "S":
+                L.H5Tclose(tp)
+    finally:
+        L.H5Fclose(f)
+
+
+def hdf5_load(path: str) -> Dict[str, np.ndarray]:
+    if not os.path.exists(path):
+        raise FileNotFoundError(path)
+    L = _lib()
+    f = _check(L.H5Fopen(path.encode(), H5F_ACC_RDONLY, H5P_DEFAULT), f"open {path}")
+    try:
+        g, names = _group_members(L, f, "/")
+        out = {k: _read_dataset(L, f, k) for k in names}
+        if g is not None:
+            L.H5Gclose(g)
+        return out
+    finally:
+        L.H5Fclose(f)
