@@ -36,9 +36,9 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK = 8.0e12   # B/s, MI355X spec (MI355X_MICROARCH.md)
-# profiles/r01c_bench_50kx30k_pmc.csv, k_cdc_partial_grouped<float,SQRT,PARTIAL,8> at the default workload on 1 GPU:
-# 2 * FETCH_SIZE (75 241 084 KiB; gfx950 half-count correction) + WRITE_SIZE (49 999 KiB), in bytes per launch
-PMC_TRAFFIC_DEFAULT = 2 * 75241084.0 * 1024 + 49998.78125 * 1024
+# profiles/r01d_bench_50kx30k_pmc.csv, k_cdc_partial_grouped<float,SQRT,PARTIAL,8> at the default workload on 1 GPU:
+# 2 * FETCH_SIZE (74 062 060 KiB; gfx950 half-count correction) + WRITE_SIZE (49 999 KiB), in bytes per launch
+PMC_TRAFFIC_DEFAULT = 2 * 74062059.625 * 1024 + 49998.6875 * 1024
 
 
 def parse():
@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass; the default workload "
-                         "uses the figure recorded in profiles/r01c_bench_50kx30k_pmc.csv, other workloads report null")
+                         "uses the figure recorded in profiles/r01d_bench_50kx30k_pmc.csv, other workloads report null")
     ap.add_argument("--slab", type=int, default=0, help="gene slab of the pooling kernel (0 = library default)")
     ap.add_argument("--exchange", choices=["halo", "allgather"], default="halo",
                     help="N > 1: how ranks obtain the rows of e = Sx_sz their neighbour lists reference")
@@ -343,7 +343,7 @@ def main():
                          "note": "achieved = ALGORITHMIC bytes (no reuse credited: (nrndm+2)*G*4 + nrndm*8 per cell) / HIP-event "
                                  "launch time. The grouped kernel reads a neighbour row once per 8-cell group (3.5x reuse out of "
                                  "LDS) and adjacent groups share rows in the per-XCD L2, so frac > 1 means it beats the no-reuse HBM "
-                                 "roofline; `traffic` is the PMC-measured L2-miss traffic of the same launch (profiles/r01c_*). The "
+                                 "roofline; `traffic` is the PMC-measured L2-miss traffic of the same launch (profiles/r01d_*). The "
                                  "kernel is VALU/transcendental-bound: 9.9 VALU instr incl. one quarter-rate v_sqrt_f32 per "
                                  "pair-gene, VALU pipes 95 % busy (4 x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)."},
         }

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void k_knn_pool(const T *__restrict__ data, T 
 
 using namespace vcy;
 
+namespace vcy {
 // ---------------------------------------------------------------------------------------------
 // Count-matrix variant.  The loom layers are uint16 molecule counts (velocyto/constants.py:11) and the
 // size-normalised matrices are just  S_sz[c,:] = norm_factor[c] * S[c,:]  (analysis.py:546-549, 573-579), so
@@ -186,6 +187,8 @@ __global__ __launch_bounds__(256) void k_knn_pool_counts(const unsigned short *_
         }
     }
 }
+
+}  // namespace vcy
 
 static int knn_pool_impl(const void *data, void *out, const void *data2, void *out2, const int64_t *indptr, const int32_t *indices,
                          const void *w, const int32_t *order, int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int maximum,
