@@ -229,6 +229,14 @@ def test_facade_randomized_control_is_statistical(vcy, golden):
     assert abs(np.mean(cr[nz])) < abs(np.mean(vlm.corrcoef[nz])) + 0.05        # negative control carries less signal
     vlm.calculate_embedding_shift()
     assert vlm.delta_embedding_random.shape == vlm.delta_embedding.shape and hasattr(vlm, "scaling_rndm")
+    # device-side neighbour sampling (extension): same sampling law, rows are valid subsets of the embedding kNN, no repeats
+    ref_knn = vlm.embedding_knn.copy()
+    vlm.estimate_transition_prob(hidim="Sx_sz", embed="ts", transform="sqrt", n_neighbors=40, knn_random=True, sampled_fraction=0.5,
+                                 calculate_randomized=False, device_sampling=True)
+    s = vlm.sampling_ixs
+    assert s.shape == (vlm.S.shape[1], 20) and all(len(set(r)) == 20 for r in s) and s.max() <= 40
+    assert np.mean(s < 20) > 0.55                                   # nearer neighbours are preferred (p from 0.5 down to 0.1)
+    assert vlm.corrcoef.shape == ref_knn.shape
 
 
 def test_estimation_module_api(vcy, golden):

@@ -436,6 +436,9 @@ class VelocytoLoom:
         """analysis.py:1452-1668."""
         self.which_hidim = hidim
         n_neighbors = kwargs.pop("n_neighbors", None)
+        # extension (not in the reference): draw the neighbour subsample on the device instead of replaying numpy's
+        # legacy RNG stream cell by cell (3 s at 50k cells); same distribution, different random numbers
+        device_sampling = bool(kwargs.pop("device_sampling", False))
         if kwargs:
             logging.warning(f"keyword arguments were passed but could not be interpreted {kwargs}")
         C = self.dev("S").C
@@ -475,8 +478,15 @@ class VelocytoLoom:
             p = np.linspace(sampling_probs[0], sampling_probs[1], neigh_ixs.shape[1])
             p = p / p.sum()
             size = int(sampled_fraction * (n_neighbors + 1))
-            # identical numpy legacy-RNG stream to the reference (:1561-1564)
-            sampling_ixs = np.stack([np.random.choice(neigh_ixs.shape[1], size=(size,), replace=False, p=p) for _ in range(C)], 0)
+            if device_sampling:
+                # weighted sampling without replacement (Efraimidis-Spirakis keys u^(1/p), top `size`) with torch's device RNG
+                gen = torch.Generator(device=hi.t.device).manual_seed(int(random_seed))
+                keys = torch.log(torch.rand((C, neigh_ixs.shape[1]), generator=gen, device=hi.t.device, dtype=torch.float64)) / \
+                    torch.as_tensor(p, device=hi.t.device)[None, :]
+                sampling_ixs = torch.topk(keys, size, dim=1).indices.cpu().numpy()
+            else:
+                # identical numpy legacy-RNG stream to the reference (:1561-1564)
+                sampling_ixs = np.stack([np.random.choice(neigh_ixs.shape[1], size=(size,), replace=False, p=p) for _ in range(C)], 0)
             self.sampling_ixs = sampling_ixs
             neigh_ixs = neigh_ixs[np.arange(C)[:, None], sampling_ixs]
             nonzero = neigh_ixs.shape[0] * neigh_ixs.shape[1]
