@@ -140,6 +140,14 @@ int vcy_knn_search(const float *xt, const double *x64, int32_t *idx, double *dis
                    int64_t C, int64_t P, int64_t ldx, int64_t q0, int64_t Q, int64_t k, int include_self,
                    vcy_stream stream);
 
+/* The same search for EXTERNAL query points (sklearn's NearestNeighbors.fit(points).kneighbors(X), as called by
+ * calculate_grid_arrows analysis.py:1793-1795 and Diffusion.compute_transition_matrix2 diffusion.py:40-41):
+ * qt (P, ldq) feature-major fp32 and q64 (>= q0+Q, P) row-major fp64 coordinates of the queries; for queries
+ * q0..q0+Q-1 the k nearest of the C points, nearest first, ties by index.                                   */
+int vcy_knn_query(const float *xt, const double *x64, const float *qt, const double *q64, int64_t ldq, int32_t *idx,
+                  double *dist, void *workspace, int64_t C, int64_t P, int64_t ldx, int64_t q0, int64_t Q, int64_t k,
+                  vcy_stream stream);
+
 /* neighbors.balance_knn_loop / balance_knn_loop_constrained (neighbors.py:11-140): the
  * sequential greedy in-degree-capped selection.  HOST function on HOST pointers (the
  * reference runs it as numba-compiled scalar code; it is O(C * sight) integer work with a
@@ -163,6 +171,11 @@ int vcy_fit_slope(const void *Y, const void *X, float *gamma, void *workspace, i
 int vcy_fit_slope_moments(const void *Y, const void *X, double *moments, void *workspace, int64_t C, int64_t G,
                           int64_t ld, int dtype, vcy_stream stream);
 int vcy_fit_slope_from_moments(const double *moments, float *gamma, int64_t G, vcy_stream stream);
+
+/* Per-gene raw moments over cells, (5, G) fp64 = [sum x, sum y, sum x*x, sum x*y, sum y*y] (x = X, y = Y): the paired row
+ * correlation of filter_genes_by_phase_portrait (analysis.py:1285-1288, 1307).  workspace: vcy_fit_workspace_bytes(G).   */
+int vcy_gene_moments(const void *Y, const void *X, double *moments, void *workspace, int64_t C, int64_t G, int64_t ld,
+                     int dtype, vcy_stream stream);
 
 /* Per-gene order statistics over cells with numpy.percentile's linear interpolation
  * (analysis.py:1183-1218 use np.percentile(M, q, axis=1)).  M: (C, ld) cells-major.

@@ -615,3 +615,88 @@ def diffuse(x, tr, n_steps=10, mode="path_integral"):
         if mode == "path_integral":
             acc = acc + v
     return acc if mode == "path_integral" else v
+
+
+# --------------------------------------------------------------------------- "next" rows
+def knn_query(points, queries, k) -> Tuple[np.ndarray, np.ndarray]:
+    """NearestNeighbors(...).fit(points).kneighbors(queries): exact fp64 brute force, nearest first, ties by index."""
+    X, Qm = _c64(points), _c64(queries)
+    d2 = ((Qm[:, None, :] - X[None, :, :]) ** 2).sum(-1)
+    order = np.lexsort((np.broadcast_to(np.arange(X.shape[0]), d2.shape), d2), axis=1)[:, :k]
+    return np.sqrt(np.take_along_axis(d2, order, 1)), order
+
+
+def _norm_pdf(x, scale):
+    return np.exp(-0.5 * (x / scale) ** 2) / (scale * np.sqrt(2 * np.pi))
+
+
+def calculate_grid_arrows(embedding, delta_embedding, smooth=0.5, steps=(40, 40), n_neighbors=100):
+    """VelocytoLoom.calculate_grid_arrows (analysis.py:1735-1816).  Returns flow_grid, flow, flow_norm,
+    flow_norm_magnitude, total_p_mass."""
+    emb = _c64(embedding)
+    grs = []
+    for i in range(emb.shape[1]):
+        m, M = np.min(emb[:, i]), np.max(emb[:, i])
+        m = m - 0.025 * np.abs(M - m)
+        M = M + 0.025 * np.abs(M - m)            # (sic: uses the already widened m, analysis.py:1785-1786)
+        grs.append(np.linspace(m, M, steps[i]))
+    grid = np.vstack([g.flat for g in np.meshgrid(*grs)]).T
+    dists, neighs = knn_query(emb, grid, n_neighbors)
+    std = np.mean([g[1] - g[0] for g in grs])
+    w = _norm_pdf(dists, smooth * std)
+    mass = w.sum(1)
+    UZ = (np.asarray(delta_embedding)[neighs] * w[:, :, None]).sum(1) / np.maximum(1, mass)[:, None]
+    mag = np.linalg.norm(UZ, axis=1)
+    flow_norm = UZ / np.percentile(mag, 99.5)
+    return grid, UZ, flow_norm, np.linalg.norm(flow_norm, axis=1), mass
+
+
+def _l1_rows(M):
+    s = np.abs(M).sum(1)
+    s[s == 0] = 1.0
+    return M / s[:, None]
+
+
+def compute_transition_matrix2(x0, v, sigma, reverse=False, n_neighbors=20):
+    """Diffusion.compute_transition_matrix2 (diffusion.py:14-53), dense."""
+    x0, v = _c64(x0), _c64(v)
+    x1 = x0 - v if reverse else x0 + v
+    dists, nearest = knn_query(x0, x1, n_neighbors)
+    n = x0.shape[0]
+    tr = np.zeros((n, n))
+    np.add.at(tr, (np.repeat(np.arange(n), n_neighbors), nearest.ravel()), _norm_pdf(dists.ravel(), sigma))
+    return _l1_rows(tr)
+
+
+def compute_transition_matrix(knn_row, knn_col, x, v, epsilon=0.0, reverse=False):
+    """Diffusion.compute_transition_matrix (diffusion.py:55-91), dense (n, n)."""
+    x, v = _c64(x), _c64(v)
+    uv = x[knn_col] - x[knn_row]
+    norms = np.linalg.norm(uv, axis=1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        uv = uv / norms[:, None]
+        proj = (v[knn_row] * uv).sum(1)
+        if reverse:
+            proj = -proj
+        proj = np.clip(proj + epsilon, 0, None)
+        p = proj * (1 / norms)
+    n = x.shape[0]
+    tr = np.zeros((n, n))
+    np.add.at(tr, (knn_row, knn_col), p)
+    return _l1_rows(tr)
+
+
+def phase_portrait_filter(R2, gammas, Sx_sz, Ux_sz, minR2=0.1, min_gamma=0.01, minCorr=0.1):
+    """The gene mask of VelocytoLoom.filter_genes_by_phase_portrait (analysis.py:1267-1308)."""
+    keep = np.ones(np.asarray(gammas).shape, dtype=bool)
+    if minR2 is not None:
+        keep &= (np.sqrt(np.abs(R2)) * np.sign(R2)) > minR2
+    if min_gamma is not None:
+        keep &= np.asarray(gammas) > min_gamma
+    if minCorr is not None:
+        A, B = _c64(Sx_sz), _c64(Ux_sz)
+        A_m, B_m = A - A.mean(1)[:, None], B - B.mean(1)[:, None]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            corr = (A_m * B_m).sum(1) / (np.linalg.norm(A_m, 2, 1) * np.linalg.norm(B_m, 2, 1))
+        keep &= corr > minCorr
+    return keep

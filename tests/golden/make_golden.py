@@ -299,12 +299,44 @@ def golden_pipeline(ana, dif):
             out[f"tr_{direction}"] = vlm.tr.toarray()
             vlm.run_markov(n_steps=50)
             out[f"diffused_{direction}"] = np.asarray(vlm.diffused).ravel()
+    golden_next(vlm, dif, ana)
     p0 = rng.random(C)
     d = dif.Diffusion()
     out["diffuse_p0"] = p0
     out["diffuse_path_integral"] = np.asarray(d.diffuse(p0, vlm.tr, n_steps=7, mode="path_integral")).ravel()
     out["diffuse_time_evolution"] = np.asarray(d.diffuse(p0, vlm.tr, n_steps=7, mode="time_evolution")).ravel()
     save("pipeline", **out)
+
+
+def golden_next(vlm, dif, ana):
+    """SURVEY.md section 8(f) "next" rows, recorded from the same pipeline state: calculate_grid_arrows, the two
+    Diffusion transition-matrix builders, filter_genes_by_phase_portrait."""
+    from copy import deepcopy
+    out = {}
+    with np.errstate(all="ignore"):
+        vlm.calculate_grid_arrows(smooth=0.8, steps=(12, 10), n_neighbors=30, n_jobs=1)
+    for k in ("flow_grid", "flow", "flow_norm", "flow_norm_magnitude", "total_p_mass"):
+        out[k] = np.asarray(getattr(vlm, k))
+    d = dif.Diffusion()
+    out["embedding"], out["delta_embedding"] = vlm.embedding, vlm.delta_embedding
+    out["tm2_fwd"] = d.compute_transition_matrix2(vlm.embedding, vlm.delta_embedding, sigma=0.7).toarray()
+    out["tm2_rev"] = d.compute_transition_matrix2(vlm.embedding, vlm.delta_embedding, sigma=0.7, reverse=True).toarray()
+    knn = vlm.embedding_knn.tocoo()
+    out["knn_row"], out["knn_col"] = knn.row, knn.col
+    with np.errstate(all="ignore"):
+        out["tm1_fwd"] = d.compute_transition_matrix(vlm.embedding_knn, vlm.embedding, vlm.delta_embedding, epsilon=0.01).toarray()
+        out["tm1_rev"] = d.compute_transition_matrix(vlm.embedding_knn, vlm.embedding, vlm.delta_embedding, epsilon=0.01, reverse=True).toarray()
+    v2 = deepcopy(vlm)
+    v2.ra = {"Gene": np.arange(v2.S.shape[0])}
+    v2.filter_genes_by_phase_portrait(minR2=0.1, min_gamma=0.05, minCorr=0.1)
+    out["filter_kept_genes"] = v2.ra["Gene"]
+    out["filter_Sx_sz"] = np.ascontiguousarray(v2.Sx_sz)
+    out["filter_gammas"] = v2.gammas
+    v3 = deepcopy(vlm)
+    v3.ra = {"Gene": np.arange(v3.S.shape[0])}
+    v3.filter_genes_good_fit(minR=0.2, min_gamma=0.02)
+    out["goodfit_kept_genes"] = v3.ra["Gene"]
+    save("next", **out)
 
 
 if __name__ == "__main__":

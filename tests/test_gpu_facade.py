@@ -408,3 +408,50 @@ def test_facade_less_travelled_options(vcy, golden, oracle):
     vlm.pcs = g["pcs"]
     with pytest.raises(ValueError):
         vlm.knn_imputation(k=5, group_constraint=np.zeros(vlm.S.shape[1]))
+
+
+def test_next_rows_grid_arrows_filters_builders(vcy, golden, oracle):
+    """SURVEY.md section 8(f) rows against the reference's outputs (tests/golden/next.npz)."""
+    g, pl = golden("next"), golden("pipeline")
+    from velocyto_amd import ops
+    # external-query kNN
+    idx, dist = ops.knn_query(g["embedding"], g["flow_grid"], 30)
+    od, oi = oracle.knn_query(g["embedding"], g["flow_grid"], 30)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    np.testing.assert_allclose(dist.cpu().numpy(), od, atol=1e-12)
+    vlm = vcy.analysis.VelocytoLoom.from_arrays(pl["S"], pl["U"], dtype="float64")
+    vlm.embedding, vlm.delta_embedding = g["embedding"], g["delta_embedding"]
+    vlm.calculate_grid_arrows(smooth=0.8, steps=(12, 10), n_neighbors=30)
+    for k in ("flow_grid", "flow", "flow_norm", "flow_norm_magnitude", "total_p_mass"):
+        np.testing.assert_allclose(getattr(vlm, k), g[k], rtol=1e-9, atol=1e-14)
+    with pytest.raises(KeyError):
+        vlm.ts = g["embedding"]; vlm.calculate_grid_arrows(embed="ts")
+    # phase-portrait filters
+    for dtype in ("float64", "float32"):
+        v = vcy.analysis.VelocytoLoom.from_arrays(pl["S"], pl["U"], dtype=dtype)
+        v.normalize("both")
+        v.Sx, v.Ux, v.Sx_sz, v.Ux_sz = pl["Sx"], pl["Ux"], pl["Sx"], pl["Ux"]
+        v.gammas, v.q, v.R2 = pl["gammas"].copy(), pl["q"].copy(), pl["R2"].copy()
+        v.filter_genes_by_phase_portrait(minR2=0.1, min_gamma=0.05, minCorr=0.1)
+        assert np.array_equal(v.ra["Gene"], g["filter_kept_genes"])
+        np.testing.assert_allclose(v.Sx_sz, g["filter_Sx_sz"], rtol=1e-6 if dtype == "float32" else 0)
+        np.testing.assert_array_equal(v.gammas, g["filter_gammas"])
+        assert v.S.shape[0] == len(g["filter_kept_genes"]) and v.S_norm.shape == v.S.shape
+    v = vcy.analysis.VelocytoLoom.from_arrays(pl["S"], pl["U"], dtype="float64")
+    v.gammas, v.q, v.R2 = pl["gammas"].copy(), pl["q"].copy(), pl["R2"].copy()
+    v.filter_genes_good_fit(minR=0.2, min_gamma=0.02)
+    assert np.array_equal(v.ra["Gene"], g["goodfit_kept_genes"])
+    # Diffusion transition-matrix builders
+    d = vcy.diffusion.Diffusion()
+    for rev, key in ((False, "tm2_fwd"), (True, "tm2_rev")):
+        tr = d.compute_transition_matrix2(g["embedding"], g["delta_embedding"], sigma=0.7, reverse=rev).toarray()
+        ref = g[key]
+        np.testing.assert_allclose(tr[:ref.shape[0], :ref.shape[1]], ref, rtol=1e-9, atol=1e-15)
+    from scipy import sparse
+    knn = sparse.coo_matrix((np.ones(len(g["knn_row"])), (g["knn_row"], g["knn_col"])))
+    for rev, key in ((False, "tm1_fwd"), (True, "tm1_rev")):
+        with np.errstate(all="ignore"):
+            tr = d.compute_transition_matrix(knn, g["embedding"], g["delta_embedding"], epsilon=0.01, reverse=rev).toarray()
+        ref = g[key]
+        assert tr.shape == ref.shape
+        np.testing.assert_allclose(np.nan_to_num(tr), np.nan_to_num(ref), rtol=1e-9, atol=1e-14)

@@ -260,3 +260,36 @@ def test_pipeline_embedding_shift_and_markov(oracle, golden):
     tr = g["tr_backwards"]
     np.testing.assert_allclose(oracle.diffuse(g["diffuse_p0"], tr, 7, "path_integral").ravel(), g["diffuse_path_integral"], rtol=1e-10)
     np.testing.assert_allclose(oracle.diffuse(g["diffuse_p0"], tr, 7, "time_evolution").ravel(), g["diffuse_time_evolution"], rtol=1e-10)
+
+
+# ----------------------------------------------------------------------------- "next" rows
+def test_next_grid_arrows(oracle, golden):
+    g = golden("next")
+    grid, flow, flow_norm, mag, mass = oracle.calculate_grid_arrows(g["embedding"], g["delta_embedding"], smooth=0.8, steps=(12, 10), n_neighbors=30)
+    np.testing.assert_allclose(grid, g["flow_grid"], rtol=1e-13)
+    np.testing.assert_allclose(mass, g["total_p_mass"], rtol=1e-10)
+    np.testing.assert_allclose(flow, g["flow"], rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(flow_norm, g["flow_norm"], rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(mag, g["flow_norm_magnitude"], rtol=1e-9, atol=1e-14)
+
+
+def test_next_diffusion_builders(oracle, golden):
+    g = golden("next")
+    for rev, key in ((False, "tm2_fwd"), (True, "tm2_rev")):
+        tr = oracle.compute_transition_matrix2(g["embedding"], g["delta_embedding"], 0.7, reverse=rev)
+        ref = g[key]
+        np.testing.assert_allclose(tr[:ref.shape[0], :ref.shape[1]], ref, rtol=1e-9, atol=1e-15)
+    for rev, key in ((False, "tm1_fwd"), (True, "tm1_rev")):
+        with np.errstate(all="ignore"):
+            tr = oracle.compute_transition_matrix(g["knn_row"], g["knn_col"], g["embedding"], g["delta_embedding"], 0.01, reverse=rev)
+        ref = g[key]
+        nan_equal_close(tr[:ref.shape[0], :ref.shape[1]], ref, atol=1e-14, rtol=1e-9)
+
+
+def test_next_phase_portrait_filter(oracle, golden):
+    g, p = golden("next"), golden("pipeline")
+    keep = oracle.phase_portrait_filter(p["R2"], p["gammas"], p["Sx"], p["Ux"], minR2=0.1, min_gamma=0.05, minCorr=0.1)
+    assert np.array_equal(np.nonzero(keep)[0], g["filter_kept_genes"])
+    np.testing.assert_array_equal(p["Sx"][keep], g["filter_Sx_sz"])
+    keep2 = oracle.phase_portrait_filter(p["R2"], p["gammas"], p["Sx"], p["Ux"], minR2=0.2, min_gamma=0.02, minCorr=None)
+    assert np.array_equal(np.nonzero(keep2)[0], g["goodfit_kept_genes"])

@@ -39,11 +39,13 @@ SIGNATURES = {
                                     c_int, c_i64, c_int, c_vp]),
     "vcy_knn_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "vcy_knn_search": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_vp]),
+    "vcy_knn_query": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp]),
     "vcy_balance_knn_host": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp]),
     "vcy_fit_workspace_bytes": (c_sz, [c_i64]),
     "vcy_fit_slope": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]),
     "vcy_fit_slope_moments": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]),
     "vcy_fit_slope_from_moments": (c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "vcy_gene_moments": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]),
     "vcy_quantile_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "vcy_gene_quantiles": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, ctypes.POINTER(c_dbl), c_int, c_vp, c_vp, c_i64,
                                    c_i64, c_i64, c_int, c_vp]),

@@ -552,6 +552,72 @@ class VelocytoLoom:
             if sc is not None:
                 self.scaling_rndm = sc.cpu().numpy()
 
+    # ------------------------------------------------------------------ consumers of the path ("next" rows)
+    def calculate_grid_arrows(self, embed: str = "embedding", smooth: float = 0.5, steps: Tuple = (40, 40), n_neighbors: int = 100,
+                              n_jobs: int = 4) -> None:
+        """analysis.py:1735-1816: Gaussian-kernel average of delta_embedding on a regular grid.  The neighbour search
+        of the grid points among the cells runs on the device (vcy_knn_query); the (grid x n_neighbors) weighting that
+        follows is a few hundred KB and stays in NumPy like the reference."""
+        embedding = np.asarray(getattr(self, embed), dtype=np.float64)
+        if not hasattr(self, f"delta_{embed}"):
+            raise KeyError("This embedding does not have a delta_*")
+        delta_embedding = np.asarray(getattr(self, f"delta_{embed}"))
+        grs = []
+        for dim_i in range(embedding.shape[1]):
+            m, M = np.min(embedding[:, dim_i]), np.max(embedding[:, dim_i])
+            m = m - 0.025 * np.abs(M - m)
+            M = M + 0.025 * np.abs(M - m)                      # (uses the widened m, as the reference does)
+            grs.append(np.linspace(m, M, steps[dim_i]))
+        gridpoints_coordinates = np.vstack([i.flat for i in np.meshgrid(*grs)]).T
+        neighs, dists = ops.knn_query(embedding, gridpoints_coordinates, n_neighbors)
+        neighs, dists = neighs.cpu().numpy().astype(np.int64), dists.cpu().numpy()
+        std = np.mean([(g[1] - g[0]) for g in grs])
+        scale = smooth * std
+        gaussian_w = np.exp(-0.5 * (dists / scale) ** 2) / (scale * np.sqrt(2 * np.pi))     # scipy.stats.norm.pdf
+        self.total_p_mass = gaussian_w.sum(1)
+        UZ = (delta_embedding[neighs] * gaussian_w[:, :, None]).sum(1) / np.maximum(1, self.total_p_mass)[:, None]
+        magnitude = np.linalg.norm(UZ, axis=1)
+        self.flow_embedding = embedding
+        self.flow_grid = gridpoints_coordinates
+        self.flow = UZ
+        self.flow_norm = UZ / np.percentile(magnitude, 99.5)
+        self.flow_norm_magnitude = np.linalg.norm(self.flow_norm, axis=1)
+        if "_corr_random" in self.__dict__ and hasattr(self, f"delta_{embed}_random"):
+            UZ_rndm = (np.asarray(getattr(self, f"delta_{embed}_random"))[neighs] * gaussian_w[:, :, None]).sum(1) / np.maximum(1, self.total_p_mass)[:, None]
+            magnitude_rndm = np.linalg.norm(UZ, axis=1)        # (sic: the reference scales the control by the real magnitudes, :1812)
+            self.flow_rndm = UZ_rndm
+            self.flow_norm_rndm = UZ_rndm / np.percentile(magnitude_rndm, 99.5)
+            self.flow_norm_magnitude_rndm = np.linalg.norm(self.flow_norm_rndm, axis=1)
+
+    def filter_genes_good_fit(self, minR: float = 0.1, min_gamma: float = 0.01) -> None:
+        """analysis.py:1262-1265."""
+        return self.filter_genes_by_phase_portrait(minR2=minR, min_gamma=min_gamma, minCorr=None)
+
+    def filter_genes_by_phase_portrait(self, minR2: float = 0.1, min_gamma: float = 0.01, minCorr: float = 0.1) -> None:
+        """analysis.py:1267-1319: drop genes with a poor fit (R2), a small gamma or a weak spliced/unspliced correlation
+        (per-gene Pearson r from one moments pass on the device); every gene-indexed attribute is subset."""
+        keep = np.ones(self.gammas.shape, dtype=bool)
+        if minR2 is not None:
+            keep &= (np.sqrt(np.abs(self.R2)) * np.sign(self.R2)) > minR2
+        if min_gamma is not None:
+            keep &= self.gammas > min_gamma
+        if minCorr is not None:
+            mom = ops.gene_moments(self.dev("Ux_sz"), self.dev("Sx_sz"))        # x = Sx_sz, y = Ux_sz
+            n = float(self.dev("Sx_sz").C)
+            sx, sy, sxx, sxy, syy = mom
+            corr = ((sxy - sx * sy / n) / torch.sqrt((sxx - sx * sx / n) * (syy - sy * sy / n))).cpu().numpy()
+            with np.errstate(invalid="ignore"):
+                keep &= corr > minCorr
+        self.ra = {k: v[keep] for k, v in self.ra.items()}
+        kd = torch.from_numpy(keep)
+        for name in ("U", "U_sz", "U_norm", "Ux", "Ux_sz", "Ux_norm", "S", "S_sz", "S_norm", "Sx", "Sx_sz", "Sx_norm"):
+            if name in self._dev:
+                self._set_dev(name, ops.select_genes(self._dev[name], kd))
+        self.__dict__.get("_counts", {}).clear()                     # count-layer fast path no longer matches the gene set
+        for name in ("gammas", "q", "R2"):
+            if hasattr(self, name):
+                setattr(self, name, getattr(self, name)[keep])
+
     # ------------------------------------------------------------------ stage F
     def prepare_markov(self, sigma_D: np.ndarray, sigma_W: np.ndarray, direction: str = "forward", cells_ixs: np.ndarray = None) -> None:
         """analysis.py:1818-1863 (cells_ixs=None)."""

@@ -455,6 +455,38 @@ extern "C" int vcy_fit_weighted(const void *Y, const void *X, int weight_mode, c
     return VCY_OK;
 }
 
+// (5, G) fp64 per-gene raw moments over cells [sum x, sum y, sum xx, sum xy, sum yy]: the ingredients of the paired
+// row correlation of filter_genes_by_phase_portrait (analysis.py:1285-1288) and of any unweighted per-gene fit.
+__global__ void k_gene_moments_reduce(const double *__restrict__ part, double *__restrict__ mom, int G)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    for (int k = 0; k < 5; ++k) {
+        double s = 0.0;
+        for (int cb = 0; cb < FIT_CB; ++cb) s += part[((int64_t)cb * FIT_NMOM + k) * G + g];
+        mom[(int64_t)k * G + g] = s;
+    }
+}
+
+extern "C" int vcy_gene_moments(const void *Y, const void *X, double *moments, void *workspace, int64_t C, int64_t G, int64_t ld,
+                                int dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(Y && X && moments && workspace && C > 0 && G > 0 && ld >= G, "gene_moments: bad arguments");
+    VCY_REQUIRE(dtype == VCY_F32 || dtype == VCY_F64, "gene_moments: bad dtype");
+    hipStream_t st = as_stream(stream);
+    dim3 grid((unsigned)((G + 255) / 256), FIT_CB);
+    if (dtype == VCY_F32)
+        hipLaunchKernelGGL((k_moments_weighted<float, 2>), grid, dim3(256), 0, st, (const float *)Y, (const float *)X, (const float *)nullptr, (const float *)nullptr,
+                           (const float *)nullptr, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (double *)workspace, (int)C, (int)G, ld);
+    else
+        hipLaunchKernelGGL((k_moments_weighted<double, 2>), grid, dim3(256), 0, st, (const double *)Y, (const double *)X, (const double *)nullptr, (const double *)nullptr,
+                           (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (double *)workspace, (int)C, (int)G, ld);
+    VCY_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_gene_moments_reduce, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, (const double *)workspace, moments, (int)G);
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}
+
 extern "C" size_t vcy_quantile_workspace_bytes(int64_t C, int64_t G) { return (size_t)C * (size_t)G * sizeof(double); }
 
 extern "C" int vcy_gene_quantiles(const void *M, const void *M2, const double *scale_a, const double *scale_b, const void *mask_src,

@@ -40,10 +40,15 @@ __device__ __forceinline__ uint32_t f32_key(float f)
 // LARGE = false: candidate arrays (fp64 distance, index)[nsort] live in LDS (k <= ~4k);
 // LARGE = true : they live in a per-workgroup slice of the global workspace (any k < C), same code.
 template <bool LARGE>
-__global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt, const double *__restrict__ x64, int32_t *__restrict__ idx_out,
+__global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt, const double *__restrict__ x64, const float *__restrict__ qt,
+                                                     const double *__restrict__ q64, int64_t ldq, int32_t *__restrict__ idx_out,
                                                      double *__restrict__ dist_out, float *__restrict__ ws, char *__restrict__ ws_sort, int C, int P,
                                                      int64_t ldx, int64_t q0, int Q, int k, int ksel, int nsort, int include_self)
 {
+    // qt/q64 == NULL: the queries are rows q0.. of the point set itself (kneighbors / kneighbors_graph of the fitted
+    // data); otherwise qt (P, ldq) / q64 (Q_total, P) hold EXTERNAL query points (NearestNeighbors.kneighbors(X)) and
+    // no candidate is excluded.
+    const bool external = qt != nullptr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *sd;
     int *si;
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
 
     for (int t = tid; t < KNN_QB * P; t += 256) {
         const int qq = t / P, p = t - qq * P;
-        xq[t] = qq < nq ? xt[(int64_t)p * ldx + q0 + qb0 + qq] : 0.f;
+        xq[t] = qq < nq ? (external ? qt[(int64_t)p * ldq + q0 + qb0 + qq] : xt[(int64_t)p * ldx + q0 + qb0 + qq]) : 0.f;
     }
     __syncthreads();
     // ---- phase 1: distances
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
                 for (int qq = 0; qq < KNN_QB; ++qq) {
                     if (qq < nq) {
                         float v = acc[c][qq];
-                        if (!include_self && (int64_t)jc == q0 + qb0 + qq) v = INFINITY;   // query excluded (kneighbors_graph(X=None))
+                        if (!include_self && !external && (int64_t)jc == q0 + qb0 + qq) v = INFINITY;   // query excluded (kneighbors_graph(X=None))
                         wrow[(int64_t)qq * C + jc] = v;
                         if (v < m1[qq]) {
                             if (v < m0[qq]) { m1[qq] = m0[qq]; m0[qq] = v; }
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
         for (int t = tid; t < ncand; t += 256) {
             const int j = si[t];
             double d2 = 0.0;
-            const double *a = x64 + qcell * P, *b = x64 + (int64_t)j * P;
+            const double *a = (external ? q64 : x64) + qcell * P, *b = x64 + (int64_t)j * P;
             for (int p = 0; p < P; ++p) { const double df = a[p] - b[p]; d2 = fma(df, df, d2); }
             sd[t] = d2;
         }
@@ -263,11 +268,12 @@ extern "C" size_t vcy_knn_workspace_bytes(int64_t C, int64_t Q, int64_t k)
     return bytes;
 }
 
-extern "C" int vcy_knn_search(const float *xt, const double *x64, int32_t *idx, double *dist, void *workspace, int64_t C, int64_t P,
-                              int64_t ldx, int64_t q0, int64_t Q, int64_t k, int include_self, vcy_stream stream)
+static int knn_search_impl(const float *xt, const double *x64, const float *qt, const double *q64, int64_t ldq, int32_t *idx, double *dist,
+                           void *workspace, int64_t C, int64_t P, int64_t ldx, int64_t q0, int64_t Q, int64_t k, int include_self,
+                           vcy_stream stream)
 {
     VCY_REQUIRE(xt && x64 && idx && dist && workspace, "knn_search: null pointer");
-    VCY_REQUIRE(C > 1 && P > 0 && ldx >= C && Q > 0 && q0 >= 0 && q0 + Q <= C, "knn_search: bad shape");
+    VCY_REQUIRE(C > 1 && P > 0 && ldx >= C && Q > 0 && q0 >= 0 && (qt != nullptr || q0 + Q <= C), "knn_search: bad shape");
     const int64_t avail = include_self ? C : C - 1;
     VCY_REQUIRE(k > 0 && k <= avail, "knn_search: k exceeds the number of candidates");
     int64_t ksel; int nsort; bool large;
@@ -279,15 +285,28 @@ extern "C" int vcy_knn_search(const float *xt, const double *x64, int32_t *idx, 
     VCY_REQUIRE(lds <= 150 * 1024, "knn_search: feature dimension too large for LDS");
     if (large) {
         VCY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_knn_search<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_knn_search<true>, dim3(blocks), dim3(256), lds, as_stream(stream), xt, x64, idx, dist, (float *)workspace, ws_sort, (int)C,
+        hipLaunchKernelGGL(k_knn_search<true>, dim3(blocks), dim3(256), lds, as_stream(stream), xt, x64, qt, q64, ldq, idx, dist, (float *)workspace, ws_sort, (int)C,
                            (int)P, ldx, q0, (int)Q, (int)k, (int)ksel, nsort, include_self);
     } else {
         VCY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_knn_search<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_knn_search<false>, dim3(blocks), dim3(256), lds, as_stream(stream), xt, x64, idx, dist, (float *)workspace, ws_sort, (int)C,
+        hipLaunchKernelGGL(k_knn_search<false>, dim3(blocks), dim3(256), lds, as_stream(stream), xt, x64, qt, q64, ldq, idx, dist, (float *)workspace, ws_sort, (int)C,
                            (int)P, ldx, q0, (int)Q, (int)k, (int)ksel, nsort, include_self);
     }
     VCY_LAUNCH_CHECK();
     return VCY_OK;
+}
+
+extern "C" int vcy_knn_search(const float *xt, const double *x64, int32_t *idx, double *dist, void *workspace, int64_t C, int64_t P,
+                              int64_t ldx, int64_t q0, int64_t Q, int64_t k, int include_self, vcy_stream stream)
+{
+    return knn_search_impl(xt, x64, nullptr, nullptr, 0, idx, dist, workspace, C, P, ldx, q0, Q, k, include_self, stream);
+}
+
+extern "C" int vcy_knn_query(const float *xt, const double *x64, const float *qt, const double *q64, int64_t ldq, int32_t *idx, double *dist,
+                             void *workspace, int64_t C, int64_t P, int64_t ldx, int64_t q0, int64_t Q, int64_t k, vcy_stream stream)
+{
+    VCY_REQUIRE(qt && q64 && ldq >= q0 + Q, "knn_query: bad query arguments");
+    return knn_search_impl(xt, x64, qt, q64, ldq, idx, dist, workspace, C, P, ldx, q0, Q, k, /*include_self*/ 1, stream);
 }
 
 // Sequential greedy balancing (neighbors.py:47-69 / 113-137): for each cell `el` in the given

@@ -351,6 +351,31 @@ def knn_search(space, k: int, include_self: bool = False, q0: int = 0, Q: Option
     return idx, dist
 
 
+def knn_query(points, queries, k: int, query_block: int = 8192) -> Tuple[torch.Tensor, torch.Tensor]:
+    """k nearest of `points` (C, P) for every row of `queries` (Q, P): (idx int32 (Q,k), dist float64 (Q,k))."""
+    dev = require_gpu()
+    to64 = lambda a: (torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)) if not isinstance(a, torch.Tensor) else a.double()).to(dev).contiguous()
+    x64, q64 = to64(points), to64(queries)
+    C, P = x64.shape
+    Q = q64.shape[0]
+    assert q64.shape[1] == P and 0 < k <= C
+    ldx, ldq = (C + 63) // 64 * 64, (Q + 63) // 64 * 64
+    xt = torch.zeros((P, ldx), dtype=torch.float32, device=dev)
+    xt[:, :C] = x64.t().float()
+    qt = torch.zeros((P, ldq), dtype=torch.float32, device=dev)
+    qt[:, :Q] = q64.t().float()
+    idx = torch.empty((Q, k), dtype=torch.int32, device=dev)
+    dist = torch.empty((Q, k), dtype=torch.float64, device=dev)
+    L = _lib.lib()
+    qb = min(Q, query_block)
+    ws = torch.empty(int(L.vcy_knn_workspace_bytes(C, qb, k)), dtype=torch.uint8, device=dev)
+    for s in range(0, Q, qb):
+        n = min(qb, Q - s)
+        _lib.check(L.vcy_knn_query(xt.data_ptr(), x64.data_ptr(), qt.data_ptr(), q64.data_ptr(), ldq, idx[s:s + n].data_ptr(),
+                                   dist[s:s + n].data_ptr(), ws.data_ptr(), C, P, ldx, s, n, k, _stream()), "knn_query")
+    return idx, dist
+
+
 def balance_knn_host(dsi: np.ndarray, dist: Optional[np.ndarray], lsi: np.ndarray, groups: Optional[np.ndarray], maxl: int, k: int
                      ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """Host greedy balancing loop (neighbors.py:11-140) in C++ (vcy_balance_knn_host)."""
@@ -408,6 +433,23 @@ def fit_slope_from_moments(mom: torch.Tensor) -> torch.Tensor:
     gamma = torch.empty(G, dtype=torch.float32, device=mom.device)
     _lib.check(_lib.lib().vcy_fit_slope_from_moments(mom.contiguous().data_ptr(), gamma.data_ptr(), G, _stream()), "fit_slope_from_moments")
     return gamma
+
+
+def gene_moments(Y: CellMatrix, X: CellMatrix) -> torch.Tensor:
+    """(5, G) fp64 [sum x, sum y, sum xx, sum xy, sum yy] per gene over cells."""
+    assert Y.t.shape == X.t.shape and Y.dtype == X.dtype
+    mom = torch.empty((5, Y.G), dtype=torch.float64, device=Y.t.device)
+    ws = _fit_workspace(Y.G, Y.t.device)
+    _lib.check(_lib.lib().vcy_gene_moments(Y.t.data_ptr(), X.t.data_ptr(), mom.data_ptr(), ws.data_ptr(), Y.C, Y.G, Y.ld, Y.code, _stream()), "gene_moments")
+    return mom
+
+
+def select_genes(M: CellMatrix, keep: torch.Tensor) -> CellMatrix:
+    """Gene (column) subset of a cells-major matrix, re-padded (index plumbing)."""
+    idx = torch.nonzero(keep.to(M.t.device), as_tuple=False).ravel()
+    out = CellMatrix(torch.zeros((M.C, padded_ld(int(idx.numel()))), dtype=M.dtype, device=M.t.device), int(idx.numel()))
+    out.t[:, : idx.numel()] = M.t.index_select(1, idx)
+    return out
 
 
 def gene_quantiles(M: CellMatrix, qs: Sequence[float], M2: Optional[CellMatrix] = None, scale_a: Optional[torch.Tensor] = None,
