@@ -12,7 +12,10 @@
 // HBM roofline: a (c, i) pair must read neighbour i's G elements; e[c], d[c] are read once
 // per cell and parked in LDS.  Algorithmic bytes per cell = (nrndm + 2) * G * sizeof(T)
 // + nrndm * (4 + sizeof(T)).  ~14 VALU lane-ops + 1 transcendental per 4 B loaded keeps the
-// VALU at ~1/3 of its rate when HBM runs at 6 TB/s, so the kernel is HBM-bound by design.
+// VALU at ~1/3 of its rate when HBM runs at 6 TB/s, so the one-cell-per-workgroup kernel
+// (k_cdc_partial) is HBM-bound by design; the grouped kernel (k_cdc_partial_grouped) shares
+// neighbour rows among 8 adjacent cells out of LDS, cuts the HBM-side traffic 10x and is
+// VALU/transcendental-bound instead.
 #include <stdlib.h>
 #include "common.h"
 
