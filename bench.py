@@ -9,7 +9,7 @@ dataset, inputs (count layers + size factors, pcs, sampled embedding neighbours)
   A  knn_imputation : exact kNN search in pcs + connectivity weights + pooling of S_sz and U_sz (gathered from the
                       resident uint16 count layers and per-cell size factors: S_sz = factor * counts)
   B  fit_slope      : per-gene gamma = max(0, <Sx,Ux>/<Sx,Sx>)
-  C  velocity chain : predict_U -> velocity -> delta_S -> signed-sqrt dmat (fused)
+  C  velocity chain : predict_U -> velocity -> delta_S -> signed-sqrt dmat (one fused pass; by default folded into D's staging)
   D  colDeltaCorSqrtpartial on the sampled embedding neighbours (the dominant kernel)
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): cells are sharded, total work
@@ -58,6 +58,8 @@ def parse():
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass; the default workload "
                          "uses the figure recorded in profiles/r01d_bench_50kx30k_pmc.csv, other workloads report null")
     ap.add_argument("--slab", type=int, default=0, help="gene slab of the pooling kernel (0 = library default)")
+    ap.add_argument("--no-fuse", dest="fuse", action="store_false",
+                    help="materialise dmat with k_velocity_chain instead of folding the velocity chain into stage D")
     ap.add_argument("--exchange", choices=["halo", "allgather"], default="halo",
                     help="N > 1: how ranks obtain the rows of e = Sx_sz their neighbour lists reference")
     ap.add_argument("--order", choices=["natural", "embedding"], default="embedding",
@@ -202,8 +204,11 @@ class Pipeline:
         self.D.all_reduce_sum(mom)
         gamma = ops.fit_slope_from_moments(mom)
         ev[2].record()
-        # ---- C: predict_U -> velocity -> shift -> dmat, fused
-        dmat = ops.velocity_chain(self.Sx_loc, self.Ux_loc, gamma, None, want=("dmat",), transform=ops.SQRT, psc=1e-10)["dmat"]
+        # ---- C: predict_U -> velocity -> shift -> signed-sqrt dmat.  Default: folded into stage D's staging of d[c]
+        #         (vcy_coldeltacor_partial_fused, bit-identical); --no-fuse materialises dmat with k_velocity_chain.
+        dmat = None
+        if not a.fuse:
+            dmat = ops.velocity_chain(self.Sx_loc, self.Ux_loc, gamma, None, want=("dmat",), transform=ops.SQRT, psc=1e-10)["dmat"]
         ev[3].record()
         # ---- D: colDeltaCorSqrtpartial; sharded: every rank needs all of e = Sx_sz
         if self.plan is not None:
@@ -211,8 +216,12 @@ class Pipeline:
         elif self.collect:
             self.D.all_gather_rows(self.Sx_loc.t, C, out=self.Sx_full.t)
         ev[4].record()
-        ops.coldeltacor_partial(self.Sx_full, dmat, self.neigh_loc, ops.SQRT, ops.RULES_PARTIAL, 1e-10, cell0=c0,
-                                d_row0=c0, order=self.order, out=self.corr_loc, validate=False)
+        if a.fuse:
+            ops.coldeltacor_partial_fused(self.Sx_full, self.Ux_loc, gamma, None, self.neigh_loc, ops.SQRT, ops.RULES_PARTIAL, 1e-10,
+                                          cell0=c0, u_row0=c0, order=self.order, out=self.corr_loc, validate=False)
+        else:
+            ops.coldeltacor_partial(self.Sx_full, dmat, self.neigh_loc, ops.SQRT, ops.RULES_PARTIAL, 1e-10, cell0=c0,
+                                    d_row0=c0, order=self.order, out=self.corr_loc, validate=False)
         ev[5].record()
         if self.collect:
             self.D.all_gather_rows(self.corr_loc, C, out=self.corr)
@@ -336,6 +345,7 @@ def main():
                                       ", all-gather of correlation rows",
                        "stage_ms": {"A_knn_imputation": stage[0], "B_fit_slope": stage[1], "C_velocity_chain": stage[2],
                                     "D_exchange": stage[3], "D_coldeltacor": stage[4]},
+                       "velocity_chain": "folded into the staging of d[c] in the stage-D kernel" if a.fuse else "k_velocity_chain (dmat materialised)",
                        "cell_order_D": a.order},
             "roofline": {"bound": "hbm", "kernel": "k_cdc_partial_grouped<float, SQRT, PARTIAL, 8>", "achieved": achieved / 1e9,
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,

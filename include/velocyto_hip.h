@@ -80,6 +80,17 @@ int vcy_coldeltacor_partial(const void *e, const void *d, const int32_t *ixs, vo
                             int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int64_t d_row0,
                             int64_t nrndm, int transform, int rules, double psc, int dtype, vcy_stream stream);
 
+/* Stage C folded into stage D: the same correlations with d = the dmat of estimate_transition_prob computed on the fly from
+ * the velocity chain (analysis.py:1346, 1369, 1399, 1538, 1575-1601; constant_velocity assumption),
+ *     dmat = sign(D) f(|D| + psc),  D = (Sx + used_dt * dt_shift * (Ux - (gamma Sx + q))) - Sx,   f as `transform`,
+ * so that neither velocity nor dmat is materialised.  e = Sx_sz (C, ld); Ux_sz holds rows u_row0..; gamma, q (G) float32
+ * (q may be NULL).  Needs the grouped kernel; returns VCY_ERR_UNSUPPORTED otherwise (call vcy_velocity_chain +
+ * vcy_coldeltacor_partial instead).  Results are bit-identical to that two-kernel sequence.                           */
+int vcy_coldeltacor_partial_fused(const void *Sx_sz, const void *Ux_sz, const float *gamma, const float *q, const int32_t *ixs,
+                                  void *out, const int32_t *order, int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out,
+                                  int64_t u_row0, int64_t nrndm, int transform, int rules, double psc, double dt_shift,
+                                  double used_dt, int dtype, vcy_stream stream);
+
 /* speedboosted._colDeltaCor / _colDeltaCorSqrt / _colDeltaCorLog10 (speedboosted.pyx:13-257,
  * 542-572; wrappers estimation.py:11-33, 65-87, 119-141): all pairs.
  * rm is the dense (C_out, ld_rm) row block for cells cell0..cell0+C_out-1, columns 0..C-1;

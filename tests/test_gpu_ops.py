@@ -123,6 +123,34 @@ def test_coldeltacor_partial_vs_oracle(ops, oracle, dtype, G, transform, psc):
     np.testing.assert_allclose(got3[~self_pair[10:31]], got[10:31][~self_pair[10:31]], atol=1e-12 if dtype == "float64" else 2e-5)
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("transform", ["sqrt", "log10", "linear"])
+def test_coldeltacor_partial_fused_equals_two_kernels(ops, dtype, transform):
+    """Velocity chain folded into the correlation kernel == velocity_chain followed by coldeltacor_partial, bit for bit."""
+    rng = np.random.default_rng(17)
+    G, C, nr = 3100, 72, 24
+    Sx = rng.gamma(2.0, 1.0, (G, C)) * (rng.random((G, C)) < 0.7)
+    Ux = rng.gamma(1.0, 1.0, (G, C)) * (rng.random((G, C)) < 0.6)
+    gam = torch.from_numpy(rng.random(G).astype(np.float32))
+    q = torch.from_numpy((0.1 * rng.random(G)).astype(np.float32))
+    ixs = np.stack([rng.choice(C, nr, replace=False) for _ in range(C)])
+    S, U = ops.CellMatrix.from_genes_major(Sx, dtype), ops.CellMatrix.from_genes_major(Ux, dtype)
+    tr = ops.TRANSFORMS[transform]
+    psc = 1e-10 if transform == "sqrt" else (1.0 if transform == "log10" else 0.0)
+    for qq, dts, udt in ((q, 1.0, 1.0), (None, 0.5, 2.0)):
+        dm = ops.velocity_chain(S, U, gam, qq, want=("dmat",), dt_shift=dts, used_dt=udt, transform=tr, psc=psc)["dmat"]
+        ref = ops.coldeltacor_partial(S, dm, ixs, tr, ops.RULES_PARTIAL, psc)
+        got = ops.coldeltacor_partial_fused(S, U, gam, qq, ixs, tr, ops.RULES_PARTIAL, psc, dt_shift=dts, used_dt=udt)
+        assert torch.equal(torch.nan_to_num(got, nan=7.0), torch.nan_to_num(ref, nan=7.0))
+    part = ops.coldeltacor_partial_fused(S, ops.CellMatrix(U.t[16:64].contiguous(), G), gam, None, ixs[16:64], tr, ops.RULES_PARTIAL, psc,
+                                         dt_shift=0.5, used_dt=2.0, cell0=16, u_row0=16)
+    np.testing.assert_allclose(torch.nan_to_num(part, nan=7.0).cpu().numpy(), torch.nan_to_num(got[16:64], nan=7.0).cpu().numpy(),
+                               atol=1e-12 if dtype == "float64" else 2e-5)
+    with pytest.raises(NotImplementedError):                 # too few cells for the grouped kernel: caller uses the two-kernel path
+        ops.coldeltacor_partial_fused(ops.CellMatrix(S.t[:8].contiguous(), G), ops.CellMatrix(U.t[:8].contiguous(), G), gam, None,
+                                      ixs[:8] % 8, tr)
+
+
 def test_coldeltacor_partial_edge_shapes(ops, oracle):
     rng = np.random.default_rng(5)
     for G, C, nr in ((1, 2, 1), (5, 3, 2), (63, 7, 7), (260, 5, 300)):

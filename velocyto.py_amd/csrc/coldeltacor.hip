@@ -192,11 +192,33 @@ __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, c
 //      over the wave and adds into acc[pair] (owned by that wave: deterministic, no atomics).
 constexpr int GRP_MAX_NV = 6;
 
+// Optional fusion of the velocity chain into the staging of d[c] (stage C folded into stage D): instead of reading
+// a materialised dmat row, the group's members compute it on the fly from Ux, Sx (= e), gamma and q,
+//     dmat = sign(D) f(|D| + psc),  D = (Sx + used_dt * dt_shift * (Ux - (gamma Sx + q))) - Sx
+// (analysis.py:1346, 1369, 1399, 1538, 1575-1601; identical arithmetic to k_velocity_chain), which removes one
+// 6 GB write + read per pass at 50k x 30k.  Ux == nullptr: d is read as given.
+template <typename T> struct FuseArgs {
+    const T *Ux;
+    const float *gamma, *q;
+    T dt_shift, used_dt;
+};
+
+template <typename T, int TR> __device__ __forceinline__ T fused_dmat(T s, T u, float gm, float qq, T dt_shift, T used_dt, T psc)
+{
+    const T upred = (T)gm * s + (T)qq;
+    const T ds = dt_shift * (u - upred);
+    const T D = (s + used_dt * ds) - s;
+    if (TR == VCY_LINEAR) return D;
+    const T a = fabs(D) + psc;
+    const T f = (TR == VCY_SQRT) ? fast_sqrt<T>(a) : fast_log10<T>(a);
+    return D > T(0) ? f : (D < T(0) ? -f : T(0) * f);
+}
+
 template <typename T, int TR, int RULES, int GC>
 __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restrict__ e, const T *__restrict__ d,
                                                                const int32_t *__restrict__ ixs, T *__restrict__ out,
                                                                const int32_t *__restrict__ order, int G, int64_t ld, int64_t cell0,
-                                                               int64_t d_row0, int C_out, int nrndm, int npad, T psc)
+                                                               int64_t d_row0, int C_out, int nrndm, int npad, T psc, FuseArgs<T> fuse)
 {
     using V = typename Vec<T>::type;
     constexpr int N = Vec<T>::N;
@@ -286,12 +308,20 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
         if (tid == 0) *s_next = 0;
         if (sh < snh && sm < gcount) {
             const int64_t c = cell0 + s_cells[sm];
-            const T *er = e + c * ld + g0, *dr = d + (c - d_row0) * ld + g0;
+            const T *er = e + c * ld + g0;
+            const T *dr = (fuse.Ux ? fuse.Ux : d) + (c - d_row0) * ld + g0;     // fused: the member's Ux row
             for (int v = sh * 64 + lane; v < nvec; v += 64 * snh) {
                 V ev = reinterpret_cast<const V *>(er)[v];
                 V dv = reinterpret_cast<const V *>(dr)[v];
                 T *dp = reinterpret_cast<T *>(&dv);
                 T *ep = reinterpret_cast<T *>(&ev);
+                if (fuse.Ux) {
+#pragma unroll
+                    for (int k = 0; k < N; ++k) {
+                        const int g = g0 + v * N + k;
+                        if (g < G) dp[k] = fused_dmat<T, TR>(ep[k], dp[k], fuse.gamma[g], fuse.q ? fuse.q[g] : 0.f, fuse.dt_shift, fuse.used_dt, psc);
+                    }
+                }
                 if (ragged && v == nvec - 1) {
 #pragma unroll
                     for (int k = 0; k < N; ++k) if (k >= gl - v * N) { dp[k] = T(0); ep[k] = T(0); }
@@ -541,7 +571,8 @@ static int g_group_pref = -1;    // -1 auto, 0 never, >0 group size (env VCY_CDC
 
 template <typename T, int TR, int RULES>
 static int launch_partial(const void *e, const void *d, const int32_t *ixs, void *out, const int32_t *order, int64_t G,
-                          int64_t ld, int64_t cell0, int64_t C_out, int64_t d_row0, int64_t nrndm, double psc, hipStream_t st)
+                          int64_t ld, int64_t cell0, int64_t C_out, int64_t d_row0, int64_t nrndm, double psc, hipStream_t st,
+                          FuseArgs<T> fuse = FuseArgs<T>{nullptr, nullptr, nullptr, T(1), T(1)})
 {
     constexpr int N = Vec<T>::N;
     {   // grouped variant: cells adjacent in the schedule order share neighbour rows out of LDS
@@ -557,10 +588,11 @@ static int launch_partial(const void *e, const void *d, const int32_t *ixs, void
             VCY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
             const unsigned groups = (unsigned)(((C_out + GC - 1) / GC + 7) / 8 * 8);
             hipLaunchKernelGGL(kern, dim3(groups), dim3(1024), lds_g, st, (const T *)e, (const T *)d, ixs, (T *)out, order, (int)G, ld, cell0, d_row0,
-                               (int)C_out, (int)nrndm, npad, (T)psc);
+                               (int)C_out, (int)nrndm, npad, (T)psc, fuse);
             VCY_LAUNCH_CHECK();
             return VCY_OK;
         }
+        if (fuse.Ux) return fail(VCY_ERR_UNSUPPORTED, "%s: the fused velocity-chain form needs the grouped kernel (8 <= nrndm, 8*nrndm pairs within the LDS budget, >= 32 cells)", "coldeltacor_partial_fused");
     }
     const int quantum = 64 * N;  // one wave-instruction worth of elements
     const size_t fixed = sizeof(T) * 3 * ((nrndm + 1) & ~1) + 32 * sizeof(double);
@@ -585,10 +617,10 @@ static int launch_partial(const void *e, const void *d, const int32_t *ixs, void
 template <typename T>
 static int dispatch_partial(const void *e, const void *d, const int32_t *ixs, void *out, const int32_t *order, int64_t G,
                             int64_t ld, int64_t cell0, int64_t C_out, int64_t d_row0, int64_t nrndm, int transform, int rules,
-                            double psc, hipStream_t st)
+                            double psc, hipStream_t st, FuseArgs<T> fuse = FuseArgs<T>{nullptr, nullptr, nullptr, T(1), T(1)})
 {
 #define VCY_CASE(TR, RU) \
-    if (transform == TR && rules == RU) return launch_partial<T, TR, RU>(e, d, ixs, out, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st);
+    if (transform == TR && rules == RU) return launch_partial<T, TR, RU>(e, d, ixs, out, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st, fuse);
     VCY_CASE(VCY_LINEAR, VCY_RULES_PARTIAL)
     VCY_CASE(VCY_LINEAR, VCY_RULES_FULL)
     VCY_CASE(VCY_SQRT, VCY_RULES_PARTIAL)
@@ -638,6 +670,27 @@ extern "C" int vcy_coldeltacor_partial(const void *e, const void *d, const int32
     hipStream_t st = as_stream(stream);
     if (dtype == VCY_F32) return dispatch_partial<float>(e, d, ixs, out, order, G, ld, cell0, C_out, d_row0, nrndm, transform, rules, psc, st);
     return dispatch_partial<double>(e, d, ixs, out, order, G, ld, cell0, C_out, d_row0, nrndm, transform, rules, psc, st);
+}
+
+extern "C" int vcy_coldeltacor_partial_fused(const void *Sx_sz, const void *Ux_sz, const float *gamma, const float *q, const int32_t *ixs,
+                                            void *out, const int32_t *order, int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out,
+                                            int64_t u_row0, int64_t nrndm, int transform, int rules, double psc, double dt_shift,
+                                            double used_dt, int dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(Sx_sz && Ux_sz && gamma && ixs && out, "coldeltacor_partial_fused: null pointer");
+    VCY_REQUIRE(C > 0 && G > 0 && nrndm > 0 && C_out > 0 && cell0 >= 0 && cell0 + C_out <= C && ld >= G, "coldeltacor_partial_fused: bad shape");
+    VCY_REQUIRE(u_row0 >= 0 && u_row0 <= cell0, "coldeltacor_partial_fused: Ux must cover cells cell0..cell0+C_out-1");
+    VCY_REQUIRE(dtype == VCY_F32 || dtype == VCY_F64, "coldeltacor_partial_fused: bad dtype");
+    VCY_REQUIRE(ld % (dtype == VCY_F32 ? 4 : 2) == 0, "coldeltacor_partial_fused: ld must keep rows 16-byte aligned");
+    int rc = query_device();
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    if (dtype == VCY_F32) {
+        FuseArgs<float> f{(const float *)Ux_sz, gamma, q, (float)dt_shift, (float)used_dt};
+        return dispatch_partial<float>(Sx_sz, Ux_sz, ixs, out, order, G, ld, cell0, C_out, u_row0, nrndm, transform, rules, psc, st, f);
+    }
+    FuseArgs<double> f{(const double *)Ux_sz, gamma, q, dt_shift, used_dt};
+    return dispatch_partial<double>(Sx_sz, Ux_sz, ixs, out, order, G, ld, cell0, C_out, u_row0, nrndm, transform, rules, psc, st, f);
 }
 
 extern "C" int vcy_coldeltacor_full(const void *e, const void *d, void *rm, int64_t C, int64_t G, int64_t ld, int64_t cell0,

@@ -221,6 +221,31 @@ def coldeltacor_partial(e: CellMatrix, d: CellMatrix, ixs, transform: int, rules
     return out
 
 
+def coldeltacor_partial_fused(Sx: CellMatrix, Ux: CellMatrix, gamma: torch.Tensor, q: Optional[torch.Tensor], ixs, transform: int,
+                              rules: int = RULES_PARTIAL, psc: float = 0.0, dt_shift: float = 1.0, used_dt: float = 1.0, cell0: int = 0,
+                              u_row0: int = 0, order: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                              validate: bool = True) -> torch.Tensor:
+    """Stage C + D in one launch: correlations against the dmat the velocity chain would produce (vcy_coldeltacor_partial_fused).
+    Raises NotImplementedError when the grouped kernel cannot take the request (use velocity_chain + coldeltacor_partial)."""
+    assert Sx.ld == Ux.ld and Sx.dtype == Ux.dtype and Sx.G == Ux.G
+    dev = Sx.t.device
+    ix = _as_i32(ixs, dev)
+    C_out, nrndm = ix.shape
+    assert u_row0 <= cell0 and cell0 + C_out <= u_row0 + Ux.C
+    if validate and ix.numel() and (int(ix.min()) < 0 or int(ix.max()) >= Sx.C):
+        raise ValueError("neighbour index out of range")
+    if out is None:
+        out = torch.empty((C_out, nrndm), dtype=Sx.dtype, device=dev)
+    gamma = gamma.to(device=dev, dtype=torch.float32).contiguous()
+    q = None if q is None else q.to(device=dev, dtype=torch.float32).contiguous()
+    if order is not None:
+        order = order.to(device=dev, dtype=torch.int32).contiguous()
+    _lib.check(_lib.lib().vcy_coldeltacor_partial_fused(Sx.t.data_ptr(), Ux.t.data_ptr(), gamma.data_ptr(), _p(q), ix.data_ptr(), out.data_ptr(),
+                                                        _p(order), Sx.C, Sx.G, Sx.ld, cell0, C_out, u_row0, nrndm, transform, rules, float(psc),
+                                                        float(dt_shift), float(used_dt), Sx.code, _stream()), "coldeltacor_partial_fused")
+    return out
+
+
 def coldeltacor_full(e: CellMatrix, d: CellMatrix, transform: int, psc: float = 0.0, cell0: int = 0,
                      C_out: Optional[int] = None, rm: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
     """Dense correlation rows rm[c, i] for c in [cell0, cell0+C_out), all i."""
