@@ -47,6 +47,22 @@ template <typename T, int TR, int RULES> __device__ __forceinline__ T xform(T t,
     return r;
 }
 
+// f32 fast path of the hot variant (partial sqrt).  Counters put the grouped kernel at ~95 % VALU-busy, so the only lever
+// is issue slots per element; wave64 slots on gfx950: plain f32 op 1, v_sqrt_f32 2, v_pk_*_f32 2 (measured,
+// tools/ubench/valu_rates.hip - packing buys nothing).  The literal rule costs add, sqrt, cmp, bfi, cndmask = 6 slots
+// besides the subtract and the three accumulations; this form costs 5:
+//     c = clamp(|t| * 2^54, 0, 1)      one v_mul with |src| and the clamp output modifier
+//     u = fma(psc, c, |t|)             = |t| + psc (same rounding) when c == 1, 0 when t == 0
+//     A = copysign(sqrt(u), t)         v_sqrt + v_bfi
+// c is exactly 1 for |t| >= 2^-54 (5.6e-17) and exactly 0 for t == 0, so every element the rule of
+// speedboosted.pyx:372-378 can tell apart in practice gets bit-identical values; only 0 < |t| < 1e-16 (unreachable for
+// f32 differences of values above 1e-9) sees a ramp instead of a hard zero.  The f64 parity build keeps the literal rule.
+template <> __device__ __forceinline__ float xform<float, VCY_SQRT, VCY_RULES_PARTIAL>(float t, float psc)
+{
+    const float c = __builtin_amdgcn_fmed3f(fabsf(t) * 0x1p54f, 0.0f, 1.0f);
+    return copysignf(fast_sqrt<float>(fmaf(psc, c, fabsf(t))), t);
+}
+
 template <typename T> __device__ __forceinline__ T pearson_from_moments(double sA, double sAA, double sAb, double sb, double sbb, double n)
 {
     const double cov = sAb - sA * sb / n;
@@ -575,9 +591,9 @@ static int launch_partial(const void *e, const void *d, const int32_t *ixs, void
                           FuseArgs<T> fuse = FuseArgs<T>{nullptr, nullptr, nullptr, T(1), T(1)})
 {
     constexpr int N = Vec<T>::N;
+    if (g_group_pref < 0) { const char *ev = getenv("VCY_CDC_GROUP"); g_group_pref = ev ? atoi(ev) : 8; }
     {   // grouped variant: cells adjacent in the schedule order share neighbour rows out of LDS
         constexpr int GC = 8;
-        if (g_group_pref < 0) { const char *ev = getenv("VCY_CDC_GROUP"); g_group_pref = ev ? atoi(ev) : GC; }
         const int64_t maxpairs = GC * nrndm;
         int npad = 2;
         while (npad < maxpairs) npad <<= 1;
