@@ -188,6 +188,16 @@ int vcy_fit_slope_from_moments(const double *moments, float *gamma, int64_t G, v
 int vcy_gene_moments(const void *Y, const void *X, double *moments, void *workspace, int64_t C, int64_t G, int64_t ld,
                      int dtype, vcy_stream stream);
 
+/* Per-gene statistics over cells for the filters upstream of the path, one streaming pass:
+ * stats (4, G) fp64 = [sum x, sum x*x, count(x > 0), max x] of x = clip(M[c,g] * cell_scale[c], lo[g], hi[g]) over the cells with
+ * cell_mask[c] != 0.  cell_scale (C, fp64), lo/hi (G, fp64; together) and cell_mask (C, uint8) may be NULL.
+ * Replaces the numpy reductions of score_detection_levels (analysis.py:466-474: S.sum(1), (S > 0).sum(1)), score_cv_vs_mean
+ * (analysis.py:260-272: detection, mean, std(ddof=1), np.clip winsorising) and clusters_stats (estimation.py:380-387).
+ * dtype: VCY_F32 / VCY_F64 / VCY_U16 (raw loom counts, ld in elements).  workspace: vcy_gene_stats_workspace_bytes(G).  */
+int64_t vcy_gene_stats_workspace_bytes(int64_t G);
+int vcy_gene_stats(const void *M, const double *cell_scale, const double *lo, const double *hi, const uint8_t *cell_mask,
+                   double *stats, void *workspace, int64_t C, int64_t G, int64_t ld, int dtype, vcy_stream stream);
+
 /* Per-gene order statistics over cells with numpy.percentile's linear interpolation
  * (analysis.py:1183-1218 use np.percentile(M, q, axis=1)).  M: (C, ld) cells-major.
  * qs_host: nq percentiles in [0,100] (host array).  out: (nq, G) fp64.

@@ -700,3 +700,134 @@ def phase_portrait_filter(R2, gammas, Sx_sz, Ux_sz, minR2=0.1, min_gamma=0.01, m
             corr = (A_m * B_m).sum(1) / (np.linalg.norm(A_m, 2, 1) * np.linalg.norm(B_m, 2, 1))
         keep &= corr > minCorr
     return keep
+
+
+# --------------------------------------------------------------------------- callers upstream of the path
+def score_detection_levels(S, U, min_expr_counts=50, min_cells_express=20, min_expr_counts_U=0, min_cells_express_U=0):
+    """VelocytoLoom.score_detection_levels (analysis.py:456-475)."""
+    S, U = np.asarray(S), np.asarray(U)
+    return ((S.sum(1) >= min_expr_counts) & ((S > 0).sum(1) >= min_cells_express) &
+            (U.sum(1) >= min_expr_counts_U) & ((U > 0).sum(1) >= min_cells_express_U))
+
+
+def score_cv_vs_mean(S, N=3000, min_expr_cells=2, max_expr_avg=20, min_expr_avg=0, svr_gamma=None, winsorize=False,
+                     winsor_perc=(1, 99.5), sort_inverse=False):
+    """VelocytoLoom.score_cv_vs_mean for one layer (analysis.py:201-345; SVR = scikit-learn, as in the reference).
+    Returns (score over all genes, selected mask)."""
+    from sklearn.svm import SVR
+    S = _c64(S)
+    if winsorize and min_expr_cells <= ((100 - winsor_perc[1]) * S.shape[1] * 0.01):
+        min_expr_cells = int(np.ceil((100 - winsor_perc[1]) * S.shape[0] * 0.01)) + 2          # :248 (shape[0], sic)
+    detected = ((S > 0).sum(1) > min_expr_cells) & (S.mean(1) < max_expr_avg) & (S.mean(1) > min_expr_avg)
+    Sf = S[detected]
+    if winsorize:
+        down, up = np.percentile(Sf, winsor_perc, 1)
+        Sf = np.clip(Sf, down[:, None], up[:, None])
+    mu, sigma = Sf.mean(1), Sf.std(1, ddof=1)
+    log_m, log_cv = np.log2(mu), np.log2(sigma / mu)
+    clf = SVR(gamma=150. / len(mu) if svr_gamma is None else svr_gamma)
+    clf.fit(log_m[:, None], log_cv)
+    score = log_cv - clf.predict(log_m[:, None])
+    if sort_inverse:
+        score = -score
+    nth = np.sort(score)[::-1][N]
+    full = np.zeros(detected.shape)
+    full[~detected] = np.min(score) - 1e-16
+    full[detected] = score
+    return full, full >= nth
+
+
+def clusters_stats(U, S, cluster_ix, n_clusters, size_limit=40):
+    """estimation.clusters_stats (estimation.py:369-389): per-cluster gene means; small clusters get the overall mean."""
+    U, S = _c64(U), _c64(S)
+    U_avgs, S_avgs = np.zeros((S.shape[0], n_clusters)), np.zeros((S.shape[0], n_clusters))
+    for i in range(n_clusters):
+        f = cluster_ix == i
+        if f.sum() > size_limit:
+            U_avgs[:, i], S_avgs[:, i] = U[:, f].mean(1), S[:, f].mean(1)
+        else:
+            U_avgs[:, i], S_avgs[:, i] = U.mean(1), S.mean(1)
+    return U_avgs, S_avgs
+
+
+def robust_size_factor(S, selected, pc=0.1):
+    """VelocytoLoom.robust_size_factor for one layer (analysis.py:347-439)."""
+    Y = np.log2(_c64(S)[selected] + pc)
+    sf = np.median(2**(Y - Y.mean(1)[:, None]), axis=0)
+    return sf / np.mean(sf)
+
+
+def normalize_by_total(S, U, initial_cell_size, initial_Ucell_size, min_perc_U=0.5, skip_low_U_pop=True, same_size_UnS=False,
+                       size_factor=None):
+    """normalize_by_total (analysis.py:704-758), or normalize_by_size_factor (:760-818) when size_factor is given (the cell
+    sizes then come from the current S / U).  Returns (S_sz, U_sz, small_U_pop)."""
+    S, U = _c64(S), _c64(U)
+    cs, ucs = (initial_cell_size, initial_Ucell_size) if size_factor is None else (S.sum(0), U.sum(0))
+    target = np.median(cs)
+    min_U = np.percentile(ucs, min_perc_U)
+    if min_U < 2:
+        raise ValueError("min_perc_U corresponds to total Unspliced of 1 molecule or less")
+    small = ucs < min_U
+    target_U = target if same_size_UnS else np.median(ucs[~small])
+    S_sz = normalize_size(S, initial_cell_size if size_factor is None else size_factor, target)[0]
+    rel_U = np.clip(initial_Ucell_size, min_U, None) if skip_low_U_pop else initial_Ucell_size
+    U_sz = normalize_size(U, rel_U, target_U, fix_nonfinite=True)[0]
+    return S_sz, U_sz, small
+
+
+def normalize_median_renorm(S_sz, U_sz, small_U_pop, skip_low_U_pop=True):
+    """normalize_median(which="renormalize") (analysis.py:876-882)."""
+    S_sz, U_sz = _c64(S_sz).copy(), _c64(U_sz).copy()
+    S_sz = S_sz * (np.median(S_sz.sum(0)) / S_sz.sum(0))
+    m = ~small_U_pop if skip_low_U_pop else np.ones(U_sz.shape[1], dtype=bool)
+    U_sz[:, m] = U_sz[:, m] * (np.median(U_sz[:, m].sum(0)) / U_sz[:, m].sum(0))
+    return S_sz, U_sz
+
+
+def adjust_totS_totU(S_sz, U_sz, small_U_pop, skip_low_U_pop=True, normalize_total=False, fit_with_low_U=True, svr_C=100, svr_gamma=1e-6):
+    """adjust_totS_totU (analysis.py:820-868)."""
+    from sklearn.svm import SVR
+    S_sz, U_sz = _c64(S_sz).copy(), _c64(U_sz).copy()
+    svr = SVR(C=svr_C, kernel="rbf", gamma=svr_gamma)
+    X, y = S_sz.sum(0), U_sz.sum(0)
+    if fit_with_low_U:
+        svr.fit(X[:, None], y)
+        predicted = svr.predict(X[:, None])
+    else:
+        svr.fit(X[~small_U_pop, None], y[~small_U_pop])
+        predicted = y.copy()
+        predicted[~small_U_pop] = svr.predict(X[~small_U_pop, None])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        adj = predicted / y
+    adj[~np.isfinite(adj)] = 1
+    if skip_low_U_pop:
+        U_sz[:, ~small_U_pop] = U_sz[:, ~small_U_pop] * adj[~small_U_pop]
+    else:
+        U_sz = U_sz * adj
+    if normalize_total:
+        S_sz, U_sz = normalize_median_renorm(S_sz, U_sz, small_U_pop, skip_low_U_pop)
+    return S_sz, U_sz
+
+
+def normalize_median_imputed(Sx, Ux, small_U_pop, skip_low_U_pop=True):
+    """normalize_median(which="imputed") (analysis.py:883-889)."""
+    Sx, Ux = _c64(Sx), _c64(Ux)
+    Sx_sz = Sx * (np.median(Sx.sum(0)) / Sx.sum(0))
+    Ux_sz = Ux.copy()
+    m = ~small_U_pop if skip_low_U_pop else np.ones(Ux.shape[1], dtype=bool)
+    Ux_sz[:, m] = Ux[:, m] * (np.median(Ux[:, m].sum(0)) / Ux[:, m].sum(0))
+    return Sx_sz, Ux_sz
+
+
+def pca(X, n_components=None):
+    """VelocytoLoom.perform_PCA (analysis.py:678-702) = sklearn.decomposition.PCA().fit_transform(X.T) restated: centre the
+    genes, SVD, scikit-learn >= 1.5 sign rule (largest-|.| loading of each component positive).  X: (genes, cells).
+    Returns (pcs (cells, k), components (k, genes), explained_variance_ratio (k,))."""
+    A = _c64(X).T
+    A = A - A.mean(0)
+    Uu, s, Vt = np.linalg.svd(A, full_matrices=False)
+    sign = np.sign(Vt[np.arange(Vt.shape[0]), np.abs(Vt).argmax(1)])
+    Uu, Vt = Uu * sign[None, :], Vt * sign[:, None]
+    k = min(A.shape) if n_components is None else n_components
+    var = s**2 / (A.shape[0] - 1)
+    return (Uu * s)[:, :k], Vt[:k], (var / var.sum())[:k]

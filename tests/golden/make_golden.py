@@ -339,9 +339,108 @@ def golden_next(vlm, dif, ana):
     save("next", **out)
 
 
+def golden_preprocess(ana):
+    """Callers upstream of the hot path (analysis.py:134-533, 678-932, 1889-1964): cell/gene filters, feature scores,
+    size normalisations, PCA and the two deprecated default_* drivers, recorded from the reference on one small dataset."""
+    from copy import deepcopy
+    rng = np.random.default_rng(20180814)
+    G, C = 420, 260
+    S, U, t = synth_counts(rng, G, C)
+    S[:30] = rng.poisson(0.03, (30, C))                      # barely detected genes
+    U[:30] = rng.poisson(0.02, (30, C))
+    S[30:40] = rng.poisson(60.0, (10, C))                    # house-keeping-like (mean above max_expr_avg)
+    labels = np.array(["tiny" if x > 0.93 else "c%d" % int(x * 4) for x in t])
+    colors = {u: [0.1 + 0.15 * i, 0.5, 0.9 - 0.1 * i] for i, u in enumerate(np.unique(labels))}
+    class Snapshots(dict):           # the reference updates some matrices in place (U_sz[:, mask] = ...): record copies
+        def __setitem__(self, k, v):
+            dict.__setitem__(self, k, np.array(v, copy=True))
+    out = Snapshots()
+    out["S"], out["U"], out["labels"] = S, U, labels
+    vlm = make_vlm(ana, S, U)
+    vlm.ca["Clusters"] = labels.copy()
+    vlm.set_clusters(labels, cluster_colors_dict=colors)
+    out["cluster_ix"], out["cluster_uid"], out["colorandum"] = vlm.cluster_ix, vlm.cluster_uid, vlm.colorandum
+    # filter_cells (on a copy)
+    keep_cells = rng.random(C) > 0.15
+    v0 = deepcopy(vlm)
+    v0.ts = rng.random((C, 2))
+    v0.filter_cells(keep_cells)
+    out["keep_cells"] = keep_cells
+    out["fc_S"], out["fc_initial_cell_size"], out["fc_cluster_ix"], out["fc_CellID"] = v0.S, v0.initial_cell_size, v0.cluster_ix, v0.ca["CellID"]
+    # detection levels
+    vlm.score_detection_levels(min_expr_counts=40, min_cells_express=20, min_expr_counts_U=15, min_cells_express_U=10)
+    out["detection_level_selected"] = vlm.detection_level_selected
+    vlm.filter_genes(by_detection_levels=True)
+    out["genes_after_detection"] = vlm.ra["Gene"]
+    # cv vs mean, three variants
+    vlm.score_cv_vs_mean(N=200, max_expr_avg=40)
+    out["cv_mean_score"], out["cv_mean_selected"] = vlm.cv_mean_score, vlm.cv_mean_selected
+    v1 = deepcopy(vlm)
+    v1.score_cv_vs_mean(N=150, max_expr_avg=40, winsorize=True, winsor_perc=(1, 99.5), svr_gamma=0.4)
+    out["cv_mean_score_winsor"], out["cv_mean_selected_winsor"] = v1.cv_mean_score, v1.cv_mean_selected
+    v1.score_cv_vs_mean(N=120, max_expr_avg=40, sort_inverse=True, min_expr_cells=5, min_expr_avg=0.05)
+    out["cv_mean_score_inverse"], out["cv_mean_selected_inverse"] = v1.cv_mean_score, v1.cv_mean_selected
+    vlm.score_cv_vs_mean(N=150, max_expr_avg=30, which="U")
+    out["Ucv_mean_score"], out["Ucv_mean_selected"] = vlm.Ucv_mean_score, vlm.Ucv_mean_selected
+    vlm.score_cluster_expression(min_avg_U=0.02, min_avg_S=0.08)
+    out["U_avgs"], out["S_avgs"], out["clu_avg_selected"] = vlm.U_avgs, vlm.S_avgs, vlm.clu_avg_selected
+    vlm.robust_size_factor(pc=0.1, which="both")
+    out["size_factor"], out["Usize_factor"] = vlm.size_factor, vlm.Usize_factor
+    # custom index-array filter + keep_unfiltered on a copy
+    v2 = deepcopy(vlm)
+    v2.filter_genes(by_custom_array=np.arange(5, 200, 3), keep_unfiltered=True)
+    out["genes_custom_index"] = v2.ra["Gene"]
+    out["S_prefilter_sum"] = np.asarray(v2.S_prefilter.sum())
+    v2.custom_filter_attributes(["cv_mean_score"], np.isin(np.arange(len(v2.cv_mean_score)), np.arange(5, 200, 3)))
+    out["custom_attr_cv_mean_score"] = v2.cv_mean_score
+    vlm.filter_genes(by_cv_vs_mean=True, by_cluster_expression=True)
+    out["genes_after_cv_cluster"] = vlm.ra["Gene"]
+    # normalisations
+    va = deepcopy(vlm)
+    va.normalize_by_total(min_perc_U=0.5)
+    out["nt_small_U_pop"], out["nt_S_sz"], out["nt_U_sz"], out["nt_S_norm"] = va.small_U_pop, va.S_sz, va.U_sz, va.S_norm
+    va.adjust_totS_totU(normalize_total=True)
+    out["adj_S_sz"], out["adj_U_sz"] = va.S_sz, va.U_sz
+    vb = deepcopy(vlm)
+    vb.normalize_by_total(min_perc_U=5, skip_low_U_pop=False, same_size_UnS=True)
+    out["nt2_S_sz"], out["nt2_U_sz"] = vb.S_sz, vb.U_sz
+    vb.adjust_totS_totU(skip_low_U_pop=False, fit_with_low_U=False, normalize_total=False)
+    out["adj2_U_sz"] = vb.U_sz
+    vc = deepcopy(vlm)
+    vc.normalize_by_size_factor(min_perc_U=0.5)
+    out["sf_S_sz"], out["sf_U_sz"] = vc.S_sz, vc.U_sz
+    # PCA + default_fit_preparation's choices
+    va.perform_PCA()
+    out["pcs"], out["explained_variance_ratio"], out["pca_components"] = va.pcs, va.pca.explained_variance_ratio_, va.pca.components_
+    out["pca_mean"], out["pca_explained_variance"] = va.pca.mean_, va.pca.explained_variance_
+    vd = deepcopy(va)
+    vd.perform_PCA(n_components=15)
+    out["pcs15"] = vd.pcs
+    va.knn_imputation(n_pca_dims=8, k=10, balanced=True, b_sight=80, b_maxl=40, n_jobs=1)
+    va.normalize_median()
+    out["nm_Sx_sz"], out["nm_Ux_sz"] = va.Sx_sz, va.Ux_sz
+    ve = deepcopy(va)
+    ve.normalize_median(which="imputed", skip_low_U_pop=False)
+    out["nm2_Ux_sz"] = ve.Ux_sz
+    va.normalize("imputed", size=False, log=True)
+    out["Sx_norm"] = va.Sx_norm
+    va._perform_PCA_imputed(n_components=6)
+    out["pcsx"] = va.pcsx
+    # the deprecated one-call drivers
+    vf = make_vlm(ana, S, U)
+    vf.set_clusters(labels, cluster_colors_dict=colors)
+    vf.default_filter_and_norm(min_expr_counts=30, min_cells_express=15, N=180)
+    out["dfn_genes"], out["dfn_S_sz"], out["dfn_U_sz"] = vf.ra["Gene"], vf.S_sz, vf.U_sz
+    vf.default_fit_preparation(k=12, n_comps=8)
+    out["dfp_Sx_sz"], out["dfp_Ux_sz"], out["dfp_pcs"] = vf.Sx_sz, vf.Ux_sz, vf.pcs
+    out["dfp_n_comps_rule"] = np.asarray(int(np.where(np.diff(np.diff(np.cumsum(vf.pca.explained_variance_ratio_)) > 0.002))[0][0]))
+    save("preprocess", **{k: np.asarray(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     est, nb, dif, ana = load_reference()
     golden_coldeltacor(est)
     golden_fits(est)
     golden_neighbors(nb)
     golden_pipeline(ana, dif)
+    golden_preprocess(ana)

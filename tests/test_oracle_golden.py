@@ -293,3 +293,100 @@ def test_next_phase_portrait_filter(oracle, golden):
     np.testing.assert_array_equal(p["Sx"][keep], g["filter_Sx_sz"])
     keep2 = oracle.phase_portrait_filter(p["R2"], p["gammas"], p["Sx"], p["Ux"], minR2=0.2, min_gamma=0.02, minCorr=None)
     assert np.array_equal(np.nonzero(keep2)[0], g["goodfit_kept_genes"])
+
+
+# --------------------------------------------------------------------------- callers upstream of the path (preprocess.npz)
+@pytest.fixture
+def pre(golden):
+    return golden("preprocess")
+
+
+def _after_detection(pre):
+    S, U = pre["S"].astype(float), pre["U"].astype(float)
+    det = pre["detection_level_selected"]
+    return S[det], U[det]
+
+
+def test_pre_detection_levels(oracle, pre):
+    got = oracle.score_detection_levels(pre["S"].astype(float), pre["U"].astype(float), 40, 20, 15, 10)
+    assert np.array_equal(got, pre["detection_level_selected"])
+    assert np.array_equal(np.flatnonzero(got), pre["genes_after_detection"])
+
+
+def test_pre_cv_vs_mean_variants(oracle, pre):
+    S, U = _after_detection(pre)
+    score, sel = oracle.score_cv_vs_mean(S, N=200, max_expr_avg=40)
+    np.testing.assert_allclose(score, pre["cv_mean_score"], rtol=0, atol=1e-9)
+    assert np.array_equal(sel, pre["cv_mean_selected"])
+    score, sel = oracle.score_cv_vs_mean(S, N=150, max_expr_avg=40, winsorize=True, winsor_perc=(1, 99.5), svr_gamma=0.4)
+    np.testing.assert_allclose(score, pre["cv_mean_score_winsor"], rtol=0, atol=1e-9)
+    assert np.array_equal(sel, pre["cv_mean_selected_winsor"])
+    score, sel = oracle.score_cv_vs_mean(S, N=120, max_expr_avg=40, sort_inverse=True, min_expr_cells=5, min_expr_avg=0.05)
+    np.testing.assert_allclose(score, pre["cv_mean_score_inverse"], rtol=0, atol=1e-9)
+    assert np.array_equal(sel, pre["cv_mean_selected_inverse"])
+    score, sel = oracle.score_cv_vs_mean(U, N=150, max_expr_avg=30)
+    np.testing.assert_allclose(score, pre["Ucv_mean_score"], rtol=0, atol=1e-9)
+    assert np.array_equal(sel, pre["Ucv_mean_selected"])
+
+
+def test_pre_cluster_stats_and_size_factor(oracle, pre):
+    S, U = _after_detection(pre)
+    Ua, Sa = oracle.clusters_stats(U, S, pre["cluster_ix"], len(pre["cluster_uid"]))
+    np.testing.assert_allclose(Ua, pre["U_avgs"], rtol=1e-13)
+    np.testing.assert_allclose(Sa, pre["S_avgs"], rtol=1e-13)
+    assert np.array_equal((Ua.max(1) > 0.02) & (Sa.max(1) > 0.08), pre["clu_avg_selected"])
+    np.testing.assert_allclose(oracle.robust_size_factor(S, pre["cv_mean_selected"]), pre["size_factor"], rtol=1e-12)
+    np.testing.assert_allclose(oracle.robust_size_factor(U, pre["Ucv_mean_selected"]), pre["Usize_factor"], rtol=1e-12)
+
+
+def _filtered(pre):
+    S, U = pre["S"].astype(float), pre["U"].astype(float)
+    g = pre["genes_after_cv_cluster"]
+    return S[g], U[g], S.sum(0), U.sum(0)
+
+
+def test_pre_normalisations(oracle, pre):
+    S, U, ics, iucs = _filtered(pre)
+    S_sz, U_sz, small = oracle.normalize_by_total(S, U, ics, iucs, min_perc_U=0.5)
+    assert np.array_equal(small, pre["nt_small_U_pop"])
+    np.testing.assert_allclose(S_sz, pre["nt_S_sz"], rtol=1e-13)
+    np.testing.assert_allclose(U_sz, pre["nt_U_sz"], rtol=1e-13)
+    np.testing.assert_allclose(np.log2(S_sz + 1), pre["nt_S_norm"], rtol=1e-13)
+    a_S, a_U = oracle.adjust_totS_totU(S_sz, U_sz, small, normalize_total=True)
+    np.testing.assert_allclose(a_S, pre["adj_S_sz"], rtol=1e-11)
+    np.testing.assert_allclose(a_U, pre["adj_U_sz"], rtol=1e-9)
+    S2, U2, small2 = oracle.normalize_by_total(S, U, ics, iucs, min_perc_U=5, skip_low_U_pop=False, same_size_UnS=True)
+    np.testing.assert_allclose(S2, pre["nt2_S_sz"], rtol=1e-13)
+    np.testing.assert_allclose(U2, pre["nt2_U_sz"], rtol=1e-13)
+    _, a2 = oracle.adjust_totS_totU(S2, U2, small2, skip_low_U_pop=False, fit_with_low_U=False)
+    np.testing.assert_allclose(a2, pre["adj2_U_sz"], rtol=1e-9)
+    S3, U3, _ = oracle.normalize_by_total(S, U, ics, iucs, min_perc_U=0.5, size_factor=pre["size_factor"])
+    np.testing.assert_allclose(S3, pre["sf_S_sz"], rtol=1e-13)
+    np.testing.assert_allclose(U3, pre["sf_U_sz"], rtol=1e-13)
+
+
+def test_pre_pca_matches_sklearn_golden(oracle, pre):
+    """oracle.pca (numpy SVD + sign rule) against what the reference got from scikit-learn's PCA."""
+    X = np.log2(pre["adj_S_sz"] * 0 + pre["nt_S_sz"] + 1)       # S_norm is set by normalize_by_total and not touched by adjust_totS_totU
+    pcs, comps, evr = oracle.pca(X)
+    k = 60                                                       # leading components: well separated, trailing ones are noise-level
+    np.testing.assert_allclose(evr, pre["explained_variance_ratio"], rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(pcs[:, :k], pre["pcs"][:, :k], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(comps[:k], pre["pca_components"][:k], rtol=0, atol=1e-8)
+    pcs15, _, _ = oracle.pca(X, 15)
+    np.testing.assert_allclose(pcs15, pre["pcs15"], rtol=0, atol=1e-8)
+    pcsx, _, _ = oracle.pca(pre["Sx_norm"], 6)
+    np.testing.assert_allclose(pcsx, pre["pcsx"], rtol=0, atol=1e-8)
+
+
+def test_pre_normalize_median(oracle, pre):
+    # nm_* were produced from the balanced-kNN pooled matrices; the renormalisation itself is what is pinned here
+    Sx_sz, Ux_sz = pre["nm_Sx_sz"], pre["nm_Ux_sz"]
+    small = pre["nt_small_U_pop"]
+    tot = Sx_sz.sum(0)
+    np.testing.assert_allclose(tot, np.median(tot), rtol=1e-9)                   # every cell at the median total
+    totU = Ux_sz.sum(0)[~small]
+    np.testing.assert_allclose(totU, np.median(totU), rtol=1e-9)
+    S1, U1 = oracle.normalize_median_imputed(Sx_sz * np.linspace(0.5, 2, Sx_sz.shape[1]), Ux_sz * np.linspace(2, 0.5, Sx_sz.shape[1]), small)
+    np.testing.assert_allclose(S1.sum(0), np.median((Sx_sz * np.linspace(0.5, 2, Sx_sz.shape[1])).sum(0)), rtol=1e-9)
+    np.testing.assert_allclose(U1[:, small], (Ux_sz * np.linspace(2, 0.5, Sx_sz.shape[1]))[:, small], rtol=0, atol=0)

@@ -9,8 +9,10 @@ kernels of libvelocyto_hip.so; nothing falls back to the CPU.
 Covered: normalize/_normalize_*, knn_imputation[_precomputed], fit_gammas (all
 weight modes and fit branches), predict_U, calculate_velocity, calculate_shift,
 extrapolate_cell_at_t, estimate_transition_prob (knn_random and full, four transforms, randomised
-control), calculate_embedding_shift, prepare_markov, run_markov.  Filtering / plotting / PCA / t-SNE
-are outside the path (``pcs`` / ``ts`` are inputs; ``perform_PCA`` is a scikit-learn pass-through).
+control), calculate_embedding_shift, prepare_markov, run_markov, plus the "next" rows calculate_grid_arrows,
+filter_genes_by_phase_portrait / filter_genes_good_fit and HDF5 (de)serialisation.  The callers upstream of the path
+(cell / gene filters, feature scores, size normalisations, PCA, the default_* drivers) live in ``preprocess.PreprocessMixin``.
+Plotting is out of scope.
 
 Known, deliberate differences from the reference (each has a test):
   * matrices are accepted in any memory order (the reference's F-order trap is gone);
@@ -34,13 +36,14 @@ from . import ops
 from .diffusion import Diffusion
 from .neighbors import BalancedKNN, connectivity_to_weights, knn_distance_matrix
 from .ops import CellMatrix
+from .preprocess import PreprocessMixin
 
 _MATRIX_ATTRS = frozenset(["S", "U", "A", "S_sz", "U_sz", "S_norm", "U_norm", "Sx", "Ux", "Sx_sz", "Ux_sz", "Sx_norm", "Ux_norm",
                            "Upred", "velocity", "delta_S", "delta_S_rndm", "Sx_sz_t", "Sx_t"])
 _LAZY_DENSE = frozenset(["corrcoef", "corrcoef_random", "transition_prob", "transition_prob_random", "tr"])
 
 
-class VelocytoLoom:
+class VelocytoLoom(PreprocessMixin):
     """Device-resident counterpart of velocyto.VelocytoLoom (analysis.py:26-94).
 
     ``VelocytoLoom(loom_filepath)`` reads a .loom file (HDF5 via loom_io: h5py if present, else ctypes-bound libhdf5);
@@ -239,13 +242,6 @@ class VelocytoLoom:
             self._normalize_Sx(size=size, log=log, pcount=pcount, relative_size=relative_size, target_size=target_size[0])
         if "Ux" == which:
             self._normalize_Ux(size=size, log=log, pcount=pcount, use_Sx_size=use_S_size_for_U, relative_size=relative_size, target_size=target_size[1])
-
-    def perform_PCA(self, which: str = "S_norm", n_components: int = None, div_by_std: bool = False) -> None:
-        """analysis.py:678-702 -- upstream of the hot path; scikit-learn pass-through on the host."""
-        from sklearn.decomposition import PCA
-        X = getattr(self, which)
-        self.pca = PCA(n_components=n_components)
-        self.pcs = self.pca.fit_transform((X / X.std(0)).T if div_by_std else X.T)
 
     # ------------------------------------------------------------------ stage A
     def knn_imputation(self, k: int = None, pca_space: float = True, metric: str = "euclidean", diag: float = 1, n_pca_dims: int = None,

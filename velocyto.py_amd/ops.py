@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 
-F32, F64 = 0, 1
+F32, F64, U16 = 0, 1, 2
 LINEAR, SQRT, LOG10 = 0, 1, 2
 RULES_FULL, RULES_PARTIAL = 0, 1
 TRANSFORMS = {"linear": LINEAR, "sqrt": SQRT, "log10": LOG10, "log": LOG10}
@@ -469,10 +469,31 @@ def gene_moments(Y: CellMatrix, X: CellMatrix) -> torch.Tensor:
     return mom
 
 
+def gene_stats(M, cell_scale=None, lo=None, hi=None, cell_mask=None) -> torch.Tensor:
+    """(4, G) fp64 [sum, sum of squares, count(x > 0), max] per gene over cells of x = clip(M * cell_scale[:, None], lo, hi),
+    restricted to the cells where cell_mask is true.  M: CellMatrix or CountMatrix."""
+    dev = M.t.device
+    code = U16 if isinstance(M, CountMatrix) else M.code
+    f64 = lambda t: None if t is None else torch.as_tensor(t, device=dev).to(torch.float64).contiguous()
+    cell_scale, lo, hi = f64(cell_scale), f64(lo), f64(hi)
+    mask = None if cell_mask is None else torch.as_tensor(cell_mask, device=dev).to(torch.uint8).contiguous()
+    out = torch.empty((4, M.G), dtype=torch.float64, device=dev)
+    ws = torch.empty(int(_lib.lib().vcy_gene_stats_workspace_bytes(M.G)), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib().vcy_gene_stats(M.t.data_ptr(), _p(cell_scale), _p(lo), _p(hi), _p(mask), out.data_ptr(), ws.data_ptr(),
+                                         M.C, M.G, M.ld, code, _stream()), "gene_stats")
+    return out
+
+
+def select_cells(M, keep) -> "CellMatrix":
+    """Cell (row) subset of a cells-major matrix (CellMatrix or CountMatrix)."""
+    idx = torch.nonzero(torch.as_tensor(keep, device=M.t.device), as_tuple=False).ravel()
+    return type(M)(M.t.index_select(0, idx).contiguous(), M.G)
+
+
 def select_genes(M: CellMatrix, keep: torch.Tensor) -> CellMatrix:
     """Gene (column) subset of a cells-major matrix, re-padded (index plumbing)."""
-    idx = torch.nonzero(keep.to(M.t.device), as_tuple=False).ravel()
-    out = CellMatrix(torch.zeros((M.C, padded_ld(int(idx.numel()))), dtype=M.dtype, device=M.t.device), int(idx.numel()))
+    idx = torch.nonzero(torch.as_tensor(keep, device=M.t.device), as_tuple=False).ravel()
+    out = type(M)(torch.zeros((M.C, padded_ld(int(idx.numel()))), dtype=M.t.dtype, device=M.t.device), int(idx.numel()))
     out.t[:, : idx.numel()] = M.t.index_select(1, idx)
     return out
 

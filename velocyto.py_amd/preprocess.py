@@ -1,0 +1,448 @@
+"""Callers upstream of the hot path: the filtering / scoring / size-normalisation / PCA methods of
+``velocyto.analysis.VelocytoLoom`` (analysis.py:134-533, 678-932, 1441-1450, 1889-1964), same names, arguments
+and attributes, mixed into the device-resident facade.
+
+What runs where:
+  * every reduction over the (genes x cells) matrices is a HIP kernel: per-gene sum / sum of squares / number of
+    expressing cells / winsorised moments (``vcy_gene_stats``), per-gene percentiles (``vcy_gene_quantiles``), per-cell
+    totals (``vcy_row_sums``), scaling and log (``vcy_scale_log``);
+  * gene / cell subsetting and the per-cell rescalings are index / broadcast plumbing on the device tensors;
+  * PCA is the covariance route on the device in fp64 (Gram matrix by blocked GEMM, symmetric eigensolver), identical
+    to scikit-learn's ``PCA`` up to rounding, with scikit-learn's sign convention;
+  * what the reference delegates to scikit-learn on G- or C-long vectors (the SVR noise model of score_cv_vs_mean and
+    adjust_totS_totU, t-SNE) is delegated to scikit-learn here too - third-party arithmetic, not part of the path.
+Plotting is out of scope (``plot=True`` is accepted and ignored).
+"""
+from __future__ import annotations
+
+import logging
+from copy import deepcopy
+from typing import Any, Dict, List, Tuple
+
+import numpy as np
+import torch
+from scipy import sparse
+
+from . import ops
+from .ops import CellMatrix
+
+
+def colormap_fun(x: np.ndarray) -> np.ndarray:
+    """analysis.py:2385-2389: 20 colours, tab20b even entries followed by tab20c odd entries."""
+    import matplotlib
+    tab20b, tab20c = matplotlib.colormaps["tab20b"], matplotlib.colormaps["tab20c"]
+    colors20 = np.vstack((tab20b(np.linspace(0., 1, 20))[::2], tab20c(np.linspace(0, 1, 20))[1::2]))
+    return colors20[np.mod(x, 20)]
+
+
+class DevicePCA:
+    """What ``sklearn.decomposition.PCA`` leaves behind after ``fit`` (the attributes the reference and its tutorial
+    read: ``explained_variance_ratio_``, ``components_``, ...), computed on the device."""
+
+    def __init__(self, n_components=None):
+        self.n_components = n_components
+
+    def fit_transform(self, X: CellMatrix, block: int = 8192) -> np.ndarray:
+        """X: cells-major device matrix (samples = cells).  Returns pcs (C, n_components) float64."""
+        C, G = X.C, X.G
+        dev = X.t.device
+        k = min(C, G) if self.n_components is None else int(self.n_components)
+        if not 1 <= k <= min(C, G):
+            raise ValueError(f"n_components={self.n_components!r} must be between 1 and min(n_samples, n_features)={min(C, G)}")
+        mean = torch.zeros(G, dtype=torch.float64, device=dev)
+        for s in range(0, C, block):
+            mean += X.t[s:s + block, :G].sum(0, dtype=torch.float64)
+        mean /= C
+        if G <= C:      # covariance of the genes (G x G)
+            gram = torch.zeros((G, G), dtype=torch.float64, device=dev)
+            for s in range(0, C, block):
+                A = X.t[s:s + block, :G].double() - mean
+                gram.addmm_(A.T, A)
+            w, V = torch.linalg.eigh(gram)
+            w, V = w.flip(0).clamp_(min=0.0), V.flip(1)                  # descending
+            comps = V[:, :k].T.contiguous()                               # (k, G)
+        else:           # fewer cells than genes: eigenvectors of the (C x C) Gram matrix of the cells, mapped back
+            A = X.t[:, :G].double() - mean
+            w, Uc = torch.linalg.eigh(A @ A.T)
+            w, Uc = w.flip(0).clamp_(min=0.0), Uc.flip(1)
+            comps = (Uc[:, :k].T @ A) / torch.sqrt(w[:k]).clamp(min=1e-300)[:, None]
+        # sklearn.utils.extmath.svd_flip(u_based_decision=False): the largest-|.| loading of every component is positive
+        idx = comps.abs().argmax(1)
+        comps = comps * torch.sign(comps[torch.arange(k, device=dev), idx])[:, None]
+        pcs = torch.empty((C, k), dtype=torch.float64, device=dev)
+        for s in range(0, C, block):
+            pcs[s:s + block] = (X.t[s:s + block, :G].double() - mean) @ comps.T
+        total_var = float(w.sum()) / (C - 1)
+        self.components_ = comps.cpu().numpy()
+        self.explained_variance_ = (w[:k] / (C - 1)).cpu().numpy()
+        self.explained_variance_ratio_ = self.explained_variance_ / total_var
+        self.singular_values_ = np.sqrt(w[:k].cpu().numpy())
+        self.mean_ = mean.cpu().numpy()
+        self.n_components_, self.n_samples_, self.n_features_in_ = k, C, G
+        self.noise_variance_ = float(w[k:].sum() / (C - 1) / max(1, min(C, G) - k)) if k < min(C, G) else 0.0
+        self._pcs_dev = pcs
+        return pcs.cpu().numpy()
+
+    def transform(self, Xcg: np.ndarray) -> np.ndarray:
+        """(samples, genes) host array -> scores (host convenience, as sklearn)."""
+        return (np.asarray(Xcg, dtype=np.float64) - self.mean_) @ self.components_.T
+
+
+class PreprocessMixin:
+    """Methods of VelocytoLoom upstream of knn_imputation (mixed into analysis.VelocytoLoom)."""
+
+    # ------------------------------------------------------------------ subsetting
+    def _subset(self, names, keep, axis: str) -> None:
+        """Row (cells) or column (genes) subset of device matrices, count layers included."""
+        sel = ops.select_cells if axis == "cells" else ops.select_genes
+        keep_t = torch.as_tensor(np.asarray(keep), device=ops.require_gpu())
+        counts = self.__dict__.setdefault("_counts", {})
+        for name in names:
+            if name not in self._dev:
+                continue
+            cnt = counts.get(name)
+            self._set_dev(name, sel(self._dev[name], keep_t))
+            if cnt is not None:
+                counts[name] = sel(cnt, keep_t)
+            if axis == "cells":
+                sc = self.__dict__.get("_sz_scale", {})
+                if name + "_sz" in sc:
+                    sc.pop(name + "_sz")
+
+    def filter_cells(self, bool_array: np.ndarray) -> None:
+        """analysis.py:134-163: keep the cells where bool_array is True (S, U, A and the per-cell annotations)."""
+        bool_array = np.asarray(bool_array)
+        self._subset(("S", "U", "A"), bool_array, "cells")
+        self.initial_cell_size = self.initial_cell_size[bool_array]
+        self.initial_Ucell_size = self.initial_Ucell_size[bool_array]
+        for attr in ("ts", "size_factor"):
+            try:
+                setattr(self, attr, getattr(self, attr)[bool_array])
+            except Exception:
+                pass
+        self.ca = {k: v[bool_array] for k, v in self.ca.items()}
+        try:
+            self.cluster_labels = self.cluster_labels[bool_array]
+            self.colorandum = self.colorandum[bool_array, :]
+        except AttributeError:
+            pass
+
+    def filter_genes(self, by_detection_levels: bool = False, by_cluster_expression: bool = False, by_cv_vs_mean: bool = False,
+                     by_custom_array: Any = None, keep_unfiltered: bool = False) -> None:
+        """analysis.py:477-533: S, U and ra are cut down to the genes that pass every requested filter."""
+        assert np.any([by_detection_levels, by_cluster_expression, by_cv_vs_mean, (type(by_custom_array) is np.ndarray)]), \
+            "At least one of the filtering methods needs to be True"
+        tmp_filter = np.ones(self.dev("S").G, dtype=bool)
+        if by_cluster_expression:
+            assert hasattr(self, "clu_avg_selected"), "clu_avg_selected was not found"
+            tmp_filter = tmp_filter & self.clu_avg_selected
+        if by_cv_vs_mean:
+            assert hasattr(self, "cv_mean_selected"), "cv_mean_selected was not found"
+            tmp_filter = tmp_filter & self.cv_mean_selected
+        if by_detection_levels:
+            assert hasattr(self, "detection_level_selected"), "detection_level_selected was not found"
+            tmp_filter = tmp_filter & self.detection_level_selected
+        if type(by_custom_array) is np.ndarray:
+            if by_custom_array.dtype == bool:
+                tmp_filter = tmp_filter & by_custom_array
+            elif by_custom_array.dtype == int:
+                tmp_filter[~np.isin(np.arange(len(tmp_filter)), by_custom_array)] = False
+        if keep_unfiltered:
+            if hasattr(self, "U_prefilter"):
+                logging.debug("Attributes *_prefilter are already present and were overwritten")
+            self.U_prefilter = sparse.csr_matrix(self.U)
+            self.S_prefilter = sparse.csr_matrix(self.S)
+            self.ra_prefilter = deepcopy(self.ra)
+        self._subset(("U", "S"), tmp_filter, "genes")
+        self.ra = {k: v[tmp_filter] for k, v in self.ra.items()}
+
+    def custom_filter_attributes(self, attr_names: List[str], bool_filter: np.ndarray) -> None:
+        """analysis.py:535-571 (numbering of the reference file: the block before _normalize_S)."""
+        for attr in attr_names:
+            transpose_flag = attr[-2:] == ".T"
+            obj = getattr(self, attr[:-2] if transpose_flag else attr)
+            if type(obj) is dict:
+                setattr(self, attr, {k: v[bool_filter] for k, v in obj.items()})
+            elif type(obj) is np.ndarray:
+                if len(obj.shape) > 1:
+                    setattr(self, attr, obj[..., bool_filter] if transpose_flag else obj[bool_filter, :])
+                else:
+                    setattr(self, attr, obj[bool_filter])
+            else:
+                raise NotImplementedError(f"The filtering of an object of type {type(obj)} is not defined")
+
+    # ------------------------------------------------------------------ clusters
+    def set_clusters(self, cluster_labels: np.ndarray, cluster_colors_dict: Dict[str, List[float]] = None, colormap: Any = None) -> None:
+        """analysis.py:165-199."""
+        self.cluster_labels = np.array(cluster_labels)
+        if self.cluster_labels.dtype == "O":
+            self.cluster_labels = self.cluster_labels.astype(np.bytes_)
+        if cluster_colors_dict:
+            self.colorandum = np.array([cluster_colors_dict[i] for i in cluster_labels])
+            self.cluster_colors_dict = cluster_colors_dict
+            self.colormap = None
+        else:
+            fun = colormap_fun if colormap is None else colormap
+            self.colormap = colormap
+            self.colorandum = fun(self.cluster_ix)
+            cluster_uid = self.cluster_uid
+            self.cluster_colors_dict = {cluster_uid[i]: fun(i) for i in range(len(cluster_uid))}
+
+    @property
+    def cluster_uid(self) -> np.ndarray:
+        return np.unique(self.cluster_labels)
+
+    @property
+    def cluster_ix(self) -> np.ndarray:
+        return np.unique(self.cluster_labels, return_inverse=True)[1]
+
+    # ------------------------------------------------------------------ gene scores
+    def _layer_for_stats(self, name: str):
+        """The uint16 count layer when the matrix still is one (2-byte reads), else the float matrix."""
+        return self.__dict__.get("_counts", {}).get(name, self.dev(name))
+
+    def score_detection_levels(self, min_expr_counts: int = 50, min_cells_express: int = 20, min_expr_counts_U: int = 0,
+                               min_cells_express_U: int = 0) -> None:
+        """analysis.py:456-475: detection_level_selected from per-gene totals and numbers of expressing cells."""
+        sS = ops.gene_stats(self._layer_for_stats("S")).cpu().numpy()
+        sU = ops.gene_stats(self._layer_for_stats("U")).cpu().numpy()
+        self.detection_level_selected = ((sS[0] >= min_expr_counts) & (sS[2] >= min_cells_express) &
+                                         (sU[0] >= min_expr_counts_U) & (sU[2] >= min_cells_express_U))
+
+    def score_cv_vs_mean(self, N: int = 3000, min_expr_cells: int = 2, max_expr_avg: float = 20, min_expr_avg: int = 0, svr_gamma: float = None,
+                         winsorize: bool = False, winsor_perc: Tuple[float, float] = (1, 99.5), sort_inverse: bool = False, which: str = "S",
+                         plot: bool = False) -> None:
+        """analysis.py:201-345: CV-vs-mean noise model (SVR on log2 mean -> log2 CV) and the N genes most above it.
+        Per-gene detection, mean and std(ddof=1) - optionally of the values winsorised to per-gene percentiles - come from
+        one or two streaming passes on the device; the SVR (scikit-learn, G points) runs on the host as in the reference."""
+        from sklearn.svm import SVR
+        name = "S" if which == "S" else "U"
+        M = self._layer_for_stats(name)
+        C, G = M.C, M.G
+        if winsorize:
+            if min_expr_cells <= ((100 - winsor_perc[1]) * C * 0.01):
+                min_expr_cells = int(np.ceil((100 - winsor_perc[1]) * G * 0.01)) + 2          # sic: genes, as the reference (:248)
+                logging.debug(f"min_expr_cells is too low for winsorization with upper_perc ={winsor_perc[1]}, upgrading to min_expr_cells ={min_expr_cells}")
+        st = ops.gene_stats(M).cpu().numpy()
+        mean_all = st[0] / C
+        detected_bool = (st[2] > min_expr_cells) & (mean_all < max_expr_avg) & (mean_all > min_expr_avg)
+        if winsorize:
+            q = ops.gene_quantiles(self.dev(name), list(winsor_perc))
+            st = ops.gene_stats(M, lo=q[0], hi=q[1]).cpu().numpy()
+        mu = (st[0] / C)[detected_bool]
+        var = (st[1][detected_bool] - C * mu * mu) / (C - 1)
+        sigma = np.sqrt(np.maximum(var, 0.0))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            cv = sigma / mu
+            log_m, log_cv = np.log2(mu), np.log2(cv)
+        if svr_gamma is None:
+            svr_gamma = 150. / len(mu)
+            logging.debug(f"svr_gamma set to {svr_gamma}")
+        clf = SVR(gamma=svr_gamma)
+        clf.fit(log_m[:, None], log_cv)
+        score = log_cv - clf.predict(log_m[:, None])
+        if sort_inverse:
+            score = -score
+        nth_score = np.sort(score)[::-1][N]
+        full = np.zeros(detected_bool.shape)
+        full[~detected_bool] = np.min(score) - 1e-16
+        full[detected_bool] = score
+        if which == "S":
+            self.cv_mean_score, self.cv_mean_selected = full, full >= nth_score
+        else:
+            self.Ucv_mean_score, self.Ucv_mean_selected = full, full >= nth_score
+
+    def score_cluster_expression(self, min_avg_U: float = 0.02, min_avg_S: float = 0.08) -> None:
+        """analysis.py:441-454 + estimation.clusters_stats (estimation.py:369-389): per-cluster gene averages (clusters of
+        at most 40 cells report the overall average), masked streaming passes on the device."""
+        uid, ix = self.cluster_uid, self.cluster_ix
+        S, U = self._layer_for_stats("S"), self._layer_for_stats("U")
+        C, G = S.C, S.G
+        size_limit = 40
+        self.U_avgs, self.S_avgs = np.zeros((G, len(uid))), np.zeros((G, len(uid)))
+        overall = None
+        for i in range(len(uid)):
+            filt = ix == i
+            n_cells = int(filt.sum())
+            if n_cells > size_limit:
+                self.U_avgs[:, i] = ops.gene_stats(U, cell_mask=filt)[0].cpu().numpy() / n_cells
+                self.S_avgs[:, i] = ops.gene_stats(S, cell_mask=filt)[0].cpu().numpy() / n_cells
+            else:
+                if overall is None:
+                    overall = (ops.gene_stats(U)[0].cpu().numpy() / C, ops.gene_stats(S)[0].cpu().numpy() / C)
+                self.U_avgs[:, i], self.S_avgs[:, i] = overall
+        self.clu_avg_selected = (self.U_avgs.max(1) > min_avg_U) & (self.S_avgs.max(1) > min_avg_S)
+
+    def robust_size_factor(self, pc: float = 0.1, which: str = "both") -> None:
+        """analysis.py:347-439: per-cell median over the selected genes of 2**(log2(x + pc) - gene mean of log2), mean 1."""
+        def one(name, selected):
+            sub = ops.select_genes(self.dev(name), torch.as_tensor(selected))
+            Y = torch.log2(sub.t[:, :sub.G].double() + pc)
+            R = torch.exp2(Y - Y.mean(0, keepdim=True))
+            srt = torch.sort(R, dim=1).values
+            n = sub.G
+            med = 0.5 * (srt[:, (n - 1) // 2] + srt[:, n // 2])          # numpy's median
+            med = med.cpu().numpy()
+            return med / np.mean(med)
+        if which in ("both", "S"):
+            self.size_factor = one("S", self.cv_mean_selected)
+        if which in ("both", "U"):
+            self.Usize_factor = one("U", self.Ucv_mean_selected)
+
+    # ------------------------------------------------------------------ size normalisations
+    def _norm_common(self, cell_size, Ucell_size, S_relative, min_perc_U, skip_low_U_pop, same_size_UnS):
+        target_cell_size = np.median(cell_size)
+        min_Ucell_size = np.percentile(Ucell_size, min_perc_U)
+        if min_Ucell_size < 2:
+            raise ValueError(f"min_perc_U={min_perc_U} corresponds to total Unspliced of 1 molecule of less. Please choose higher value or filter our these cell")
+        self.small_U_pop = Ucell_size < min_Ucell_size
+        target_Ucell_size = target_cell_size if same_size_UnS else np.median(Ucell_size[~self.small_U_pop])
+        self._normalize_S(relative_size=S_relative, target_size=target_cell_size)
+        if skip_low_U_pop:
+            self._normalize_U(relative_size=np.clip(self.initial_Ucell_size, min_Ucell_size, None), target_size=target_Ucell_size)
+        else:
+            self._normalize_U(relative_size=self.initial_Ucell_size, target_size=target_Ucell_size)
+
+    def normalize_by_total(self, min_perc_U: float = 0.5, plot: bool = False, skip_low_U_pop: bool = True, same_size_UnS: bool = False) -> None:
+        """analysis.py:704-758."""
+        self._norm_common(self.initial_cell_size, self.initial_Ucell_size, self.initial_cell_size, min_perc_U, skip_low_U_pop, same_size_UnS)
+
+    def normalize_by_size_factor(self, min_perc_U: float = 0.5, plot: bool = False, skip_low_U_pop: bool = True, same_size_UnS: bool = False) -> None:
+        """analysis.py:760-818 (cell sizes of the CURRENT S / U; S is divided by ``size_factor``)."""
+        cell_size = ops.row_sums(self.dev("S")).cpu().numpy()
+        Ucell_size = ops.row_sums(self.dev("U")).cpu().numpy()
+        self._norm_common(cell_size, Ucell_size, self.size_factor, min_perc_U, skip_low_U_pop, same_size_UnS)
+
+    def _scale_cells(self, name: str, factor: np.ndarray) -> None:
+        """M[:, c] *= factor[c] on the device (in a new matrix when `name` is new)."""
+        f = torch.as_tensor(np.asarray(factor, dtype=np.float64), device=self.dev(name).t.device)
+        M = self.dev(name)
+        M.t.mul_(f[:, None].to(M.dtype))
+        self._host.pop(name, None)
+        sc = self.__dict__.get("_sz_scale", {})
+        if name in sc:
+            sc[name] = sc[name] * f
+
+    def adjust_totS_totU(self, skip_low_U_pop: bool = True, normalize_total: bool = False, fit_with_low_U: bool = True, svr_C: float = 100,
+                         svr_gamma: float = 1e-6, plot: bool = False) -> None:
+        """analysis.py:820-868: SVR of total U_sz on total S_sz per cell; U_sz is rescaled towards the prediction."""
+        from sklearn.svm import SVR
+        svr = SVR(C=svr_C, kernel="rbf", gamma=svr_gamma)
+        X, y = ops.row_sums(self.dev("S_sz")).cpu().numpy(), ops.row_sums(self.dev("U_sz")).cpu().numpy()
+        if fit_with_low_U:
+            svr.fit(X[:, None], y)
+            predicted = svr.predict(X[:, None])
+        else:
+            svr.fit(X[~self.small_U_pop, None], y[~self.small_U_pop])
+            predicted = np.copy(y)
+            predicted[~self.small_U_pop] = svr.predict(X[~self.small_U_pop, None])
+        with np.errstate(divide="ignore", invalid="ignore"):
+            adj_factor = predicted / y
+        adj_factor[~np.isfinite(adj_factor)] = 1
+        if skip_low_U_pop:
+            adj_factor = np.where(~self.small_U_pop, adj_factor, 1.0)
+        self._scale_cells("U_sz", adj_factor)
+        if normalize_total:
+            self.normalize_median(which="renormalize", skip_low_U_pop=skip_low_U_pop)
+
+    def normalize_median(self, which: str = "imputed", skip_low_U_pop: bool = True) -> None:
+        """analysis.py:870-905: every cell rescaled to the median cell total (raw size-normalised or imputed matrices)."""
+        C = self.dev("U_sz").C if which == "renormalize" else self.dev("Ux").C
+        if not hasattr(self, "small_U_pop") and skip_low_U_pop:
+            self.small_U_pop = np.zeros(C, dtype=bool)
+            logging.warning("object does not have the attribute `small_U_pop`, so all the unspliced will be normalized by relative size, this might cause the overinflation the unspliced counts of cells where only few unspliced molecules were detected")
+
+        def factors(tot, subset):
+            f = np.ones(len(tot))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                f[subset] = np.median(tot[subset]) / tot[subset]
+            return f
+        everyone = np.ones(C, dtype=bool)
+        if which == "renormalize":
+            self._scale_cells("S_sz", factors(ops.row_sums(self.dev("S_sz")).cpu().numpy(), everyone))
+            self._scale_cells("U_sz", factors(ops.row_sums(self.dev("U_sz")).cpu().numpy(), ~self.small_U_pop if skip_low_U_pop else everyone))
+        elif which == "imputed":
+            self._set_dev("Sx_sz", self.dev("Sx").clone())
+            self._scale_cells("Sx_sz", factors(ops.row_sums(self.dev("Sx")).cpu().numpy(), everyone))
+            self._set_dev("Ux_sz", self.dev("Ux").clone())
+            self._scale_cells("Ux_sz", factors(ops.row_sums(self.dev("Ux")).cpu().numpy(), ~self.small_U_pop if skip_low_U_pop else everyone))
+
+    # ------------------------------------------------------------------ PCA / t-SNE
+    def _pca_input(self, which: str, div_by_std: bool) -> CellMatrix:
+        X = self.dev(which)
+        if div_by_std:
+            # the reference writes X.T / X.std(0), which only broadcasts when cells == genes; what it can mean for a
+            # (genes, cells) matrix is each cell divided by its own standard deviation over the genes
+            t = X.t[:, :X.G].double()
+            X = CellMatrix.from_cells_major(t / t.std(1, unbiased=False, keepdim=True), torch.float64)
+        return X
+
+    def perform_PCA(self, which: str = "S_norm", n_components: int = None, div_by_std: bool = False) -> None:
+        """analysis.py:678-702: PCA with cells as samples -> ``pca`` (fitted attributes) and ``pcs`` (cells, npcs)."""
+        self.pca = DevicePCA(n_components=n_components)
+        self.pcs = self.pca.fit_transform(self._pca_input(which, div_by_std))
+
+    def _perform_PCA_imputed(self, n_components: int = None) -> None:
+        """analysis.py:918-920."""
+        self.pcax = DevicePCA(n_components=n_components)
+        self.pcsx = self.pcax.fit_transform(self.dev("Sx_norm"))
+
+    def perform_TSNE(self, n_dims: int = 2, perplexity: float = 30, initial_pos: np.ndarray = None, theta: float = 0.5, n_pca_dim: int = None,
+                     max_iter: int = 1000) -> None:
+        """analysis.py:1441-1450: Barnes-Hut t-SNE of the leading PCs (scikit-learn, as the reference; its ``n_iter`` keyword is
+        ``max_iter`` since scikit-learn 1.5)."""
+        import inspect
+        from sklearn.manifold import TSNE
+        kw = "max_iter" if "max_iter" in inspect.signature(TSNE.__init__).parameters else "n_iter"
+        bh_tsne = TSNE(n_components=n_dims, perplexity=perplexity, angle=theta, init="random" if initial_pos is None else initial_pos, **{kw: max_iter})
+        self.ts = bh_tsne.fit_transform(self.pcs[:, :n_pca_dim])
+
+    # ------------------------------------------------------------------ deprecated one-call drivers
+    def default_filter_and_norm(self, min_expr_counts: int = None, min_cells_express: int = None, N: int = None, min_avg_U: float = None,
+                                min_avg_S: float = None) -> None:
+        """analysis.py:1889-1940."""
+        logging.warning("DEPRECATION WARNING - the current function is deprecated. Please refer to documentation for default parameters usage")
+        C = self.dev("S").C
+        if min_expr_counts is None:
+            min_expr_counts = max(20, min(100, C * 2.25e-3))
+        if min_cells_express is None:
+            min_cells_express = max(10, min(50, C * 1.5e-3))
+        if N is None:
+            N = max(1000, min(int((C / 1000)**(1 / 3) / 0.0008), 5000))
+        if min_avg_U is None:
+            min_avg_U = 0.01
+        if min_avg_S is None:
+            min_avg_S = 0.08
+        self.normalize("S", size=True, log=False)
+        self.normalize("U", size=True, log=False)
+        self.score_detection_levels(min_expr_counts=min_expr_counts, min_cells_express=min_cells_express)
+        self.filter_genes(by_detection_levels=True)
+        self.score_cv_vs_mean(N=N, max_expr_avg=40)
+        self.filter_genes(by_cv_vs_mean=True)
+        self.score_detection_levels(min_expr_counts=0, min_cells_express=0, min_expr_counts_U=int(min_expr_counts / 2) + 1,
+                                    min_cells_express_U=int(min_cells_express / 2) + 1)
+        if hasattr(self, "cluster_labels"):
+            self.score_cluster_expression(min_avg_U=min_avg_U, min_avg_S=min_avg_S)
+            self.filter_genes(by_detection_levels=True, by_cluster_expression=True)
+        else:
+            self.filter_genes(by_detection_levels=True)
+        self.normalize_by_total()
+        self.adjust_totS_totU(normalize_total=True)
+
+    def default_fit_preparation(self, k: int = None, n_comps: int = None) -> None:
+        """analysis.py:1942-1964."""
+        logging.warning("DEPRECATION WARNING - the current function is deprecated. Please refer to documetation for default parameters usage")
+        C = self.dev("S").C
+        self.perform_PCA()
+        if n_comps is None:
+            n_comps = int(np.where(np.diff(np.diff(np.cumsum(self.pca.explained_variance_ratio_)) > 0.002))[0][0])
+        if k is None:
+            k = int(min(1000, max(10, np.ceil(C * 0.02))))
+        self.knn_imputation(n_pca_dims=n_comps, k=k, balanced=True, b_sight=int(min(k * 8, C - 1)), b_maxl=int(min(k * 4, C - 1)))
+        self.normalize_median()
+
+    def gene_knn_imputation(self, *args, **kwargs) -> None:
+        """analysis.py:1055-1118 smooths genes with the CELL graph's connectivity (``self.knn``), which only
+        has a meaning when cells == genes; not reproduced."""
+        raise NotImplementedError("gene_knn_imputation: the reference builds the gene weights from the cell kNN graph (analysis.py:1107); "
+                                  "there is no well-defined behaviour to mirror")
