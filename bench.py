@@ -36,9 +36,9 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK = 8.0e12   # B/s, MI355X spec (MI355X_MICROARCH.md)
-# profiles/r01d_bench_50kx30k_pmc.csv, k_cdc_partial_grouped<float,SQRT,PARTIAL,8> at the default workload on 1 GPU:
-# 2 * FETCH_SIZE (74 062 060 KiB; gfx950 half-count correction) + WRITE_SIZE (49 999 KiB), in bytes per launch
-PMC_TRAFFIC_DEFAULT = 2 * 74062059.625 * 1024 + 49998.6875 * 1024
+# profiles/r01e_bench_50kx30k_pmc.csv, k_cdc_partial_grouped<float,SQRT,PARTIAL,8> (velocity chain folded in) at the default
+# workload on 1 GPU: 2 * FETCH_SIZE (80 050 726 KiB; gfx950 half-count correction) + WRITE_SIZE (50 000 KiB), in bytes per launch
+PMC_TRAFFIC_DEFAULT = 2 * 80050726.0625 * 1024 + 49999.96875 * 1024
 
 
 def parse():
@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass; the default workload "
-                         "uses the figure recorded in profiles/r01d_bench_50kx30k_pmc.csv, other workloads report null")
+                         "uses the figure recorded in profiles/r01e_bench_50kx30k_pmc.csv, other workloads report null")
     ap.add_argument("--slab", type=int, default=0, help="gene slab of the pooling kernel (0 = library default)")
     ap.add_argument("--no-fuse", dest="fuse", action="store_false",
                     help="materialise dmat with k_velocity_chain instead of folding the velocity chain into stage D")
@@ -147,6 +147,8 @@ class Pipeline:
         C, G = args.cells, args.genes
         # resident inputs: the loom's uint16 count layers + per-cell size factors (S_sz = fS * S is never materialised)
         self.cS, self.cU, self.fS, self.fU, self.pcs = synth_counts(C, G, args.pca_dims, dev)
+        if world > 1:
+            dist.broadcast(self.pcs, 0)          # every rank must relabel / shard by the same embedding, bit for bit
         self.collect = world > 1 or distributed.FORCE
         if self.collect:
             # cell-sharded run: relabel the cells in Morton order of the embedding so that a rank's contiguous block
@@ -327,7 +329,7 @@ def main():
         alg_bytes = nloc * ((nr + 2) * G * 4 + nr * (4 + 4))          # (nrndm+2)*G*s + nrndm*(idx+out) per cell
         achieved = alg_bytes / (d_ms * 1e-3)
         stage = pipe.stage_ms / a.steps
-        default_wl = (C, G, nr, a.k, world, a.order) == (50000, 30000, 250, 30, 1, "embedding")
+        default_wl = (C, G, nr, a.k, world, a.order, a.fuse) == (50000, 30000, 250, 30, 1, "embedding", True)
         traffic = a.traffic_bytes if a.traffic_bytes is not None else (PMC_TRAFFIC_DEFAULT if default_wl else None)
         res = {
             "metric": "cells/sec through knn_imputation->fit_slope->colDeltaCor, 50k cells x 30k genes",
@@ -353,9 +355,9 @@ def main():
                          "note": "achieved = ALGORITHMIC bytes (no reuse credited: (nrndm+2)*G*4 + nrndm*8 per cell) / HIP-event "
                                  "launch time. The grouped kernel reads a neighbour row once per 8-cell group (3.5x reuse out of "
                                  "LDS) and adjacent groups share rows in the per-XCD L2, so frac > 1 means it beats the no-reuse HBM "
-                                 "roofline; `traffic` is the PMC-measured L2-miss traffic of the same launch (profiles/r01d_*). The "
-                                 "kernel is VALU/transcendental-bound: 9.9 VALU instr incl. one quarter-rate v_sqrt_f32 per "
-                                 "pair-gene, VALU pipes 95 % busy (4 x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)."},
+                                 "roofline; `traffic` is the PMC-measured L2-miss traffic of the same launch (profiles/r01e_*). The "
+                                 "kernel is VALU-bound: 9.0 VALU instr per pair-gene (v_sqrt_f32 takes two issue slots), VALU pipes "
+                                 "95 % busy (4 x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)."},
         }
         if not a.no_cpu_baseline and world == 1:     # reported on rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(pipe, a)

@@ -18,6 +18,23 @@ def timed(name, fn, *a, **k):
     print(f"{name:32s} {1e3*(time.perf_counter()-t0):10.1f} ms", flush=True)
     return r
 
+if os.environ.get("PRE", "1") == "1":
+    # upstream callers on the raw uint16 count layers (tutorial order): detection filter, CV-vs-mean, size normalisation, PCA
+    cS, cU, fS, fU, _ = bench.synth_counts(C, G, 30, dev)
+    pre = vcy.analysis.VelocytoLoom.from_arrays(cS, cU)
+    del cS, cU
+    timed("score_detection_levels", pre.score_detection_levels, min_expr_counts=40, min_cells_express=30)
+    timed("filter_genes(detection)", pre.filter_genes, by_detection_levels=True)
+    print(f"    genes kept: {pre.dev('S').G} of {G}")
+    timed("score_cv_vs_mean(N=3000)", pre.score_cv_vs_mean, N=3000, max_expr_avg=35)
+    timed("filter_genes(cv_vs_mean)", pre.filter_genes, by_cv_vs_mean=True)
+    timed("normalize_by_total", pre.normalize_by_total)
+    timed("adjust_totS_totU", pre.adjust_totS_totU, normalize_total=True)
+    timed(f"perform_PCA ({pre.dev('S').G} genes, all comps)", pre.perform_PCA)
+    timed("perform_PCA(n_components=30)", pre.perform_PCA, n_components=30)
+    del pre
+    torch.cuda.empty_cache()
+
 vlm = vcy.analysis.VelocytoLoom.from_arrays(S, U)       # device matrices go in as they are
 vlm.pcs = pcs.cpu().numpy(); vlm.ts = vlm.pcs[:, :2].copy()
 timed("normalize", vlm.normalize, "both")

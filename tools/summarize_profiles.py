@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of tools/profile_round.sh (gpurun_out/<tag>_*) into the committed summaries
+profiles/<tag>_bench_50kx30k_kernel_stats.csv and profiles/<tag>_bench_50kx30k_pmc.csv (library kernels only).
+
+usage: python tools/summarize_profiles.py <tag> "<one-line description of the profiled build>"
+"""
+import csv
+import glob
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, note = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
+OUT = os.path.join(ROOT, "profiles")
+ours = lambda name: "vcy::" in name or name.startswith("void k_") or " k_" in name.split("(")[0]
+
+
+def find(sub, suffix):
+    hits = glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{sub}", "**", f"*{suffix}"), recursive=True)
+    if not hits:
+        raise SystemExit(f"no {suffix} under gpurun_out/{tag}_{sub}")
+    return hits[0]
+
+
+# ---- kernel stats
+rows = list(csv.reader(open(find("stats", "kernel_stats.csv"))))
+with open(os.path.join(OUT, f"{tag}_bench_50kx30k_kernel_stats.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow([f"# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline (50k cells x 30k genes, 1 warmup + 3 timed steps): {note}; "
+                "library kernels only (torch's own elementwise/index kernels of the harness are omitted)"])
+    w.writerow(rows[0])
+    for r in rows[1:]:
+        if ours(r[0]):
+            w.writerow(r)
+
+# ---- counters: average per dispatch, per kernel
+acc = defaultdict(lambda: [0, 0.0, 0.0])
+for sub in ("fetch", "write", "sq"):
+    with open(find(sub, "counter_collection.csv")) as f:
+        for r in csv.DictReader(f):
+            if not ours(r["Kernel_Name"]):
+                continue
+            a = acc[(r["Counter_Name"], r["Kernel_Name"])]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+            a[2] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+with open(os.path.join(OUT, f"{tag}_bench_50kx30k_pmc.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow([f"# {note}. Separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_* set), each with --kernel-trace, of: python bench.py "
+                "--no-cpu-baseline --steps 1 --warmup 0 (tools/profile_round.sh). FETCH/WRITE unit = KiB per dispatch; gfx950 correction: HBM-side "
+                "read bytes = 2*FETCH_SIZE*1024 (calibrated on k_velocity_chain in round-1 profiles). SQ_* summed over the dispatch; "
+                "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count in units of 4 clocks."])
+    w.writerow(["Counter", "Kernel", "Dispatches", "AvgCounterPerDispatch", "AvgDurationNs"])
+    for (cn, kn), (n, v, d) in sorted(acc.items()):
+        w.writerow([cn, kn, n, v / n, d / n])
+src = os.path.join(ROOT, "gpurun_out", f"{tag}_bench_line.json")
+if os.path.exists(src):
+    shutil.copy(src, os.path.join(OUT, f"{tag}_bench_line.json"))
+print("wrote profiles/%s_*" % tag)

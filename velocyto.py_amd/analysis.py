@@ -98,6 +98,9 @@ class VelocytoLoom(PreprocessMixin):
     def __setattr__(self, name: str, value) -> None:
         if name in _MATRIX_ATTRS:
             self._host.pop(name, None)
+            count_layer = value if isinstance(value, ops.CountMatrix) and name in ("S", "U") else None    # device uint16 layer as is
+            if count_layer is not None:
+                value = count_layer.to_float(self._dtype)
             self._dev[name] = value if isinstance(value, CellMatrix) else CellMatrix.from_genes_major(np.asarray(value), self._dtype)
             st = self.__dict__
             if name in ("S", "U"):
@@ -106,7 +109,9 @@ class VelocytoLoom(PreprocessMixin):
                 counts = st.setdefault("_counts", {})
                 counts.pop(name, None)
                 st.setdefault("_sz_scale", {}).pop(name + "_sz", None)
-                if isinstance(value, np.ndarray) and ops.CountMatrix.representable(value):
+                if count_layer is not None:
+                    counts[name] = count_layer
+                elif isinstance(value, np.ndarray) and ops.CountMatrix.representable(value):
                     counts[name] = ops.CountMatrix.from_genes_major(value)
             elif name in ("S_sz", "U_sz"):
                 st.setdefault("_sz_scale", {}).pop(name, None)       # assigned by hand: no longer factor * counts
