@@ -136,7 +136,9 @@ def sample_neighbors_device(embedding, n_neighbors, sampled_fraction, dev, seed=
     keys = torch.log(torch.rand((idx.shape[0], n1), generator=gen, device=dev, dtype=torch.float64)) / p[None, :]
     m = int(sampled_fraction * n1)
     sel = torch.topk(keys, m, dim=1).indices
-    return torch.gather(idx, 1, sel).contiguous(), idx
+    # the order of a cell's sampled neighbours carries no meaning: keep each row sorted by neighbour index, so that column
+    # tiles of wide lists (nrndm > 256) cover the same index ranges for adjacent cells
+    return torch.sort(torch.gather(idx, 1, sel), dim=1).values.contiguous(), idx
 
 
 class Pipeline:

@@ -84,8 +84,7 @@ int vcy_coldeltacor_partial(const void *e, const void *d, const int32_t *ixs, vo
  * the velocity chain (analysis.py:1346, 1369, 1399, 1538, 1575-1601; constant_velocity assumption),
  *     dmat = sign(D) f(|D| + psc),  D = (Sx + used_dt * dt_shift * (Ux - (gamma Sx + q))) - Sx,   f as `transform`,
  * so that neither velocity nor dmat is materialised.  e = Sx_sz (C, ld); Ux_sz holds rows u_row0..; gamma, q (G) float32
- * (q may be NULL).  Needs the grouped kernel; returns VCY_ERR_UNSUPPORTED otherwise (call vcy_velocity_chain +
- * vcy_coldeltacor_partial instead).  Results are bit-identical to that two-kernel sequence.                           */
+ * (q may be NULL).  Results are bit-identical to vcy_velocity_chain followed by vcy_coldeltacor_partial.             */
 int vcy_coldeltacor_partial_fused(const void *Sx_sz, const void *Ux_sz, const float *gamma, const float *q, const int32_t *ixs,
                                   void *out, const int32_t *order, int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out,
                                   int64_t u_row0, int64_t nrndm, int transform, int rules, double psc, double dt_shift,

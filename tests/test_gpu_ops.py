@@ -146,9 +146,33 @@ def test_coldeltacor_partial_fused_equals_two_kernels(ops, dtype, transform):
                                          dt_shift=0.5, used_dt=2.0, cell0=16, u_row0=16)
     np.testing.assert_allclose(torch.nan_to_num(part, nan=7.0).cpu().numpy(), torch.nan_to_num(got[16:64], nan=7.0).cpu().numpy(),
                                atol=1e-12 if dtype == "float64" else 2e-5)
-    with pytest.raises(NotImplementedError):                 # too few cells for the grouped kernel: caller uses the two-kernel path
-        ops.coldeltacor_partial_fused(ops.CellMatrix(S.t[:8].contiguous(), G), ops.CellMatrix(U.t[:8].contiguous(), G), gam, None,
-                                      ixs[:8] % 8, tr)
+    # too few cells for the grouped kernel: the one-cell-per-workgroup kernel builds d[c] the same way (same values,
+    # other summation order)
+    S8, U8 = ops.CellMatrix(S.t[:8].contiguous(), G), ops.CellMatrix(U.t[:8].contiguous(), G)
+    small = ops.coldeltacor_partial_fused(S8, U8, gam, q, ixs[:8] % 8, tr, ops.RULES_PARTIAL, psc)
+    dm8 = ops.velocity_chain(S8, U8, gam, q, want=("dmat",), transform=tr, psc=psc)["dmat"]
+    ref8 = ops.coldeltacor_partial(S8, dm8, ixs[:8] % 8, tr, ops.RULES_PARTIAL, psc)
+    assert torch.equal(torch.nan_to_num(small, nan=7.0), torch.nan_to_num(ref8, nan=7.0))
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_coldeltacor_partial_wide_lists_are_tiled(ops, oracle, dtype):
+    """nrndm > 256: the grouped kernel walks the list in column tiles (one launch each) on index-sorted rows and the
+    wrapper restores the caller's column order; duplicates and unsorted rows included."""
+    rng = np.random.default_rng(23)
+    G, C, nr = 500, 96, 700
+    e, d = rng.gamma(2.0, 1.0, (G, C)) * (rng.random((G, C)) < 0.7), rng.normal(size=(G, C))
+    ixs = rng.integers(0, C, (C, nr))
+    want = oracle.coldeltacor_partial_compact(e, d, ixs, "sqrt", 1e-10)
+    E, D = ops.CellMatrix.from_genes_major(e, dtype), ops.CellMatrix.from_genes_major(d, dtype)
+    got = ops.coldeltacor_partial(E, D, ixs, ops.SQRT, ops.RULES_PARTIAL, 1e-10).cpu().numpy()
+    ok = ~np.isnan(want)
+    assert np.array_equal(np.isnan(got), ~ok)
+    np.testing.assert_allclose(got[ok], want[ok], atol=1e-10 if dtype == "float64" else 5e-5)
+    srt = np.sort(ixs, axis=1)
+    got_sorted = ops.coldeltacor_partial(E, D, srt, ops.SQRT, ops.RULES_PARTIAL, 1e-10).cpu().numpy()
+    np.testing.assert_array_equal(np.nan_to_num(np.take_along_axis(got_sorted, np.argsort(np.argsort(ixs, axis=1, kind="stable"), axis=1, kind="stable"), 1), nan=7.0),
+                                  np.nan_to_num(got, nan=7.0))
 
 
 def test_coldeltacor_partial_edge_shapes(ops, oracle):

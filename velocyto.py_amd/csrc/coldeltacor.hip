@@ -71,6 +71,28 @@ template <typename T> __device__ __forceinline__ T pearson_from_moments(double s
     return (T)(cov / sqrt(va * vb));  // va == 0 -> 0/0 = NaN, like the reference's 0 * inf
 }
 
+// Optional fusion of the velocity chain into the staging of d[c] (stage C folded into stage D): instead of reading
+// a materialised dmat row, the group's members compute it on the fly from Ux, Sx (= e), gamma and q,
+//     dmat = sign(D) f(|D| + psc),  D = (Sx + used_dt * dt_shift * (Ux - (gamma Sx + q))) - Sx
+// (analysis.py:1346, 1369, 1399, 1538, 1575-1601; identical arithmetic to k_velocity_chain), which removes one
+// 6 GB write + read per pass at 50k x 30k.  Ux == nullptr: d is read as given.
+template <typename T> struct FuseArgs {
+    const T *Ux;
+    const float *gamma, *q;
+    T dt_shift, used_dt;
+};
+
+template <typename T, int TR> __device__ __forceinline__ T fused_dmat(T s, T u, float gm, float qq, T dt_shift, T used_dt, T psc)
+{
+    const T upred = (T)gm * s + (T)qq;
+    const T ds = dt_shift * (u - upred);
+    const T D = (s + used_dt * ds) - s;
+    if (TR == VCY_LINEAR) return D;
+    const T a = fabs(D) + psc;
+    const T f = (TR == VCY_SQRT) ? fast_sqrt<T>(a) : fast_log10<T>(a);
+    return D > T(0) ? f : (D < T(0) ? -f : T(0) * f);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Partial kernel: one workgroup per cell c.  Genes are walked in chunks of `gchunk`; the chunk of
 // e[c] and d[c] is staged in LDS (2 * gchunk * sizeof(T) bytes), then each WAVE takes neighbours
@@ -81,7 +103,7 @@ template <typename T, int TR, int RULES>
 __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, const T *__restrict__ d,
                                                        const int32_t *__restrict__ ixs, T *__restrict__ out,
                                                        const int32_t *__restrict__ order, int G, int64_t ld,
-                                                       int64_t cell0, int64_t d_row0, int C_out, int nrndm, int gchunk, T psc)
+                                                       int64_t cell0, int64_t d_row0, int C_out, int nrndm, int gchunk, T psc, FuseArgs<T> fuse)
 {
     using V = typename Vec<T>::type;
     constexpr int N = Vec<T>::N;
@@ -99,7 +121,7 @@ __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, c
     const int cl = order ? order[pos] : pos;                      // local output row
     const int64_t c = cell0 + cl;
     const T *erow_c = e + c * ld;
-    const T *drow_c = d + (c - d_row0) * ld;
+    const T *drow_c = (fuse.Ux ? fuse.Ux : d) + (c - d_row0) * ld;          // fused: the cell's Ux row, d[c] is built while staging
 
     for (int n = tid; n < 3 * nrndm; n += blockDim.x) acc[n] = T(0);
     double sb = 0.0, sbb = 0.0;
@@ -110,7 +132,16 @@ __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, c
         __syncthreads();  // previous chunk fully consumed (also orders the acc zeroing)
         for (int v = tid; v < nvec; v += blockDim.x) {
             const V ev = reinterpret_cast<const V *>(erow_c + g0)[v];
-            const V dv = reinterpret_cast<const V *>(drow_c + g0)[v];
+            V dv = reinterpret_cast<const V *>(drow_c + g0)[v];
+            if (fuse.Ux) {
+                const T *ep = reinterpret_cast<const T *>(&ev);
+                T *dq = reinterpret_cast<T *>(&dv);
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    const int g = g0 + v * N + k;
+                    dq[k] = fused_dmat<T, TR>(ep[k], dq[k], fuse.gamma[g], fuse.q ? fuse.q[g] : 0.f, fuse.dt_shift, fuse.used_dt, psc);
+                }
+            }
             reinterpret_cast<V *>(ec)[v] = ev;
             reinterpret_cast<V *>(dc)[v] = dv;
             const T *dp = reinterpret_cast<const T *>(&dv);
@@ -118,7 +149,9 @@ __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, c
             for (int k = 0; k < N; ++k) { sb += (double)dp[k]; sbb += (double)dp[k] * (double)dp[k]; }
         }
         for (int g = nvec * N + tid; g < gl; g += blockDim.x) {  // < N scalar tail elements
-            const T ev = erow_c[g0 + g], dv = drow_c[g0 + g];
+            const T ev = erow_c[g0 + g];
+            T dv = drow_c[g0 + g];
+            if (fuse.Ux) dv = fused_dmat<T, TR>(ev, dv, fuse.gamma[g0 + g], fuse.q ? fuse.q[g0 + g] : 0.f, fuse.dt_shift, fuse.used_dt, psc);
             ec[g] = ev; dc[g] = dv;
             sb += (double)dv; sbb += (double)dv * (double)dv;
         }
@@ -208,33 +241,11 @@ __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, c
 //      over the wave and adds into acc[pair] (owned by that wave: deterministic, no atomics).
 constexpr int GRP_MAX_NV = 6;
 
-// Optional fusion of the velocity chain into the staging of d[c] (stage C folded into stage D): instead of reading
-// a materialised dmat row, the group's members compute it on the fly from Ux, Sx (= e), gamma and q,
-//     dmat = sign(D) f(|D| + psc),  D = (Sx + used_dt * dt_shift * (Ux - (gamma Sx + q))) - Sx
-// (analysis.py:1346, 1369, 1399, 1538, 1575-1601; identical arithmetic to k_velocity_chain), which removes one
-// 6 GB write + read per pass at 50k x 30k.  Ux == nullptr: d is read as given.
-template <typename T> struct FuseArgs {
-    const T *Ux;
-    const float *gamma, *q;
-    T dt_shift, used_dt;
-};
-
-template <typename T, int TR> __device__ __forceinline__ T fused_dmat(T s, T u, float gm, float qq, T dt_shift, T used_dt, T psc)
-{
-    const T upred = (T)gm * s + (T)qq;
-    const T ds = dt_shift * (u - upred);
-    const T D = (s + used_dt * ds) - s;
-    if (TR == VCY_LINEAR) return D;
-    const T a = fabs(D) + psc;
-    const T f = (TR == VCY_SQRT) ? fast_sqrt<T>(a) : fast_log10<T>(a);
-    return D > T(0) ? f : (D < T(0) ? -f : T(0) * f);
-}
-
 template <typename T, int TR, int RULES, int GC>
 __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restrict__ e, const T *__restrict__ d,
                                                                const int32_t *__restrict__ ixs, T *__restrict__ out,
                                                                const int32_t *__restrict__ order, int G, int64_t ld, int64_t cell0,
-                                                               int64_t d_row0, int C_out, int nrndm, int npad, T psc, FuseArgs<T> fuse)
+                                                               int64_t d_row0, int C_out, int nrndm, int stride, int npad, T psc, FuseArgs<T> fuse)
 {
     using V = typename Vec<T>::type;
     constexpr int N = Vec<T>::N;
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
         unsigned long long key = ~0ull;
         if (t < npairs) {
             const int m = t / nrndm, n = t - m * nrndm;
-            const unsigned i = (unsigned)ixs[(int64_t)s_cells[m] * nrndm + n];
+            const unsigned i = (unsigned)ixs[(int64_t)s_cells[m] * stride + n];        // stride: row pitch of ixs / out (a tile of a wider list)
             key = ((unsigned long long)i << 16) | ((unsigned long long)m << 12) | (unsigned)n;
         }
         keys[t] = key;
@@ -466,7 +477,7 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
     for (int p = tid; p < npairs; p += blockDim.x) {
         const unsigned long long key = keys[p];
         const int m = (int)((key >> 12) & 15), n = (int)(key & 4095);
-        out[(int64_t)s_cells[m] * nrndm + n] = pearson_from_moments<T>((double)acc[3 * p], (double)acc[3 * p + 1], (double)acc[3 * p + 2],
+        out[(int64_t)s_cells[m] * stride + n] = pearson_from_moments<T>((double)acc[3 * p], (double)acc[3 * p + 1], (double)acc[3 * p + 2],
                                                                      s_sb[m], s_sbb[m], (double)G);
     }
 }
@@ -592,23 +603,37 @@ static int launch_partial(const void *e, const void *d, const int32_t *ixs, void
 {
     constexpr int N = Vec<T>::N;
     if (g_group_pref < 0) { const char *ev = getenv("VCY_CDC_GROUP"); g_group_pref = ev ? atoi(ev) : 8; }
-    {   // grouped variant: cells adjacent in the schedule order share neighbour rows out of LDS
+    {   // grouped variant: cells adjacent in the schedule order share neighbour rows out of LDS.  Neighbour lists wider than
+        // one workgroup's LDS budget (8 x 256 pairs) are walked in column TILES of equal width, one launch per tile,
+        // each writing its own columns of `out` (the reference default n_neighbors = C/5, sampled_fraction 0.3 gives
+        // nrndm = 3000: 12 tiles; rows of ixs sorted by neighbour index make the tiles of adjacent cells overlap)
         constexpr int GC = 8;
-        const int64_t maxpairs = GC * nrndm;
+        constexpr int64_t TILE_MAX = 256;
+        if (g_group_pref < 0) { const char *ev = getenv("VCY_CDC_GROUP"); g_group_pref = ev ? atoi(ev) : GC; }
+        const size_t budget_g = (size_t)(g_lds_budget > 155648 ? 155648 : g_lds_budget);
+        int64_t ntiles = (nrndm + TILE_MAX - 1) / TILE_MAX, tile = 0;
         int npad = 2;
-        while (npad < maxpairs) npad <<= 1;
-        const size_t lds_g = (size_t)2 * GC * GRP_MAX_NV * 64 * N * sizeof(T) + (size_t)npad * 8 + sizeof(T) * 3 * ((maxpairs + 1) & ~1) +
-                             sizeof(int) * ((maxpairs + 3) & ~1) + (64 + 2 * GC) * sizeof(double) + (GC + 18) * sizeof(int) + 16;
-        if (g_group_pref == GC && nrndm <= 4095 && nrndm >= 8 && C_out >= 4 * GC && lds_g <= (size_t)(g_lds_budget > 155648 ? 155648 : g_lds_budget)) {
+        size_t lds_g = 0;
+        for (;; ++ntiles) {                                  // fewest equal-width tiles whose sort keys + accumulators fit (f64 needs narrower ones)
+            tile = (nrndm + ntiles - 1) / ntiles;
+            const int64_t maxpairs = GC * tile;
+            for (npad = 2; npad < maxpairs; npad <<= 1) {}
+            lds_g = (size_t)2 * GC * GRP_MAX_NV * 64 * N * sizeof(T) + (size_t)npad * 8 + sizeof(T) * 3 * ((maxpairs + 1) & ~1) +
+                    sizeof(int) * ((maxpairs + 3) & ~1) + (64 + 2 * GC) * sizeof(double) + (GC + 18) * sizeof(int) + 16;
+            if (lds_g <= budget_g || tile <= 16) break;
+        }
+        if (g_group_pref == GC && nrndm >= 8 && C_out >= 4 * GC && nrndm <= 0x7fffffff / 2 && lds_g <= budget_g) {
             auto kern = k_cdc_partial_grouped<T, TR, RULES, GC>;
             VCY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
             const unsigned groups = (unsigned)(((C_out + GC - 1) / GC + 7) / 8 * 8);
-            hipLaunchKernelGGL(kern, dim3(groups), dim3(1024), lds_g, st, (const T *)e, (const T *)d, ixs, (T *)out, order, (int)G, ld, cell0, d_row0,
-                               (int)C_out, (int)nrndm, npad, (T)psc, fuse);
-            VCY_LAUNCH_CHECK();
+            for (int64_t n0 = 0; n0 < nrndm; n0 += tile) {
+                const int64_t w = nrndm - n0 < tile ? nrndm - n0 : tile;
+                hipLaunchKernelGGL(kern, dim3(groups), dim3(1024), lds_g, st, (const T *)e, (const T *)d, ixs + n0, (T *)out + n0, order, (int)G, ld,
+                                   cell0, d_row0, (int)C_out, (int)w, (int)nrndm, npad, (T)psc, fuse);
+                VCY_LAUNCH_CHECK();
+            }
             return VCY_OK;
         }
-        if (fuse.Ux) return fail(VCY_ERR_UNSUPPORTED, "%s: the fused velocity-chain form needs the grouped kernel (8 <= nrndm, 8*nrndm pairs within the LDS budget, >= 32 cells)", "coldeltacor_partial_fused");
     }
     const int quantum = 64 * N;  // one wave-instruction worth of elements
     const size_t fixed = sizeof(T) * 3 * ((nrndm + 1) & ~1) + 32 * sizeof(double);
@@ -625,7 +650,7 @@ static int launch_partial(const void *e, const void *d, const int32_t *ixs, void
     VCY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int threads = (nrndm >= 16) ? 1024 : (nrndm >= 8 ? 512 : 256);
     hipLaunchKernelGGL(kern, dim3((unsigned)((C_out + 7) / 8 * 8)), dim3(threads), lds, st, (const T *)e, (const T *)d, ixs, (T *)out, order,
-                       (int)G, ld, cell0, d_row0, (int)C_out, (int)nrndm, (int)gchunk, (T)psc);
+                       (int)G, ld, cell0, d_row0, (int)C_out, (int)nrndm, (int)gchunk, (T)psc, fuse);
     VCY_LAUNCH_CHECK();
     return VCY_OK;
 }

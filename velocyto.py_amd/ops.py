@@ -198,6 +198,19 @@ def _as_i32(ixs, dev) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- stage D
+TILE_COLS = 256      # widest neighbour list one workgroup of the grouped kernel sorts in LDS (csrc/coldeltacor.hip)
+
+
+def _sorted_rows(ix: torch.Tensor, out: torch.Tensor):
+    """Lists wider than one tile are walked in column tiles; a pair's value does not depend on its column, so the rows are
+    sorted by neighbour index first (adjacent cells then meet the same rows in the same tile) and the results are put
+    back in the caller's column order.  Returns (ixs to launch with, (perm, sorted-order buffer) or None, caller's out)."""
+    if ix.shape[1] <= TILE_COLS or bool((ix[:, 1:] >= ix[:, :-1]).all()):
+        return ix, None, out
+    srt, perm = torch.sort(ix, dim=1)
+    return srt.contiguous(), (perm, torch.empty_like(out)), out
+
+
 def coldeltacor_partial(e: CellMatrix, d: CellMatrix, ixs, transform: int, rules: int = RULES_PARTIAL, psc: float = 0.0,
                         cell0: int = 0, order: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                         d_row0: int = 0, validate: bool = True) -> torch.Tensor:
@@ -215,18 +228,18 @@ def coldeltacor_partial(e: CellMatrix, d: CellMatrix, ixs, transform: int, rules
     if order is not None:
         order = order.to(device=e.t.device, dtype=torch.int32).contiguous()
         assert order.numel() == C_out
-    _lib.check(_lib.lib().vcy_coldeltacor_partial(e.t.data_ptr(), d.t.data_ptr(), ix.data_ptr(), out.data_ptr(), _p(order),
+    ix, perm, user_out = _sorted_rows(ix, out)
+    _lib.check(_lib.lib().vcy_coldeltacor_partial(e.t.data_ptr(), d.t.data_ptr(), ix.data_ptr(), (out if perm is None else perm[1]).data_ptr(), _p(order),
                                                   e.C, e.G, e.ld, cell0, C_out, d_row0, nrndm, transform, rules, float(psc),
                                                   e.code, _stream()), "coldeltacor_partial")
-    return out
+    return out if perm is None else user_out.scatter_(1, perm[0], perm[1])
 
 
 def coldeltacor_partial_fused(Sx: CellMatrix, Ux: CellMatrix, gamma: torch.Tensor, q: Optional[torch.Tensor], ixs, transform: int,
                               rules: int = RULES_PARTIAL, psc: float = 0.0, dt_shift: float = 1.0, used_dt: float = 1.0, cell0: int = 0,
                               u_row0: int = 0, order: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                               validate: bool = True) -> torch.Tensor:
-    """Stage C + D in one launch: correlations against the dmat the velocity chain would produce (vcy_coldeltacor_partial_fused).
-    Raises NotImplementedError when the grouped kernel cannot take the request (use velocity_chain + coldeltacor_partial)."""
+    """Stage C + D in one launch: correlations against the dmat the velocity chain would produce (vcy_coldeltacor_partial_fused)."""
     assert Sx.ld == Ux.ld and Sx.dtype == Ux.dtype and Sx.G == Ux.G
     dev = Sx.t.device
     ix = _as_i32(ixs, dev)
@@ -240,10 +253,12 @@ def coldeltacor_partial_fused(Sx: CellMatrix, Ux: CellMatrix, gamma: torch.Tenso
     q = None if q is None else q.to(device=dev, dtype=torch.float32).contiguous()
     if order is not None:
         order = order.to(device=dev, dtype=torch.int32).contiguous()
-    _lib.check(_lib.lib().vcy_coldeltacor_partial_fused(Sx.t.data_ptr(), Ux.t.data_ptr(), gamma.data_ptr(), _p(q), ix.data_ptr(), out.data_ptr(),
+    ix, perm, user_out = _sorted_rows(ix, out)
+    _lib.check(_lib.lib().vcy_coldeltacor_partial_fused(Sx.t.data_ptr(), Ux.t.data_ptr(), gamma.data_ptr(), _p(q), ix.data_ptr(),
+                                                        (out if perm is None else perm[1]).data_ptr(),
                                                         _p(order), Sx.C, Sx.G, Sx.ld, cell0, C_out, u_row0, nrndm, transform, rules, float(psc),
                                                         float(dt_shift), float(used_dt), Sx.code, _stream()), "coldeltacor_partial_fused")
-    return out
+    return out if perm is None else user_out.scatter_(1, perm[0], perm[1])
 
 
 def coldeltacor_full(e: CellMatrix, d: CellMatrix, transform: int, psc: float = 0.0, cell0: int = 0,
