@@ -455,3 +455,56 @@ def test_next_rows_grid_arrows_filters_builders(vcy, golden, oracle):
         ref = g[key]
         assert tr.shape == ref.shape
         np.testing.assert_allclose(np.nan_to_num(tr), np.nan_to_num(ref), rtol=1e-9, atol=1e-14)
+
+
+def test_small_helpers_of_the_reference_modules(vcy, golden):
+    """The reference's remaining module-level helpers: mutual-kNN smoothing weights, one-gene fits, cluster averages,
+    index / weight utilities, serialization entry points."""
+    import os
+    import tempfile
+    from velocyto_amd import analysis, estimation, neighbors, serialization
+    rng = np.random.default_rng(3)
+    X = rng.normal(size=(12, 90))                                  # (genes, cells)
+    w, knn = neighbors.knn_smooth_weights(X, k_search=12, k_mutual=5)
+    w = sparse.csr_matrix(w)
+    assert w.shape == (90, 90) and np.allclose(np.asarray(w.sum(1)).ravel(), 1)
+    assert knn.shape == (90, 90) and (np.diff(knn.indptr) == 12).all()
+    mk = neighbors.make_mutual(knn)
+    assert abs(mk - mk.T).max() == 0 and mk.nnz <= knn.nnz
+    top = neighbors.take_top(mk, 5)
+    assert max(len(r) for r in top.rows) <= 5 and all(list(d) == sorted(d) for d in top.data)
+    d, c = neighbors.min_n(np.array([3., 1., 2.]), np.array([7, 8, 9]), 2)
+    assert list(d) == [1., 2.] and list(c) == [8, 9]
+    # one-gene fits == row 0 of the matrix forms
+    g = golden("fits")
+    y, x = g["Y"][3], g["X"][3]
+    assert estimation._fit1_slope(y, x) == pytest.approx(float(estimation.fit_slope(g["Y"], g["X"])[3]), rel=1e-6)
+    m, q = estimation._fit1_slope_offset(y, x)
+    M, Q = estimation.fit_slope_offset(g["Y"], g["X"])
+    assert m == pytest.approx(float(M[3]), rel=1e-5, abs=1e-7) and q == pytest.approx(float(Q[3]), rel=1e-5, abs=1e-7)
+    # cluster averages against numpy
+    S, U = rng.poisson(2.0, (30, 200)).astype(float), rng.poisson(1.0, (30, 200)).astype(float)
+    ix = rng.integers(0, 3, 200)
+    ix[:10] = 3                                                    # a cluster of 10 cells (< size_limit)
+    Ua, Sa = estimation.clusters_stats(U, S, np.arange(4), ix)
+    for i in range(3):
+        np.testing.assert_allclose(Sa[:, i], S[:, ix == i].mean(1), rtol=1e-12)
+        np.testing.assert_allclose(Ua[:, i], U[:, ix == i].mean(1), rtol=1e-12)
+    np.testing.assert_allclose(Sa[:, 3], S.mean(1), rtol=1e-12)
+    a, b = np.array([5, 3, 9, 1]), np.array([9, 1, 5, 3])
+    assert np.array_equal(a[analysis.ixs_thatsort_a2b(a, b)], b)
+    W = sparse.csr_matrix(np.array([[0, 1., 1.], [1., 0, 1.], [1., 1., 0]]))
+    sc = analysis.scale_to_match_median(W, np.array([1., 2., 4.]))
+    np.testing.assert_allclose(sc.data, [1.0, 0.75, 1.0, 0.625, 1.0, 0.75])
+    # serialization round trip through the reference's entry-point names
+    p = golden("pipeline")
+    vlm = vcy.analysis.VelocytoLoom.from_arrays(p["S"], p["U"], dtype="float64")
+    vlm.normalize("both")
+    vlm.perform_PCA(n_components=5)
+    with tempfile.TemporaryDirectory() as td:
+        fn = os.path.join(td, "ck.hdf5")
+        serialization.dump_hdf5(vlm, fn)
+        back = serialization.load_hdf5(fn, dtype="float64")
+    np.testing.assert_array_equal(back.S_sz, vlm.S_sz)
+    np.testing.assert_allclose(back.pcs, vlm.pcs)
+    np.testing.assert_allclose(back.pca.explained_variance_ratio_, vlm.pca.explained_variance_ratio_)

@@ -17,7 +17,7 @@ def build(force: bool = False) -> str:
 
 def __getattr__(name):  # lazy: importing the package must not need torch/GPU
     import importlib
-    if name in ("ops", "estimation", "neighbors", "diffusion", "analysis", "speedboosted", "distributed", "loom_io"):
+    if name in ("ops", "estimation", "neighbors", "diffusion", "analysis", "speedboosted", "distributed", "loom_io", "serialization", "preprocess"):
         return importlib.import_module(f"velocyto_amd.{name}")
     if name == "VelocytoLoom":
         return importlib.import_module("velocyto_amd.analysis").VelocytoLoom

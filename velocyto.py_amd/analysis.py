@@ -36,7 +36,7 @@ from . import ops
 from .diffusion import Diffusion
 from .neighbors import BalancedKNN, connectivity_to_weights, knn_distance_matrix
 from .ops import CellMatrix
-from .preprocess import PreprocessMixin
+from .preprocess import PreprocessMixin, colormap_fun  # noqa: F401  (colormap_fun is module-level in the reference too)
 
 _MATRIX_ATTRS = frozenset(["S", "U", "A", "S_sz", "U_sz", "S_norm", "U_norm", "Sx", "Ux", "Sx_sz", "Ux_sz", "Sx_norm", "Ux_norm",
                            "Upred", "velocity", "delta_S", "delta_S_rndm", "Sx_sz_t", "Sx_t"])
@@ -650,17 +650,52 @@ class VelocytoLoom(PreprocessMixin):
         import pickle
         import zlib
         from .loom_io import hdf5_dump
+        exclude = set(kwargs.get("exclude", ()) or ())
         out = {}
         for name in self._dev:
-            out[name] = np.ascontiguousarray(getattr(self, name))
+            if name not in exclude:
+                out[name] = np.ascontiguousarray(getattr(self, name))
         for name, val in self.__dict__.items():
-            if name.startswith("_") or isinstance(val, torch.Tensor):
+            if name.startswith("_") or name in exclude or isinstance(val, torch.Tensor):
                 continue                                              # device-side caches are rebuilt on demand
             if isinstance(val, np.ndarray) and val.dtype.kind in "fiub":
                 out[name] = val
             else:
                 out["&" + name] = np.frombuffer(zlib.compress(pickle.dumps(val, protocol=2), 9), dtype=np.uint8)
         hdf5_dump(filename, out)
+
+
+    def reload_raw(self, substitute: bool = False) -> None:
+        """analysis.py:2314-2342: read the layers of ``loom_filepath`` again, either over S, U, A, ca, ra (substitute) or
+        next to them as ``raw_*``."""
+        from .loom_io import read_loom
+        layers, ca, ra = read_loom(self.loom_filepath)
+        if substitute:
+            self._init_layers(layers["spliced"], layers["unspliced"], layers.get("ambiguous"), ca, ra)
+        else:
+            self.raw_S, self.raw_U, self.raw_A = layers["spliced"], layers["unspliced"], layers.get("ambiguous")
+            self.raw_initial_cell_size, self.raw_initial_Ucell_size = self.raw_S.sum(0), self.raw_U.sum(0)
+            self.raw_ca, self.raw_ra = dict(ca), dict(ra)
+
+
+def ixs_thatsort_a2b(a: np.ndarray, b: np.ndarray, check_content: bool = True) -> np.ndarray:
+    """analysis.py:2345-2350: indices that put ``a`` in the order of ``b`` (same content)."""
+    if check_content:
+        assert len(np.intersect1d(a, b)) == len(a), f"The two arrays are not matching"
+    return np.argsort(a)[np.argsort(np.argsort(b))]
+
+
+def scale_to_match_median(sparse_matrix: sparse.csr_matrix, genes_total: np.ndarray) -> sparse.csc_matrix:
+    """analysis.py:2392-2447: every stored weight of row i is scaled by min(1, median(t) / t) with t = the totals of the
+    row's stored columns (returned with the csr index arrays reinterpreted as csc, exactly as the reference does)."""
+    m = sparse.csr_matrix(sparse_matrix)
+    genes_total = np.asarray(genes_total, dtype=np.float64)
+    new = np.zeros(m.data.shape)
+    for i in range(genes_total.shape[0]):
+        lo, hi = m.indptr[i], m.indptr[i + 1]
+        t = genes_total[m.indices[lo:hi]]
+        new[lo:hi] = np.minimum(1, np.median(t) / t) * m.data[lo:hi]
+    return sparse.csc_matrix((new, m.indices, m.indptr), shape=m.shape, copy=True)
 
 
 def _fill_diagonal_zero(m: torch.Tensor) -> None:

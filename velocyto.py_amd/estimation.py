@@ -167,15 +167,49 @@ def _weighted_offset_device(Yd, Xd, weight_mode: int, wargs: dict, fixperc_q: bo
     return ops.fit_weighted(Yd, Xd, weight_mode, fit_offset=True, box_q=True, lo_gamma=1e-8, up_gamma_default=20.0, up_gamma=up, **wargs)
 
 
-def clusters_stats(U: np.ndarray, S: np.ndarray, clusters_uid: np.ndarray, cluster_ix: np.ndarray, size_limit: int = 40
-                   ) -> Tuple[np.ndarray, np.ndarray]:
-    """estimation.py:369-389: per-cluster averages (gene-filter helper, out of the hot path; NumPy)."""
-    U_avgs = np.zeros((S.shape[0], len(clusters_uid)))
-    S_avgs = np.zeros((S.shape[0], len(clusters_uid)))
+def clusters_stats(U, S, clusters_uid: np.ndarray, cluster_ix: np.ndarray, size_limit: int = 40, dtype=None) -> Tuple[np.ndarray, np.ndarray]:
+    """estimation.py:369-389: per-cluster gene averages; clusters of at most `size_limit` cells report the overall average.
+    One masked streaming pass per cluster on the device (``vcy_gene_stats``).  U, S: (genes, cells) arrays or CellMatrix."""
+    Ud, Sd = CellMatrix.from_genes_major(U, dtype), CellMatrix.from_genes_major(S, dtype)
+    C, G = Sd.C, Sd.G
+    cluster_ix = np.asarray(cluster_ix)
+    U_avgs, S_avgs = np.zeros((G, len(clusters_uid))), np.zeros((G, len(clusters_uid)))
+    overall = None
     for i, _ in enumerate(clusters_uid):
         sel = cluster_ix == i
-        if np.sum(sel) > size_limit:
-            U_avgs[:, i], S_avgs[:, i] = U[:, sel].mean(1), S[:, sel].mean(1)
+        n = int(np.sum(sel))
+        if n > size_limit:
+            U_avgs[:, i] = ops.gene_stats(Ud, cell_mask=sel)[0].cpu().numpy() / n
+            S_avgs[:, i] = ops.gene_stats(Sd, cell_mask=sel)[0].cpu().numpy() / n
         else:
-            U_avgs[:, i], S_avgs[:, i] = U.mean(1), S.mean(1)
+            if overall is None:
+                overall = (ops.gene_stats(Ud)[0].cpu().numpy() / C, ops.gene_stats(Sd)[0].cpu().numpy() / C)
+            U_avgs[:, i], S_avgs[:, i] = overall
     return U_avgs, S_avgs
+
+
+# --------------------------------------------------------------------------- one-gene forms (estimation.py:173-264)
+def _one(v) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(v, dtype=np.float64)[None, :])
+
+
+def _fit1_slope(y: np.ndarray, x: np.ndarray) -> float:
+    """estimation.py:173-188 through the per-gene kernel (a (1, cells) problem)."""
+    return float(fit_slope(_one(y), _one(x))[0])
+
+
+def _fit1_slope_weighted(y: np.ndarray, x: np.ndarray, w: np.ndarray, limit_gamma: bool = False, bounds: Tuple[float, float] = (0, 20)) -> float:
+    """estimation.py:191-209."""
+    return float(np.asarray(fit_slope_weighted(_one(y), _one(x), _one(w), limit_gamma=limit_gamma, bounds=bounds)).ravel()[0])
+
+
+def _fit1_slope_weighted_offset(y: np.ndarray, x: np.ndarray, w: np.ndarray, fixperc_q: bool = False, limit_gamma: bool = False) -> Tuple[float, float]:
+    """estimation.py:212-241."""
+    m, q = fit_slope_weighted_offset(_one(y), _one(x), _one(w), fixperc_q=fixperc_q, return_R2=False, limit_gamma=limit_gamma)[:2]
+    return float(m[0]), float(q[0])
+
+
+def _fit1_slope_offset(y: np.ndarray, x: np.ndarray, fixperc_q: bool = False) -> Tuple[float, float]:
+    """estimation.py:244-264."""
+    m, q = fit_slope_offset(_one(y), _one(x), fixperc_q=fixperc_q)
+    return float(m[0]), float(q[0])

@@ -20,7 +20,7 @@ from . import ops
 from .ops import CellMatrix
 
 __all__ = ["knn_distance_matrix", "BalancedKNN", "knn_balance", "balance_knn_loop", "balance_knn_loop_constrained",
-           "connectivity_to_weights", "convolve_by_sparse_weights"]
+           "connectivity_to_weights", "convolve_by_sparse_weights", "make_mutual", "min_n", "take_top", "knn_smooth_weights"]
 
 
 def _search_space(data: np.ndarray, metric: Optional[str]) -> Tuple[np.ndarray, bool]:
@@ -168,3 +168,38 @@ def convolve_by_sparse_weights(data, w: sparse.spmatrix, dtype=None, as_device: 
         raise ValueError(f"weights {shape} do not match {D.C} cells")
     out = ops.knn_pool(D, indptr, indices, vals)
     return out if as_device else out.to_genes_major(order="F")
+
+
+# --------------------------------------------------------------------------- mutual-kNN smoothing helpers (unused by VelocytoLoom)
+def make_mutual(knn: sparse.spmatrix) -> sparse.spmatrix:
+    """neighbors.py:379-382: element-wise minimum with the transpose, i.e. an edge survives only if both directions exist
+    (distance graph: the smaller of the two distances)."""
+    return sparse.csr_matrix(knn).minimum(sparse.csr_matrix(knn).T)
+
+
+def min_n(row_data: np.ndarray, row_indices: np.ndarray, n: int) -> Tuple[np.ndarray, np.ndarray]:
+    """neighbors.py:393-400: the n smallest stored entries of one sparse row and their column indices."""
+    i = np.argsort(row_data)[:n]
+    return row_data[i], row_indices[i]
+
+
+def take_top(matrix: sparse.spmatrix, n: int) -> sparse.lil_matrix:
+    """neighbors.py:403-411: keep the n smallest stored entries of every row (in ascending order of value)."""
+    m = sparse.csr_matrix(matrix)
+    out = sparse.lil_matrix(m.shape, dtype=m.dtype)
+    for r in range(m.shape[0]):
+        lo, hi = m.indptr[r], m.indptr[r + 1]
+        d, c = min_n(m.data[lo:hi], m.indices[lo:hi], n)
+        out.data[r], out.rows[r] = d.tolist(), c.tolist()
+    return out
+
+
+def knn_smooth_weights(matrix: np.ndarray, metric: str = "euclidean", k_search: int = 20, k_mutual: int = 10, n_jobs: int = 10
+                       ) -> Tuple[sparse.spmatrix, sparse.csr_matrix]:
+    """neighbors.py:426-451: smoothing weights from the mutual part of a kNN graph ((genes, cells) input; the search is the
+    HIP kernel).  Returns (weights, knn)."""
+    assert k_search >= k_mutual, "k_search needs to be bigger than k_mutual"
+    knn = knn_distance_matrix(np.asarray(matrix).T, metric=metric, k=k_search, mode="distance", n_jobs=n_jobs)
+    top_mknn = take_top(make_mutual(knn), k_mutual)
+    top_mknn.setdiag(1)
+    return connectivity_to_weights(top_mknn > 0), knn

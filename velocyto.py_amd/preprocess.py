@@ -83,6 +83,9 @@ class DevicePCA:
         self._pcs_dev = pcs
         return pcs.cpu().numpy()
 
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if k != "_pcs_dev"}      # checkpoints carry host arrays only
+
     def transform(self, Xcg: np.ndarray) -> np.ndarray:
         """(samples, genes) host array -> scores (host convenience, as sklearn)."""
         return (np.asarray(Xcg, dtype=np.float64) - self.mean_) @ self.components_.T
@@ -255,22 +258,8 @@ class PreprocessMixin:
     def score_cluster_expression(self, min_avg_U: float = 0.02, min_avg_S: float = 0.08) -> None:
         """analysis.py:441-454 + estimation.clusters_stats (estimation.py:369-389): per-cluster gene averages (clusters of
         at most 40 cells report the overall average), masked streaming passes on the device."""
-        uid, ix = self.cluster_uid, self.cluster_ix
-        S, U = self._layer_for_stats("S"), self._layer_for_stats("U")
-        C, G = S.C, S.G
-        size_limit = 40
-        self.U_avgs, self.S_avgs = np.zeros((G, len(uid))), np.zeros((G, len(uid)))
-        overall = None
-        for i in range(len(uid)):
-            filt = ix == i
-            n_cells = int(filt.sum())
-            if n_cells > size_limit:
-                self.U_avgs[:, i] = ops.gene_stats(U, cell_mask=filt)[0].cpu().numpy() / n_cells
-                self.S_avgs[:, i] = ops.gene_stats(S, cell_mask=filt)[0].cpu().numpy() / n_cells
-            else:
-                if overall is None:
-                    overall = (ops.gene_stats(U)[0].cpu().numpy() / C, ops.gene_stats(S)[0].cpu().numpy() / C)
-                self.U_avgs[:, i], self.S_avgs[:, i] = overall
+        from .estimation import clusters_stats
+        self.U_avgs, self.S_avgs = clusters_stats(self.dev("U"), self.dev("S"), self.cluster_uid, self.cluster_ix, size_limit=40)
         self.clu_avg_selected = (self.U_avgs.max(1) > min_avg_U) & (self.S_avgs.max(1) > min_avg_S)
 
     def robust_size_factor(self, pc: float = 0.1, which: str = "both") -> None:

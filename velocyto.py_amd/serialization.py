@@ -1,0 +1,20 @@
+"""``velocyto/serialization.py`` call surface: ``dump_hdf5`` / ``load_hdf5`` (serialization.py:44-115) on top of the
+ctypes-bound libhdf5 of ``loom_io`` (no h5py in the image).  Device matrices are written as the reference's
+(genes, cells) float64 datasets, so files round-trip between the two implementations."""
+from __future__ import annotations
+
+from typing import Any
+
+__all__ = ["dump_hdf5", "load_hdf5"]
+
+
+def dump_hdf5(obj: Any, filename: str, data_compression: int = 7, chunks=(2048, 2048), noarray_compression: int = 9, exclude_attributes=None) -> None:
+    """serialization.py:44-97 for a VelocytoLoom of this package (compression arguments are accepted; libhdf5 is driven with
+    its defaults)."""
+    obj.to_hdf5(filename, exclude=set(exclude_attributes or ()))
+
+
+def load_hdf5(filename: str, obj_class: type = None, dtype=None):
+    """serialization.py:100-115."""
+    from .analysis import load_velocyto_hdf5
+    return load_velocyto_hdf5(filename, dtype=dtype)
