@@ -288,6 +288,36 @@ def test_knn_search_blocks_and_limits(ops, oracle):
         ops.knn_search(emb, 6000)
 
 
+def test_knn_search_rowfree_fallbacks(ops, oracle):
+    """The row-free fast path (k + 8 <= 128): a thread tracks four candidates of its strided slice (j = t mod 256).
+    (a) six near neighbours in ONE slice -> that thread overflows and the workgroup rescans its slice;
+    (b) hundreds of exact duplicates -> more than eight threads overflow -> the query recomputes its row and takes the
+        radix-select path; ties must still come out in index order.  Both against the oracle, bit-exact."""
+    rng = np.random.default_rng(11)
+    C, P, k = 2600, 6, 12
+    space = rng.normal(size=(C, P)) * 5.0
+    q = 1000
+    space[300:900] = space[300]                             # 600 identical points
+    space[2000] = space[300] + 1e-4
+    planted = [7, 263, 1031, 1287, 1543, 1799, 2055]        # all in the slice of thread 7
+    for n, j in enumerate(planted):
+        space[j] = space[q] + 1e-3 * (n + 1) * np.ones(P)
+    idx, dist = ops.knn_search(space, k)
+    od, oi = oracle.knn_search(space, k)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    np.testing.assert_allclose(dist.cpu().numpy(), od, atol=1e-12)
+    assert set(oi[q][:7]) == set(planted) and (oi[2000] < 900).all() and (oi[2000] >= 300).all()
+    i2, d2 = ops.knn_search(space, k, include_self=True)
+    od2, oi2 = oracle.knn_search(space, k, include_self=True)
+    assert np.array_equal(i2.cpu().numpy(), oi2)
+    # external queries through the same path
+    qs = space[[q, 2000, 5]] + 1e-5
+    i3, d3 = ops.knn_query(space, qs, k)
+    od3, oi3 = oracle.knn_query(space, qs, k)
+    assert np.array_equal(i3.cpu().numpy(), oi3)
+    np.testing.assert_allclose(d3.cpu().numpy(), od3, atol=1e-12)
+
+
 def test_fit_slope_golden(ops, golden):
     g = golden("fits")
     for dtype, rtol in (("float64", 2e-7), ("float32", 1e-5)):

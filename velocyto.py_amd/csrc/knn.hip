@@ -17,6 +17,12 @@
 //            << 32 | index) giving exactly Ksel keys.  Then gather the candidates <= T,
 //            recompute their distances exactly in fp64, bitonic-sort (fp64 distance, index) in
 //            LDS and emit the first k.  Both paths are deterministic, ties by index.
+// ROWS = false (Ksel <= 512, C <= 2^18; the common case) never materialises the distance rows: in phase 1 every thread
+// keeps the FOUR smallest distances of its strided slice per query as sortable words (distance bits with the low `nb`
+// mantissa bits replaced by the slice position), phase 2 takes the threshold from the two smallest of every thread as
+// before and then collects the tracked words within the threshold (compared on the high bits, one step of slack, so
+// everything the exact comparison would admit is in) - no row write, no row scan.  A thread whose fourth word is within
+// the threshold may hold more: that query alone recomputes its row and takes the radix-select path.
 // The fp32 pass only has to get the candidate SET right (margin of 8 near-ties); order and
 // returned distances are fp64, matching the reference's fp64 search up to exact ties (which
 // sklearn orders arbitrarily and this kernel orders by index; with include_self the query is an
@@ -39,11 +45,11 @@ __device__ __forceinline__ uint32_t f32_key(float f)
 
 // LARGE = false: candidate arrays (fp64 distance, index)[nsort] live in LDS (k <= ~4k);
 // LARGE = true : they live in a per-workgroup slice of the global workspace (any k < C), same code.
-template <bool LARGE>
+template <bool LARGE, bool ROWS>
 __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt, const double *__restrict__ x64, const float *__restrict__ qt,
                                                      const double *__restrict__ q64, int64_t ldq, int32_t *__restrict__ idx_out,
                                                      double *__restrict__ dist_out, float *__restrict__ ws, char *__restrict__ ws_sort, int C, int P,
-                                                     int64_t ldx, int64_t q0, int Q, int k, int ksel, int nsort, int include_self)
+                                                     int64_t ldx, int64_t q0, int Q, int k, int ksel, int nsort, int include_self, int nb)
 {
     // qt/q64 == NULL: the queries are rows q0.. of the point set itself (kneighbors / kneighbors_graph of the fitted
     // data); otherwise qt (P, ldq) / q64 (Q_total, P) hold EXTERNAL query points (NearestNeighbors.kneighbors(X)) and
@@ -66,7 +72,8 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
     __shared__ unsigned hist[256];
     __shared__ float cand[512];
     __shared__ unsigned long long s_prefix;
-    __shared__ unsigned s_rank, s_count;
+    __shared__ unsigned s_rank, s_count, s_over;
+    __shared__ int s_overtid[8];
     const int tid = threadIdx.x;
     const int qb0 = blockIdx.x * KNN_QB;
     const int nq = min(KNN_QB, Q - qb0);
@@ -77,10 +84,17 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
     }
     __syncthreads();
     // ---- phase 1: distances
-    float *wrow = ws + (int64_t)qb0 * C;
-    float m0[KNN_QB], m1[KNN_QB];       // two smallest distances this thread has seen, per query
+    // ROWS: the (QB, C) distance rows of this workgroup; !ROWS: one scratch row per workgroup (fallback of a single query)
+    float *wrow = ROWS ? ws + (int64_t)qb0 * C : ws + (int64_t)blockIdx.x * C;
+    float m0[KNN_QB], m1[KNN_QB];       // ROWS: two smallest distances this thread has seen, per query
+    unsigned tk[KNN_QB][4];             // !ROWS: four smallest (distance bits | slice position) words, ascending
+    const unsigned lowmask = (1u << nb) - 1u;
 #pragma unroll
-    for (int qq = 0; qq < KNN_QB; ++qq) { m0[qq] = INFINITY; m1[qq] = INFINITY; }
+    for (int qq = 0; qq < KNN_QB; ++qq) {
+        m0[qq] = INFINITY; m1[qq] = INFINITY;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) tk[qq][l] = 0xffffffffu;
+    }
     // KNN_NC candidates (j, j + 256, ...) per thread and iteration: the LDS reads of the 8 query coordinates are
     // shared by all of them, and KNN_NC independent global loads are in flight per feature
     for (int j = tid; j < C; j += 256 * KNN_NC) {
@@ -99,6 +113,25 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
 #pragma unroll
                 for (int c = 0; c < KNN_NC; ++c) { const float df = qv - xv[c]; acc[c][qq] = fmaf(df, df, acc[c][qq]); }
             }
+        }
+        if (!ROWS) {
+#pragma unroll
+            for (int c = 0; c < KNN_NC; ++c) {
+                const int jc = j + 256 * c;
+                const unsigned pos = (unsigned)(jc - tid) >> 8;               // slice position: jc = tid + 256 * pos
+#pragma unroll
+                for (int qq = 0; qq < KNN_QB; ++qq) {
+                    const float v = acc[c][qq];
+                    const bool self = !include_self && !external && (int64_t)jc == q0 + qb0 + qq;
+                    // non-negative floats order like their bit patterns; out of range / excluded / non-finite -> never tracked
+                    unsigned u = (jc < C && qq < nq && !self && v < INFINITY) ? ((__float_as_uint(v) & ~lowmask) | pos) : 0xffffffffu;
+                    unsigned a = min(tk[qq][0], u); u = max(tk[qq][0], u); tk[qq][0] = a;
+                    a = min(tk[qq][1], u); u = max(tk[qq][1], u); tk[qq][1] = a;
+                    a = min(tk[qq][2], u); u = max(tk[qq][2], u); tk[qq][2] = a;
+                    tk[qq][3] = min(tk[qq][3], u);
+                }
+            }
+            continue;
         }
 #pragma unroll
         for (int c = 0; c < KNN_NC; ++c) {
@@ -122,11 +155,94 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
     __syncthreads();
     // ---- phase 2: select + exact re-rank, one query at a time
     for (int qq = 0; qq < nq; ++qq) {
-        const float *row = wrow + (int64_t)qq * C;
+        const float *row = ROWS ? wrow + (int64_t)qq * C : wrow;
         const int64_t qcell = q0 + qb0 + qq;
         unsigned long long prefix = 0;
         bool have_threshold = false;
-        if (ksel <= 512) {
+        if (!ROWS) {
+            unsigned a0 = tk[0][0], a1 = tk[0][1], a2 = tk[0][2], a3 = tk[0][3];
+#pragma unroll
+            for (int t = 1; t < KNN_QB; ++t) { if (qq == t) { a0 = tk[t][0]; a1 = tk[t][1]; a2 = tk[t][2]; a3 = tk[t][3]; } }
+            unsigned *candu = reinterpret_cast<unsigned *>(cand);
+            candu[2 * tid] = a0;
+            candu[2 * tid + 1] = a1;
+            __syncthreads();
+            for (int size = 2; size <= 512; size <<= 1) {
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    const int lo = 2 * tid - (tid & (stride - 1)), hi = lo + stride;
+                    const bool up = ((lo & size) == 0);
+                    const unsigned a = candu[lo], b = candu[hi];
+                    if ((a > b) == up) { candu[lo] = b; candu[hi] = a; }
+                    __syncthreads();
+                }
+            }
+            const unsigned T = candu[ksel - 1];                 // >= the Ksel-th smallest word overall
+            __syncthreads();
+            if (T < 0x7f800000u) {
+                if (tid == 0) { s_count = 0; s_over = 0; }
+                for (int t = tid; t < nsort; t += 256) { sd[t] = INFINITY; si[t] = 0x7fffffff; }
+                __syncthreads();
+                const unsigned Tm = (T >> nb) + 1u;             // high bits only, one step of slack: a superset of {distance <= T}
+                auto take = [&](unsigned a) {
+                    if ((a >> nb) <= Tm) {
+                        const unsigned pos = atomicAdd(&s_count, 1u);
+                        if (pos < (unsigned)nsort) si[pos] = tid + 256 * (int)(a & lowmask);
+                    }
+                };
+                // a thread whose fourth word is within the threshold may hold more (about 0.5 % of the queries have one such
+                // thread): it hands its whole slice to the workgroup instead of contributing its four words
+                const bool mine_over = (a3 >> nb) <= Tm;
+                if (mine_over) {
+                    const unsigned o = atomicAdd(&s_over, 1u);
+                    if (o < 8u) s_overtid[o] = tid;
+                } else {
+                    take(a0); take(a1); take(a2); take(a3);
+                }
+                __syncthreads();
+                const unsigned nover = s_over;
+                if (nover > 0u && nover <= 8u) {
+                    const int nslice = (C + 255) / 256;
+                    for (unsigned o = 0; o < nover; ++o) {
+                        const int ot = s_overtid[o];
+                        for (int i = tid; i < nslice; i += 256) {       // one candidate of the slice per thread
+                            const int j = ot + 256 * i;
+                            if (j < C && (include_self || external || (int64_t)j != qcell)) {
+                                float d = 0.f;
+                                for (int p = 0; p < P; ++p) { const float df = xq[qq * P + p] - xt[(int64_t)p * ldx + j]; d = fmaf(df, df, d); }
+                                if (d < INFINITY && (__float_as_uint(d) >> nb) <= Tm) {
+                                    const unsigned pos = atomicAdd(&s_count, 1u);
+                                    if (pos < (unsigned)nsort) si[pos] = j;
+                                }
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+                have_threshold = nover <= 8u && s_count <= (unsigned)nsort;     // >= ksel by construction
+                __syncthreads();
+            }
+            if (!have_threshold) {
+                // rare: materialise this query's fp32 distance row (same arithmetic as phase 1) for the radix-select path
+                for (int j = tid; j < C; j += 1024) {               // four independent load streams per thread
+                    float d[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int p = 0; p < P; ++p) {
+                        const float qv = xq[qq * P + p];
+                        float xv[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) xv[c] = (j + 256 * c < C) ? xt[(int64_t)p * ldx + j + 256 * c] : 0.f;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { const float df = qv - xv[c]; d[c] = fmaf(df, df, d[c]); }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int jc = j + 256 * c;
+                        if (jc < C) wrow[jc] = (!include_self && !external && (int64_t)jc == qcell) ? INFINITY : d[c];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (ROWS && ksel <= 512) {
             // ---- fast path: threshold from the 512 per-thread local minima
             float mm0 = m0[0], mm1 = m1[0];
 #pragma unroll
@@ -283,15 +399,22 @@ static int knn_search_impl(const float *xt, const double *x64, const float *qt, 
     const unsigned blocks = (unsigned)((Q + KNN_QB - 1) / KNN_QB);
     const size_t lds = (large ? 0 : (size_t)nsort * (sizeof(double) + sizeof(int))) + (size_t)KNN_QB * P * sizeof(float);
     VCY_REQUIRE(lds <= 150 * 1024, "knn_search: feature dimension too large for LDS");
-    if (large) {
-        VCY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_knn_search<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_knn_search<true>, dim3(blocks), dim3(256), lds, as_stream(stream), xt, x64, qt, q64, ldq, idx, dist, (float *)workspace, ws_sort, (int)C,
-                           (int)P, ldx, q0, (int)Q, (int)k, (int)ksel, nsort, include_self);
-    } else {
-        VCY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_knn_search<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_knn_search<false>, dim3(blocks), dim3(256), lds, as_stream(stream), xt, x64, qt, q64, ldq, idx, dist, (float *)workspace, ws_sort, (int)C,
-                           (int)P, ldx, q0, (int)Q, (int)k, (int)ksel, nsort, include_self);
-    }
+    int nb = 1;                                                   // bits for a thread's slice position: jc = tid + 256 * pos
+    while (((int64_t)1 << nb) < (C + 255) / 256 + KNN_NC) ++nb;
+    static int rows_pref = -1;                                    // VCY_KNN_ROWS=1 forces the row-materialising kernel (A/B testing)
+    if (rows_pref < 0) { const char *ev = getenv("VCY_KNN_ROWS"); rows_pref = ev ? atoi(ev) : 0; }
+    // the threshold comes from 2 words per thread: with Ksel near 512 it is loose and most threads overflow
+    const bool rows = large || ksel > 128 || nb > 10 || rows_pref == 1;
+#define VCY_KNN_LAUNCH(L, R)                                                                                                       \
+    do {                                                                                                                           \
+        VCY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_knn_search<L, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_knn_search<L, R>), dim3(blocks), dim3(256), lds, as_stream(stream), xt, x64, qt, q64, ldq, idx, dist, (float *)workspace, \
+                           ws_sort, (int)C, (int)P, ldx, q0, (int)Q, (int)k, (int)ksel, nsort, include_self, nb);                \
+    } while (0)
+    if (large) VCY_KNN_LAUNCH(true, true);
+    else if (rows) VCY_KNN_LAUNCH(false, true);
+    else VCY_KNN_LAUNCH(false, false);
+#undef VCY_KNN_LAUNCH
     VCY_LAUNCH_CHECK();
     return VCY_OK;
 }
