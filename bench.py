@@ -101,11 +101,14 @@ def synth_counts(C, G, P, dev, seed=20180811):
         S[s:s + blk, :G] = cs.to(torch.int32).to(torch.int16)
     fS = sumS.mean() / sumS.clamp(min=1.0)                              # avg_size / cell_size
     fU = sumU.mean() / sumU.clamp(min=1.0)
-    cS, cU = ops.CountMatrix(S, G), ops.CountMatrix(U, G)
+    # resident encoding of the layers: uint8 when no count exceeds 255 (lossless; true of this generator: max 189), else uint16
+    cS, cU = ops.CountMatrix(S, G).narrowed(), ops.CountMatrix(U, G).narrowed()
+    if cS.t.dtype != cU.t.dtype:
+        cS, cU = ops.CountMatrix(S, G), ops.CountMatrix(U, G)
     # pcs: top-P principal components of log2(S_sz + 1) (perform_PCA is upstream of the path; randomised SVD here)
     L = torch.empty((C, G), dtype=torch.float32, device=dev)
     for s in range(0, C, blk):
-        L[s:s + blk] = torch.log2((S[s:s + blk, :G].to(torch.int32) & 0xFFFF).float() * fS[s:s + blk, None].float() + 1.0)
+        L[s:s + blk] = torch.log2(cS.as_int32(s, s + blk).float() * fS[s:s + blk, None].float() + 1.0)
     L -= L.mean(0, keepdim=True)
     torch.manual_seed(seed)             # svd_lowrank draws its sketch from the global RNG: keep every rank's pcs identical
     Uu, Ss, _ = torch.svd_lowrank(L, q=P, niter=2)
@@ -245,7 +248,7 @@ def cpu_baseline(pipe, args):
     Cs = min(args.cpu_cells, args.cells)
     G = args.genes
     cores = os.cpu_count() or 1
-    cnt = lambda cm: (cm.t[:Cs, :G].to(torch.int32) & 0xFFFF).double()
+    cnt = lambda cm: cm.as_int32(0, Cs).double()
     S = (cnt(pipe.cS) * pipe.fS[:Cs, None]).cpu().numpy().T.copy()     # S_sz in the reference's (G, Cs) layout
     U = (cnt(pipe.cU) * pipe.fU[:Cs, None]).cpu().numpy().T.copy()
     space = pipe.space[:Cs].cpu().numpy()
@@ -342,7 +345,8 @@ def main():
                                    f"{a.pca_dims} PCs) -> fit_slope -> velocity chain -> colDeltaCorSqrtpartial(nrndm={nr}, "
                                    f"n_neighbors={a.n_neighbors}, sampled_fraction={a.sampled_fraction}, psc=1e-10)",
                        "cells": C, "genes": G, "k": a.k, "nrndm": nr,
-                       "inputs": "uint16 spliced/unspliced count layers + per-cell size factors (S_sz = factor*counts), pcs, sampled neighbours",
+                       "inputs": f"spliced/unspliced count layers ({'uint8, no count above 255' if pipe.cS.t.dtype == torch.uint8 else 'uint16'}) + per-cell size factors "
+                                 "(S_sz = factor*counts), pcs, sampled neighbours",
                        "parallelism": "single GPU" if world == 1 else f"cells sharded over {world} GPUs in embedding (Morton) order; RCCL "
                                       "all-reduce of fit moments, " + (f"halo exchange of Sx rows (all_to_all, {pipe.plan.n_recv} of {C} rows "
                                       "received by rank 0)" if pipe.plan is not None else "all-gather of Sx shards") +

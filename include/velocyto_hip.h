@@ -36,7 +36,7 @@ extern "C" {
 #define VCY_ERR_HIP (-2)          /* HIP runtime error (launch failure, no device)  */
 #define VCY_ERR_UNSUPPORTED (-3)  /* valid request outside what the kernels cover   */
 
-typedef enum { VCY_F32 = 0, VCY_F64 = 1, VCY_U16 = 2 /* count matrices: vcy_transpose source / vcy_knn_pool_counts only */ } vcy_dtype;
+typedef enum { VCY_F32 = 0, VCY_F64 = 1, VCY_U16 = 2, VCY_U8 = 3 /* U16 / U8: count matrices (vcy_transpose, vcy_knn_pool_counts, vcy_gene_stats) */ } vcy_dtype;
 
 /* Element transform f of the six reference kernels (speedboosted.pyx). */
 typedef enum { VCY_LINEAR = 0, VCY_SQRT = 1, VCY_LOG10 = 2 } vcy_transform;
@@ -128,13 +128,15 @@ int vcy_knn_pool2(const void *data, void *out, const void *data2, void *out2, co
 /* Pooling straight from the loom's uint16 count layers (velocyto/constants.py:11): the size-normalised
  * inputs of knn_imputation are norm_factor[c] * counts[c,:] (analysis.py:546-549, 573-579), so
  *     out[c,:] = sum_p (w[p] * scale[indices[p]]) * counts[indices[p],:]
- * gives the same Sx / Ux while every gather moves 2-byte elements.  countsS/countsU: (C, ld16) uint16
- * cells-major, ld16 % 8 == 0, zero padded; scaleS/scaleU: (C) fp64 per-cell factors (1 for size_norm=False);
- * out/out2: (C_out, ld_out) of `dtype`.  countsU/scaleU/out2 may all be NULL.  maximum as vcy_knn_pool. */
+ * gives the same Sx / Ux while every gather moves 2-byte elements - or 1-byte ones: layers whose counts all fit a byte
+ * may be held as uint8 (count_dtype VCY_U8; lossless, chosen per layer at upload).  countsS/countsU: (C, ld16) of
+ * count_dtype, cells-major, ld16 % 16 == 0, zero padded; scaleS/scaleU: (C) fp64 per-cell factors (1 for size_norm=False);
+ * out/out2: (C_out, ld_out) of `dtype`, ld_out % 16 == 0 (written with 16-byte stores, columns G..ld_out zeroed).
+ * countsU/scaleU/out2 may all be NULL.  maximum as vcy_knn_pool. */
 int vcy_knn_pool_counts(const void *countsS, const void *countsU, const double *scaleS, const double *scaleU, void *out,
                         void *out2, const int64_t *indptr, const int32_t *indices, const void *w, const int32_t *order,
                         int64_t C, int64_t G, int64_t ld16, int64_t ld_out, int64_t cell0, int64_t C_out, int maximum,
-                        int64_t slab_genes, int dtype, vcy_stream stream);
+                        int64_t slab_genes, int count_dtype, int dtype, vcy_stream stream);
 
 /* Exact Euclidean kNN in a low-dimensional space (what sklearn NearestNeighbors provides to
  * neighbors.knn_distance_matrix :363-376, BalancedKNN.fit/kneighbors :239-243,282 and
@@ -192,7 +194,7 @@ int vcy_gene_moments(const void *Y, const void *X, double *moments, void *worksp
  * cell_mask[c] != 0.  cell_scale (C, fp64), lo/hi (G, fp64; together) and cell_mask (C, uint8) may be NULL.
  * Replaces the numpy reductions of score_detection_levels (analysis.py:466-474: S.sum(1), (S > 0).sum(1)), score_cv_vs_mean
  * (analysis.py:260-272: detection, mean, std(ddof=1), np.clip winsorising) and clusters_stats (estimation.py:380-387).
- * dtype: VCY_F32 / VCY_F64 / VCY_U16 (raw loom counts, ld in elements).  workspace: vcy_gene_stats_workspace_bytes(G).  */
+ * dtype: VCY_F32 / VCY_F64 / VCY_U16 / VCY_U8 (raw loom counts, ld in elements).  workspace: vcy_gene_stats_workspace_bytes(G).  */
 int64_t vcy_gene_stats_workspace_bytes(int64_t G);
 int vcy_gene_stats(const void *M, const double *cell_scale, const double *lo, const double *hi, const uint8_t *cell_mask,
                    double *stats, void *workspace, int64_t C, int64_t G, int64_t ld, int dtype, vcy_stream stream);

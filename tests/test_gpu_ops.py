@@ -213,8 +213,9 @@ def test_knn_pool_golden(ops, golden, dtype):
     np.testing.assert_array_equal(part, mx[:, 50:120])
 
 
+@pytest.mark.parametrize("narrow", [True, False])
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
-def test_knn_pool_counts(ops, oracle, golden, dtype):
+def test_knn_pool_counts(ops, oracle, golden, dtype, narrow):
     """Pooling gathered from the uint16 count layers + per-cell size factors == pooling of the normalised floats."""
     from scipy import sparse
     g = golden("pipeline")
@@ -225,8 +226,16 @@ def test_knn_pool_counts(ops, oracle, golden, dtype):
     knn = oracle.knn_graph(g["pcs"][:, :10], 12)
     w = oracle.connectivity_to_weights(knn)
     w.sort_indices()
-    cS, cU = ops.CountMatrix.from_genes_major(S), ops.CountMatrix.from_genes_major(U)
-    assert cS.ld % 64 == 0 and int(cS.t[:, cS.G:].abs().sum()) == 0
+    cS, cU = ops.CountMatrix.from_genes_major(S, narrow=narrow), ops.CountMatrix.from_genes_major(U, narrow=narrow)
+    assert cS.t.dtype == ((torch.uint8 if S.max() <= 255 else torch.int16) if narrow else torch.int16)
+    assert cS.ld % 64 == 0 and int(cS.t[:, cS.G:].to(torch.int32).abs().sum()) == 0
+    if narrow:       # narrowing after the fact, and a wide + narrow pair in one call
+        wide = ops.CountMatrix.from_genes_major(np.minimum(S, 255), narrow=False)
+        assert wide.t.dtype == torch.int16 and wide.narrowed().t.dtype == torch.uint8 and torch.equal(wide.narrowed().as_int32(), wide.as_int32())
+        over = S.copy(); over[0, 0] = 300
+        assert ops.CountMatrix.from_genes_major(over).t.dtype == torch.int16 and ops.CountMatrix.from_genes_major(over).narrowed().t.dtype == torch.int16
+        mixS, mixU = ops.knn_pool_counts(ops.CountMatrix.from_genes_major(S, narrow=False), cU, fS, fU, w.indptr, w.indices, w.data, dtype=dtype)
+        np.testing.assert_allclose(mixS.to_genes_major(), g["Sx"], rtol=1e-12 if dtype == "float64" else 3e-6, atol=1e-12 if dtype == "float64" else 3e-6)
     np.testing.assert_array_equal(cS.to_float("float64").to_genes_major(), S.astype(float))
     rt = 1e-12 if dtype == "float64" else 3e-6
     for slab in (0, 8, 24):

@@ -39,13 +39,17 @@ def start(vcy, g, dtype):
 
 
 @pytest.mark.parametrize("shape", [(1, 1), (7, 3), (300, 257), (1000, 70)])
-@pytest.mark.parametrize("kind", ["float32", "float64", "uint16"])
+@pytest.mark.parametrize("kind", ["float32", "float64", "uint16", "uint8"])
 def test_gene_stats_matches_numpy(vcy, shape, kind):
     from velocyto_amd import ops
     C, G = shape
     rng = np.random.default_rng(C * 131 + G)
     X = rng.poisson(1.5, (G, C)).astype(np.float64)               # (genes, cells)
-    M = ops.CountMatrix.from_genes_major(X.astype(np.uint16)) if kind == "uint16" else ops.CellMatrix.from_genes_major(X, getattr(torch, kind))
+    if kind in ("uint16", "uint8"):
+        M = ops.CountMatrix.from_genes_major(X.astype(np.uint16), narrow=kind == "uint8")
+        assert M.t.dtype == (torch.uint8 if kind == "uint8" else torch.int16)
+    else:
+        M = ops.CellMatrix.from_genes_major(X, getattr(torch, kind))
     st = ops.gene_stats(M).cpu().numpy()
     np.testing.assert_array_equal(st[0], X.sum(1))
     np.testing.assert_array_equal(st[1], (X * X).sum(1))

@@ -69,6 +69,7 @@ extern "C" int vcy_transpose(const void *src, void *dst, int64_t rows, int64_t c
     if (src_dtype == VCY_F64 && dst_dtype == VCY_F32) return launch_transpose<double, float>(src, dst, rows, cols, ld_src, ld_dst, st);
     if (src_dtype == VCY_F32 && dst_dtype == VCY_F64) return launch_transpose<float, double>(src, dst, rows, cols, ld_src, ld_dst, st);
     if (src_dtype == VCY_F64 && dst_dtype == VCY_F64) return launch_transpose<double, double>(src, dst, rows, cols, ld_src, ld_dst, st);
+    if (src_dtype == VCY_U8 && dst_dtype == VCY_U8) return launch_transpose<unsigned char, unsigned char>(src, dst, rows, cols, ld_src, ld_dst, st);
     if (src_dtype == VCY_U16 && dst_dtype == VCY_U16) return launch_transpose<unsigned short, unsigned short>(src, dst, rows, cols, ld_src, ld_dst, st);
     if (src_dtype == VCY_U16 && dst_dtype == VCY_F32) return launch_transpose<unsigned short, float>(src, dst, rows, cols, ld_src, ld_dst, st);
     if (src_dtype == VCY_U16 && dst_dtype == VCY_F64) return launch_transpose<unsigned short, double>(src, dst, rows, cols, ld_src, ld_dst, st);

@@ -113,16 +113,19 @@ namespace vcy {
 // the pooled matrices can be gathered straight from the 2-byte counts,
 //     out[c,:] = sum_p (w[p] * scale[indices[p]]) * counts[indices[p],:],
 // which halves the bytes every gather moves through L2/HBM.  Thread = 8 genes (one 16-byte load of uint16).
-struct alignas(16) U16x8 { unsigned short v[8]; };
+// one 16-byte gather of a count row: 8 uint16 or 16 uint8 genes (layers whose counts all fit a byte are kept as bytes)
+template <typename CT> struct alignas(16) CountVec { CT v[16 / sizeof(CT)]; };
 
-template <typename T, bool DUAL>
-__global__ __launch_bounds__(256) void k_knn_pool_counts(const unsigned short *__restrict__ cS, const unsigned short *__restrict__ cU,
+template <typename T, typename CT, bool DUAL>
+__global__ __launch_bounds__(256) void k_knn_pool_counts(const CT *__restrict__ cS, const CT *__restrict__ cU,
                                                           const double *__restrict__ scaleS, const double *__restrict__ scaleU,
                                                           T *__restrict__ out, T *__restrict__ out2, const int64_t *__restrict__ indptr,
                                                           const int32_t *__restrict__ indices, const T *__restrict__ w,
                                                           const int32_t *__restrict__ order, int G, int64_t ld16, int64_t ld_out,
                                                           int64_t cell0, int C_out, int slab, int maximum)
 {
+    constexpr int NE = 16 / sizeof(CT);                       // genes per 16-byte gather
+    using CV = CountVec<CT>;
     const int per = (C_out + 7) / 8, nblk = per * 8;          // XCD-aware slab-major schedule, as in k_knn_pool
     const int64_t b = blockIdx.x;
     const int s = (int)(b / nblk), bi = (int)(b % nblk);
@@ -131,20 +134,20 @@ __global__ __launch_bounds__(256) void k_knn_pool_counts(const unsigned short *_
     const int cl = order ? order[pos] : pos;
     const int g0 = s * slab, g1 = min(G, g0 + slab);
     const int64_t p0 = indptr[cl], p1 = indptr[cl + 1];
-    const int nvec = (g1 - g0 + 7) / 8;                       // rows are zero-padded to ld16 (multiple of 8)
+    const int nvec = (g1 - g0 + NE - 1) / NE;                 // rows are zero-padded to ld16 (multiple of 64 elements)
     for (int v = threadIdx.x; v < nvec; v += blockDim.x) {
-        T acc[8], acc2[8];
+        alignas(16) T acc[NE], acc2[NE];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { acc[k] = T(0); acc2[k] = T(0); }
+        for (int k = 0; k < NE; ++k) { acc[k] = T(0); acc2[k] = T(0); }
         int64_t p = p0;
         for (; p + 3 < p1; p += 4) {
-            U16x8 x[4], y[4]; T ws[4], wu[4];
+            CV x[4], y[4]; T ws[4], wu[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int j = indices[p + u];
                 const int64_t ro = (int64_t)j * ld16 + g0;
-                x[u] = reinterpret_cast<const U16x8 *>(cS + ro)[v];
-                if (DUAL) y[u] = reinterpret_cast<const U16x8 *>(cU + ro)[v];
+                x[u] = reinterpret_cast<const CV *>(cS + ro)[v];
+                if (DUAL) y[u] = reinterpret_cast<const CV *>(cU + ro)[v];
                 const T wp = w[p + u];
                 ws[u] = wp * (T)scaleS[j];
                 if (DUAL) wu[u] = wp * (T)scaleU[j];
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256) void k_knn_pool_counts(const unsigned short *_
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < NE; ++k) {
                     acc[k] = fma(ws[u], (T)x[u].v[k], acc[k]);
                     if (DUAL) acc2[k] = fma(wu[u], (T)y[u].v[k], acc2[k]);
                 }
@@ -160,31 +163,42 @@ __global__ __launch_bounds__(256) void k_knn_pool_counts(const unsigned short *_
         for (; p < p1; ++p) {
             const int j = indices[p];
             const int64_t ro = (int64_t)j * ld16 + g0;
-            const U16x8 xv = reinterpret_cast<const U16x8 *>(cS + ro)[v];
-            U16x8 yv;
-            if (DUAL) yv = reinterpret_cast<const U16x8 *>(cU + ro)[v];
+            const CV xv = reinterpret_cast<const CV *>(cS + ro)[v];
+            CV yv;
+            if (DUAL) yv = reinterpret_cast<const CV *>(cU + ro)[v];
             const T wp = w[p], wsv = wp * (T)scaleS[j], wuv = DUAL ? wp * (T)scaleU[j] : T(0);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { acc[k] = fma(wsv, (T)xv.v[k], acc[k]); if (DUAL) acc2[k] = fma(wuv, (T)yv.v[k], acc2[k]); }
+            for (int k = 0; k < NE; ++k) { acc[k] = fma(wsv, (T)xv.v[k], acc[k]); if (DUAL) acc2[k] = fma(wuv, (T)yv.v[k], acc2[k]); }
         }
         if (maximum) {
             const int64_t ro = (cell0 + cl) * ld16 + g0;
-            const U16x8 sv = reinterpret_cast<const U16x8 *>(cS + ro)[v];
+            const CV sv = reinterpret_cast<const CV *>(cS + ro)[v];
             const T fs = (T)scaleS[cell0 + cl];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { const T o = fs * (T)sv.v[k]; acc[k] = acc[k] > o ? acc[k] : o; }
+            for (int k = 0; k < NE; ++k) { const T o = fs * (T)sv.v[k]; acc[k] = acc[k] > o ? acc[k] : o; }
             if (DUAL) {
-                const U16x8 tv = reinterpret_cast<const U16x8 *>(cU + ro)[v];
+                const CV tv = reinterpret_cast<const CV *>(cU + ro)[v];
                 const T fu = (T)scaleU[cell0 + cl];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { const T o = fu * (T)tv.v[k]; acc2[k] = acc2[k] > o ? acc2[k] : o; }
+                for (int k = 0; k < NE; ++k) { const T o = fu * (T)tv.v[k]; acc2[k] = acc2[k] > o ? acc2[k] : o; }
             }
         }
-        T *o1 = out + (int64_t)cl * ld_out + g0 + v * 8;
-        T *o2 = DUAL ? out2 + (int64_t)cl * ld_out + g0 + v * 8 : nullptr;
+        // 16-byte stores (a lane's NE outputs are contiguous): element-wise 4-byte stores at a 32/64-byte lane stride made this
+        // kernel write-bound (13.5 of 15 ms with a single neighbour per cell).  Output rows are padded to a multiple of 64
+        // elements, so a vector that starts inside a row ends inside it; elements past G are written as zeros.
+        using OV = typename Vec<T>::type;
+        constexpr int ON = Vec<T>::N;
+        if (g0 + v * NE < ld_out) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (g0 + v * 8 + k < ld_out) { o1[k] = (g0 + v * 8 + k < G) ? acc[k] : T(0); if (DUAL) o2[k] = (g0 + v * 8 + k < G) ? acc2[k] : T(0); }
+            for (int k = 0; k < NE; ++k) { if (g0 + v * NE + k >= G) { acc[k] = T(0); acc2[k] = T(0); } }
+            OV *o1 = reinterpret_cast<OV *>(out + (int64_t)cl * ld_out + g0 + v * NE);
+#pragma unroll
+            for (int q = 0; q < NE / ON; ++q) o1[q] = *reinterpret_cast<const OV *>(&acc[q * ON]);
+            if (DUAL) {
+                OV *o2 = reinterpret_cast<OV *>(out2 + (int64_t)cl * ld_out + g0 + v * NE);
+#pragma unroll
+                for (int q = 0; q < NE / ON; ++q) o2[q] = *reinterpret_cast<const OV *>(&acc2[q * ON]);
+            }
         }
     }
 }
@@ -238,27 +252,40 @@ extern "C" int vcy_knn_pool2(const void *data, void *out, const void *data2, voi
 extern "C" int vcy_knn_pool_counts(const void *countsS, const void *countsU, const double *scaleS, const double *scaleU, void *out,
                                    void *out2, const int64_t *indptr, const int32_t *indices, const void *w, const int32_t *order,
                                    int64_t C, int64_t G, int64_t ld16, int64_t ld_out, int64_t cell0, int64_t C_out, int maximum,
-                                   int64_t slab_genes, int dtype, vcy_stream stream)
+                                   int64_t slab_genes, int count_dtype, int dtype, vcy_stream stream)
 {
     VCY_REQUIRE(countsS && scaleS && out && indptr && indices && w, "knn_pool_counts: null pointer");
     VCY_REQUIRE((countsU == nullptr) == (out2 == nullptr) && (countsU == nullptr) == (scaleU == nullptr), "knn_pool_counts: countsU/scaleU/out2 go together");
     VCY_REQUIRE(C > 0 && G > 0 && ld16 >= G && ld_out >= G && C_out > 0 && cell0 >= 0 && cell0 + C_out <= C, "knn_pool_counts: bad shape");
-    VCY_REQUIRE(ld16 % 8 == 0 && ((uintptr_t)countsS % 16) == 0 && ((uintptr_t)countsU % 16) == 0, "knn_pool_counts: count rows must be 16-byte aligned (ld16 % 8 == 0)");
+    VCY_REQUIRE(count_dtype == VCY_U16 || count_dtype == VCY_U8, "knn_pool_counts: count_dtype must be VCY_U16 or VCY_U8");
+    const int ne = count_dtype == VCY_U16 ? 8 : 16;               // genes per 16-byte gather
+    VCY_REQUIRE(ld16 % 16 == 0 && ((uintptr_t)countsS % 16) == 0 && ((uintptr_t)countsU % 16) == 0, "knn_pool_counts: count rows must be 16-byte aligned (ld % 16 == 0)");
     VCY_REQUIRE(dtype == VCY_F32 || dtype == VCY_F64, "knn_pool_counts: bad dtype");
+    VCY_REQUIRE(ld_out % 16 == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)out2 % 16) == 0, "knn_pool_counts: output rows must be 16-byte aligned with ld_out % 16 == 0");
     int64_t slab = slab_genes > 0 ? slab_genes : 1024;
-    slab = (slab + 7) / 8 * 8;
-    if (slab > G) slab = (G + 7) / 8 * 8;
+    slab = (slab + ne - 1) / ne * ne;
+    if (slab > G) slab = (G + ne - 1) / ne * ne;
     const int64_t nslab = (G + slab - 1) / slab;
-    const int threads = slab / 8 >= 256 ? 256 : (slab / 8 >= 128 ? 128 : 64);
+    const int threads = slab / ne >= 256 ? 256 : (slab / ne >= 128 ? 128 : 64);
     const int64_t blocks = nslab * ((C_out + 7) / 8 * 8);
     VCY_REQUIRE(blocks < (1LL << 31), "knn_pool_counts: grid too large");
     hipStream_t st = as_stream(stream);
-#define VCY_POOLC(T, DUAL)                                                                                                                   \
-    hipLaunchKernelGGL((k_knn_pool_counts<T, DUAL>), dim3((unsigned)blocks), dim3(threads), 0, st, (const unsigned short *)countsS,              \
-                       (const unsigned short *)countsU, scaleS, scaleU, (T *)out, (T *)out2, indptr, indices, (const T *)w, order, (int)G, ld16, \
-                       ld_out, cell0, (int)C_out, (int)slab, maximum)
-    if (dtype == VCY_F32) { if (countsU) VCY_POOLC(float, true); else VCY_POOLC(float, false); }
-    else { if (countsU) VCY_POOLC(double, true); else VCY_POOLC(double, false); }
+    // one launch per layer: pooling both layers in one launch shares the index / weight reads but doubles the accumulators
+    // (uint8: 130 VGPRs, 3 waves per SIMD) and measured slower at 50k x 30k - uint16 11.9 vs 11.0 ms, uint8 9.6 vs 8.4 ms
+#define VCY_POOLC(T, CT)                                                                                                                       \
+    do {                                                                                                                                       \
+        hipLaunchKernelGGL((k_knn_pool_counts<T, CT, false>), dim3((unsigned)blocks), dim3(threads), 0, st, (const CT *)countsS,               \
+                           (const CT *)nullptr, scaleS, (const double *)nullptr, (T *)out, (T *)nullptr, indptr, indices, (const T *)w, order,  \
+                           (int)G, ld16, ld_out, cell0, (int)C_out, (int)slab, maximum);                                                       \
+        if (countsU) {                                                                                                                         \
+            VCY_LAUNCH_CHECK();                                                                                                                \
+            hipLaunchKernelGGL((k_knn_pool_counts<T, CT, false>), dim3((unsigned)blocks), dim3(threads), 0, st, (const CT *)countsU,           \
+                               (const CT *)nullptr, scaleU, (const double *)nullptr, (T *)out2, (T *)nullptr, indptr, indices, (const T *)w,   \
+                               order, (int)G, ld16, ld_out, cell0, (int)C_out, (int)slab, maximum);                                            \
+        }                                                                                                                                      \
+    } while (0)
+    if (dtype == VCY_F32) { if (count_dtype == VCY_U16) VCY_POOLC(float, uint16_t); else VCY_POOLC(float, uint8_t); }
+    else { if (count_dtype == VCY_U16) VCY_POOLC(double, uint16_t); else VCY_POOLC(double, uint8_t); }
 #undef VCY_POOLC
     VCY_LAUNCH_CHECK();
     return VCY_OK;

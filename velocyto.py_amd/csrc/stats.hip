@@ -13,7 +13,6 @@ constexpr int STATS_CB = 64;
 constexpr int STATS_NS = 4;       // sum, sum of squares, count(x > 0), max
 
 template <typename T> __device__ __forceinline__ double load_as_double(const T *p) { return (double)*p; }
-template <> __device__ __forceinline__ double load_as_double<uint16_t>(const uint16_t *p) { return (double)*p; }
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_gene_stats(const T *__restrict__ M, const double *__restrict__ cell_scale,
@@ -80,6 +79,7 @@ extern "C" int vcy_gene_stats(const void *M, const double *cell_scale, const dou
     if (dtype == VCY_F32) hipLaunchKernelGGL(k_gene_stats<float>, grid, dim3(256), 0, st, (const float *)M, cell_scale, lo, hi, cell_mask, part, (int)C, (int)G, ld);
     else if (dtype == VCY_F64) hipLaunchKernelGGL(k_gene_stats<double>, grid, dim3(256), 0, st, (const double *)M, cell_scale, lo, hi, cell_mask, part, (int)C, (int)G, ld);
     else if (dtype == VCY_U16) hipLaunchKernelGGL(k_gene_stats<uint16_t>, grid, dim3(256), 0, st, (const uint16_t *)M, cell_scale, lo, hi, cell_mask, part, (int)C, (int)G, ld);
+    else if (dtype == VCY_U8) hipLaunchKernelGGL(k_gene_stats<uint8_t>, grid, dim3(256), 0, st, (const uint8_t *)M, cell_scale, lo, hi, cell_mask, part, (int)C, (int)G, ld);
     else return fail(VCY_ERR_INVALID, "%s: bad dtype", "gene_stats");
     VCY_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_gene_stats_reduce, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, (const double *)part, stats, (int)G);

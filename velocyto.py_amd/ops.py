@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 
-F32, F64, U16 = 0, 1, 2
+F32, F64, U16, U8 = 0, 1, 2, 3
 LINEAR, SQRT, LOG10 = 0, 1, 2
 RULES_FULL, RULES_PARTIAL = 0, 1
 TRANSFORMS = {"linear": LINEAR, "sqrt": SQRT, "log10": LOG10, "log": LOG10}
@@ -142,18 +142,20 @@ class CellMatrix:
 
 
 class CountMatrix:
-    """A (C cells, G genes) uint16 molecule-count matrix on the device (the loom layers as stored,
-    velocyto/constants.py:11), cells-major, rows padded with zeros to ld16 (multiple of 64).  Stored in an
-    int16 tensor (same bits; torch's uint16 support is partial)."""
+    """A (C cells, G genes) molecule-count matrix on the device (the loom layers as stored, velocyto/constants.py:11),
+    cells-major, rows padded with zeros to a multiple of 64 elements.  uint16 lives in an int16 tensor (same bits; torch's
+    uint16 support is partial); a layer whose counts all fit a byte may be held as uint8 (`narrowed()`, lossless) so
+    that every gather of the pooling kernel moves half the bytes."""
 
     __slots__ = ("t", "G")
 
     def __init__(self, t: torch.Tensor, G: int):
-        assert t.dim() == 2 and t.is_contiguous() and t.is_cuda and t.dtype == torch.int16 and t.shape[1] >= G and t.shape[1] % 8 == 0
+        assert t.dim() == 2 and t.is_contiguous() and t.is_cuda and t.dtype in (torch.int16, torch.uint8) and t.shape[1] >= G and t.shape[1] % 16 == 0
         self.t, self.G = t, int(G)
 
     C = property(lambda self: int(self.t.shape[0]))
     ld = property(lambda self: int(self.t.shape[1]))
+    code = property(lambda self: U8 if self.t.dtype == torch.uint8 else U16)
 
     @staticmethod
     def representable(a: np.ndarray) -> bool:
@@ -165,14 +167,21 @@ class CountMatrix:
         return False
 
     @classmethod
-    def from_genes_major(cls, a: np.ndarray) -> "CountMatrix":
-        """(G, C) integer counts (0..65535) -> device (C, ld16) uint16 through the tiled transpose kernel."""
+    def from_genes_major(cls, a: np.ndarray, narrow: bool = True) -> "CountMatrix":
+        """(G, C) integer counts (0..65535) -> device (C, ld) through the tiled transpose kernel; uint8 storage when every
+        count fits a byte and `narrow`."""
         dev = require_gpu()
-        a = np.ascontiguousarray(np.asarray(a).astype(np.uint16, copy=False))
+        a = np.asarray(a)
         G, C = a.shape
-        src = torch.from_numpy(a.view(np.int16)).to(dev)
-        out = torch.empty((C, padded_ld(G)), dtype=torch.int16, device=dev)
-        _lib.check(_lib.lib().vcy_transpose(src.data_ptr(), out.data_ptr(), G, C, C, out.shape[1], 2, 2, _stream()), "transpose(u16)")
+        if narrow and (a.size == 0 or int(a.max()) <= 255):
+            src = torch.from_numpy(np.ascontiguousarray(a.astype(np.uint8, copy=False))).to(dev)
+            out = torch.empty((C, padded_ld(G)), dtype=torch.uint8, device=dev)
+            code = U8
+        else:
+            src = torch.from_numpy(np.ascontiguousarray(a.astype(np.uint16, copy=False)).view(np.int16)).to(dev)
+            out = torch.empty((C, padded_ld(G)), dtype=torch.int16, device=dev)
+            code = U16
+        _lib.check(_lib.lib().vcy_transpose(src.data_ptr(), out.data_ptr(), G, C, C, out.shape[1], code, code, _stream()), "transpose(counts)")
         return cls(out, G)
 
     @classmethod
@@ -183,11 +192,29 @@ class CountMatrix:
         out[:, :G] = t[:, :G].to(torch.int32).to(torch.int16)       # wraps 32768..65535 onto the same 16 bits
         return cls(out, G)
 
+    def as_int32(self, c0: int = 0, c1: Optional[int] = None) -> torch.Tensor:
+        """Counts of rows c0:c1 as int32 (both storage widths)."""
+        blk = self.t[c0:c1, : self.G]
+        return blk.to(torch.int32) if blk.dtype == torch.uint8 else (blk.to(torch.int32) & 0xFFFF)
+
+    def narrowed(self, block: int = 8192) -> "CountMatrix":
+        """The same counts as uint8 if none exceeds 255 (else self)."""
+        if self.t.dtype == torch.uint8:
+            return self
+        for s in range(0, self.C, block):
+            if int((self.t[s:s + block].to(torch.int32) & 0xFFFF).max()) > 255:
+                return self
+        out = torch.empty(self.t.shape, dtype=torch.uint8, device=self.t.device)
+        for s in range(0, self.C, block):
+            out[s:s + block] = self.t[s:s + block].to(torch.uint8)      # values <= 255: the low byte is the count
+        return CountMatrix(out, self.G)
+
     def to_float(self, dtype=None) -> CellMatrix:
         """float copy (counts as they are), cells-major."""
         dt = resolve_dtype(dtype)
         out = CellMatrix(torch.zeros((self.C, padded_ld(self.G)), dtype=dt, device=self.t.device), self.G)
-        out.t[:, : self.ld] = (self.t.to(torch.int32) & 0xFFFF).to(dt)[:, : out.ld]
+        src = self.t if self.t.dtype == torch.uint8 else (self.t.to(torch.int32) & 0xFFFF)
+        out.t[:, : self.ld] = src.to(dt)[:, : out.ld]
         return out
 
 
@@ -350,7 +377,11 @@ def knn_pool_counts(cS: CountMatrix, cU: Optional[CountMatrix], scaleS, scaleU, 
     sS = f64(scaleS) if scaleS is not None else torch.ones(cS.C, dtype=torch.float64, device=dev)
     sU = None
     if cU is not None:
-        assert cU.t.shape == cS.t.shape and cU.G == cS.G
+        assert cU.G == cS.G
+        if cU.t.dtype != cS.t.dtype:          # one launch pools both layers: bring them to the wider storage
+            widen = lambda m: m if m.t.dtype == torch.int16 else CountMatrix(m.t.to(torch.int16), m.G)
+            cS, cU = widen(cS), widen(cU)
+        assert cU.t.shape == cS.t.shape
         sU = f64(scaleU) if scaleU is not None else torch.ones(cS.C, dtype=torch.float64, device=dev)
     assert ip.numel() == C_out + 1 and ix.numel() == w.numel() and sS.numel() == cS.C
     if validate and ix.numel() and (int(ix.min()) < 0 or int(ix.max()) >= cS.C):
@@ -363,7 +394,7 @@ def knn_pool_counts(cS: CountMatrix, cU: Optional[CountMatrix], scaleS, scaleU, 
         assert order.numel() == C_out
     _lib.check(_lib.lib().vcy_knn_pool_counts(cS.t.data_ptr(), None if cU is None else cU.t.data_ptr(), sS.data_ptr(), _p(sU), out.t.data_ptr(),
                                               None if cU is None else out2.t.data_ptr(), ip.data_ptr(), ix.data_ptr(), w.data_ptr(), _p(order),
-                                              cS.C, cS.G, cS.ld, out.ld, cell0, C_out, int(maximum), int(slab_genes), out.code, _stream()),
+                                              cS.C, cS.G, cS.ld, out.ld, cell0, C_out, int(maximum), int(slab_genes), cS.code, out.code, _stream()),
                "knn_pool_counts")
     return (out, out2) if cU is not None else out
 
@@ -488,7 +519,7 @@ def gene_stats(M, cell_scale=None, lo=None, hi=None, cell_mask=None) -> torch.Te
     """(4, G) fp64 [sum, sum of squares, count(x > 0), max] per gene over cells of x = clip(M * cell_scale[:, None], lo, hi),
     restricted to the cells where cell_mask is true.  M: CellMatrix or CountMatrix."""
     dev = M.t.device
-    code = U16 if isinstance(M, CountMatrix) else M.code
+    code = M.code
     f64 = lambda t: None if t is None else torch.as_tensor(t, device=dev).to(torch.float64).contiguous()
     cell_scale, lo, hi = f64(cell_scale), f64(lo), f64(hi)
     mask = None if cell_mask is None else torch.as_tensor(cell_mask, device=dev).to(torch.uint8).contiguous()
