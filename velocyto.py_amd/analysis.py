@@ -291,6 +291,10 @@ class VelocytoLoom(PreprocessMixin):
         if "S" in counts and "U" in counts and ((s_name, u_name) == ("S", "U") or
                                                 ((s_name, u_name) == ("S_sz", "U_sz") and "S_sz" in scale and "U_sz" in scale)):
             sS, sU = (None, None) if s_name == "S" else (scale["S_sz"], scale["U_sz"])
+            if counts["S"].t.dtype != counts["U"].t.dtype:      # one uint8, one uint16 layer: keep both as uint16 from now on
+                for n in ("S", "U"):
+                    if counts[n].t.dtype == torch.uint8:
+                        counts[n] = ops.CountMatrix(counts[n].t.to(torch.int16), counts[n].G)
             Sx, Ux = ops.knn_pool_counts(counts["S"], counts["U"], sS, sU, indptr, indices, vals, dtype=self._dtype, maximum=maximum)
         else:
             Sx, Ux = ops.knn_pool2(self.dev(s_name), self.dev(u_name), indptr, indices, vals, maximum=maximum)
