@@ -245,14 +245,14 @@ template <typename T, int TR, int RULES, int GC>
 __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restrict__ e, const T *__restrict__ d,
                                                                const int32_t *__restrict__ ixs, T *__restrict__ out,
                                                                const int32_t *__restrict__ order, int G, int64_t ld, int64_t cell0,
-                                                               int64_t d_row0, int C_out, int nrndm, int stride, int npad, T psc, FuseArgs<T> fuse)
+                                                               int64_t d_row0, int C_out, int pos0, int nrndm_all, int tilew, int stride, int npad, T psc, FuseArgs<T> fuse)
 {
     using V = typename Vec<T>::type;
     constexpr int N = Vec<T>::N;
     constexpr int NV = GRP_MAX_NV;
     constexpr int GCHUNK = NV * 64 * N;                         // genes per chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int maxpairs = GC * nrndm;
+    const int maxpairs = GC * tilew;                            // LDS layout is sized for a full tile
     T *ec = reinterpret_cast<T *>(smem);                        // [GC][GCHUNK]
     T *dc = ec + GC * GCHUNK;                                   // [GC][GCHUNK]
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(dc + GC * GCHUNK);   // [npad]
@@ -269,13 +269,20 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     // XCD-aware schedule: workgroup b runs on XCD b % 8 (observed; speed only) -> XCD x owns the contiguous
     // range of groups [x*per, (x+1)*per), so groups that share neighbour rows share one L2
-    const int ngroups = (C_out + GC - 1) / GC, per = (ngroups + 7) / 8;
-    const int gpos = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    // C_out cells of the schedule starting at position pos0; the neighbour list (nrndm_all columns, row pitch `stride`) is
+    // cut into column tiles of tilew: block -> (group, tile), tiles of one group are gblocks apart
+    const int ngroups = (C_out + GC - 1) / GC, per = (ngroups + 7) / 8, gblocks = per * 8;
+    const int tile = (int)blockIdx.x / gblocks, bg = (int)blockIdx.x - tile * gblocks;
+    const int gpos = (bg & 7) * per + (bg >> 3);
     if (gpos >= ngroups) return;
+    const int n0 = tile * tilew;
+    const int nrndm = min(tilew, nrndm_all - n0);
+    ixs += n0;
+    out += n0;
     const int g0cell = gpos * GC;
     const int gcount = min(GC, C_out - g0cell);
     const int npairs = gcount * nrndm;
-    if (tid < GC) s_cells[tid] = tid < gcount ? (order ? order[g0cell + tid] : g0cell + tid) : 0;
+    if (tid < GC) s_cells[tid] = tid < gcount ? (order ? order[pos0 + g0cell + tid] : pos0 + g0cell + tid) : 0;
     __syncthreads();
     // ---- 1. keys = (neighbour << 16) | (member << 12) | slot, sorted
     for (int t = tid; t < npad; t += blockDim.x) {
@@ -625,12 +632,29 @@ static int launch_partial(const void *e, const void *d, const int32_t *ixs, void
         if (g_group_pref == GC && nrndm >= 8 && C_out >= 4 * GC && nrndm <= 0x7fffffff / 2 && lds_g <= budget_g) {
             auto kern = k_cdc_partial_grouped<T, TR, RULES, GC>;
             VCY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
-            const unsigned groups = (unsigned)(((C_out + GC - 1) / GC + 7) / 8 * 8);
-            for (int64_t n0 = 0; n0 < nrndm; n0 += tile) {
-                const int64_t w = nrndm - n0 < tile ? nrndm - n0 : tile;
-                hipLaunchKernelGGL(kern, dim3(groups), dim3(1024), lds_g, st, (const T *)e, (const T *)d, ixs + n0, (T *)out + n0, order, (int)G, ld,
-                                   cell0, d_row0, (int)C_out, (int)w, (int)nrndm, npad, (T)psc, fuse);
+            // One workgroup per CU is resident (LDS), every group costs the same, so the last round of a launch would leave
+            // most CUs idle for a whole group time (6250 groups on 256 CUs: 24.4 rounds; a 6250-cell shard of an 8-GPU run:
+            // 3.05 rounds -> 4).  The groups beyond the last full round therefore run as a second launch whose neighbour
+            // lists are cut into narrower tiles, as many (group, tile) blocks as there are CUs.
+            const int64_t groups = (C_out + GC - 1) / GC, W = g_cus > 0 ? g_cus : 256;
+            const int64_t full = groups >= 2 * W ? groups / W * W : 0;
+            auto launch = [&](int64_t pos0, int64_t ncell, int64_t tw) -> int {
+                const int64_t nt = (nrndm + tw - 1) / tw;
+                const int64_t gblocks = ((ncell + GC - 1) / GC + 7) / 8 * 8;
+                hipLaunchKernelGGL(kern, dim3((unsigned)(gblocks * nt)), dim3(1024), lds_g, st, (const T *)e, (const T *)d, ixs, (T *)out, order, (int)G,
+                                   ld, cell0, d_row0, (int)ncell, (int)pos0, (int)nrndm, (int)tw, (int)nrndm, npad, (T)psc, fuse);
                 VCY_LAUNCH_CHECK();
+                return VCY_OK;
+            };
+            if (full > 0) { const int rc = launch(0, full * GC, tile); if (rc) return rc; }
+            if (groups > full) {
+                const int64_t left = groups - full;
+                int64_t split = W / (left * ntiles);                       // how many pieces each base tile can be cut into
+                if (split < 1) split = 1;
+                int64_t tw = (tile + split - 1) / split;
+                if (tw < 16) tw = tile < 16 ? tile : 16;
+                const int rc = launch(full * GC, C_out - full * GC, tw);
+                if (rc) return rc;
             }
             return VCY_OK;
         }
