@@ -245,14 +245,15 @@ template <typename T, int TR, int RULES, int GC>
 __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restrict__ e, const T *__restrict__ d,
                                                                const int32_t *__restrict__ ixs, T *__restrict__ out,
                                                                const int32_t *__restrict__ order, int G, int64_t ld, int64_t cell0,
-                                                               int64_t d_row0, int C_out, int pos0, int nrndm_all, int tilew, int stride, int npad, T psc, FuseArgs<T> fuse)
+                                                               int64_t d_row0, int C_main, int tile_main, int C_tail, int tile_tail, int nrndm_all, int stride, int npad, T psc,
+                                                               FuseArgs<T> fuse)
 {
     using V = typename Vec<T>::type;
     constexpr int N = Vec<T>::N;
     constexpr int NV = GRP_MAX_NV;
     constexpr int GCHUNK = NV * 64 * N;                         // genes per chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int maxpairs = GC * tilew;                            // LDS layout is sized for a full tile
+    const int maxpairs = GC * max(tile_main, tile_tail);        // LDS layout is sized for the widest tile
     T *ec = reinterpret_cast<T *>(smem);                        // [GC][GCHUNK]
     T *dc = ec + GC * GCHUNK;                                   // [GC][GCHUNK]
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(dc + GC * GCHUNK);   // [npad]
@@ -269,10 +270,16 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     // XCD-aware schedule: workgroup b runs on XCD b % 8 (observed; speed only) -> XCD x owns the contiguous
     // range of groups [x*per, (x+1)*per), so groups that share neighbour rows share one L2
-    // C_out cells of the schedule starting at position pos0; the neighbour list (nrndm_all columns, row pitch `stride`) is
-    // cut into column tiles of tilew: block -> (group, tile), tiles of one group are gblocks apart
+    // One launch, two parts.  Main part: the first C_main cells of the schedule, neighbour lists (nrndm_all columns, row
+    // pitch `stride`) in column tiles of tile_main.  Tail part: the C_tail cells after them - the groups beyond the last
+    // full round of the device - in narrower tiles of tile_tail, so that the blocks dispatched last are short ones.
+    // block -> (group, tile); the tiles of one group are gblocks apart.
+    const int nb_main = ((((C_main + GC - 1) / GC) + 7) / 8 * 8) * (C_main > 0 ? (nrndm_all + tile_main - 1) / tile_main : 0);
+    const bool tail = (int)blockIdx.x >= nb_main;
+    const int bx = tail ? (int)blockIdx.x - nb_main : (int)blockIdx.x;
+    const int C_out = tail ? C_tail : C_main, pos0 = tail ? C_main : 0, tilew = tail ? tile_tail : tile_main;
     const int ngroups = (C_out + GC - 1) / GC, per = (ngroups + 7) / 8, gblocks = per * 8;
-    const int tile = (int)blockIdx.x / gblocks, bg = (int)blockIdx.x - tile * gblocks;
+    const int tile = bx / gblocks, bg = bx - tile * gblocks;
     const int gpos = (bg & 7) * per + (bg >> 3);
     if (gpos >= ngroups) return;
     const int n0 = tile * tilew;
@@ -638,24 +645,20 @@ static int launch_partial(const void *e, const void *d, const int32_t *ixs, void
             // lists are cut into narrower tiles, as many (group, tile) blocks as there are CUs.
             const int64_t groups = (C_out + GC - 1) / GC, W = g_cus > 0 ? g_cus : 256;
             const int64_t full = groups >= 2 * W ? groups / W * W : 0;
-            auto launch = [&](int64_t pos0, int64_t ncell, int64_t tw) -> int {
-                const int64_t nt = (nrndm + tw - 1) / tw;
-                const int64_t gblocks = ((ncell + GC - 1) / GC + 7) / 8 * 8;
-                hipLaunchKernelGGL(kern, dim3((unsigned)(gblocks * nt)), dim3(1024), lds_g, st, (const T *)e, (const T *)d, ixs, (T *)out, order, (int)G,
-                                   ld, cell0, d_row0, (int)ncell, (int)pos0, (int)nrndm, (int)tw, (int)nrndm, npad, (T)psc, fuse);
-                VCY_LAUNCH_CHECK();
-                return VCY_OK;
-            };
-            if (full > 0) { const int rc = launch(0, full * GC, tile); if (rc) return rc; }
-            if (groups > full) {
+            const int64_t c_main = full * GC, c_tail = C_out - c_main;
+            int64_t tw = tile;
+            if (c_tail > 0) {
                 const int64_t left = groups - full;
                 int64_t split = W / (left * ntiles);                       // how many pieces each base tile can be cut into
                 if (split < 1) split = 1;
-                int64_t tw = (tile + split - 1) / split;
+                tw = (tile + split - 1) / split;
                 if (tw < 16) tw = tile < 16 ? tile : 16;
-                const int rc = launch(full * GC, C_out - full * GC, tw);
-                if (rc) return rc;
             }
+            auto nblocks = [&](int64_t ncell, int64_t w) { return ncell > 0 ? ((ncell + GC - 1) / GC + 7) / 8 * 8 * ((nrndm + w - 1) / w) : (int64_t)0; };
+            hipLaunchKernelGGL(kern, dim3((unsigned)(nblocks(c_main, tile) + nblocks(c_tail, tw))), dim3(1024), lds_g, st, (const T *)e, (const T *)d, ixs,
+                               (T *)out, order, (int)G, ld, cell0, d_row0, (int)c_main, (int)tile, (int)c_tail, (int)tw, (int)nrndm, (int)nrndm, npad,
+                               (T)psc, fuse);
+            VCY_LAUNCH_CHECK();
             return VCY_OK;
         }
     }
