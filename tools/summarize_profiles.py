@@ -21,7 +21,7 @@ def find(sub, suffix):
     hits = glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{sub}", "**", f"*{suffix}"), recursive=True)
     if not hits:
         raise SystemExit(f"no {suffix} under gpurun_out/{tag}_{sub}")
-    return hits[0]
+    return max(hits, key=os.path.getmtime)          # gpurun merges into gpurun_out/: an older pass of the same tag may still be there
 
 
 # ---- kernel stats
