@@ -40,3 +40,12 @@ print("one neighbour (self): %.2f ms" % timeit(lambda: ops.knn_pool_counts(cS8, 
 near = (torch.arange(C, device=dev, dtype=torch.int64)[:, None] + torch.arange(-15, 16, device=dev)[None, :]).clamp(0, C - 1).to(torch.int32).contiguous()
 print("31 index-adjacent neighbours, natural order: %.2f ms" % timeit(lambda: ops.knn_pool_counts(cS8, cU8, fS, fU, indptr, near, wrow, dtype=torch.float32, out=o1, out2=o2, validate=False)))
 print("real graph, natural order: %.2f ms" % timeit(lambda: ops.knn_pool_counts(cS8, cU8, fS, fU, indptr, indices, wrow, dtype=torch.float32, out=o1, out2=o2, validate=False)))
+# float inputs (hand-edited S_sz / U_sz, size_norm=False on float layers): both matrices in one launch or one each
+S32, U32 = cS8.to_float(torch.float32), cU8.to_float(torch.float32)
+S32.t.mul_(fS[:, None].float()); U32.t.mul_(fU[:, None].float())
+for slab in (0, 256, 512, 1024):
+    dual = timeit(lambda: ops.knn_pool2(S32, U32, indptr, indices, wrow, out=o1, out2=o2, validate=False, order=order, slab_genes=slab))
+    def two32():
+        ops.knn_pool(S32, indptr, indices, wrow, out=o1, validate=False, order=order, slab_genes=slab)
+        ops.knn_pool(U32, indptr, indices, wrow, out=o2, validate=False, order=order, slab_genes=slab)
+    print(f"f32  slab {slab:5d}: dual {dual:6.2f} ms   two launches {timeit(two32):6.2f} ms", flush=True)

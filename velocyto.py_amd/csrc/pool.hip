@@ -246,7 +246,11 @@ extern "C" int vcy_knn_pool2(const void *data, void *out, const void *data2, voi
                              int maximum, int64_t slab_genes, int dtype, vcy_stream stream)
 {
     VCY_REQUIRE(data2 && out2, "knn_pool2: null pointer");
-    return knn_pool_impl(data, out, data2, out2, indptr, indices, w, order, C, G, ld, cell0, C_out, maximum, slab_genes, dtype, stream);
+    // one launch per matrix: sharing the index / weight reads does not pay for the doubled accumulators (f32, 50k x 30k:
+    // 20.4 ms in one launch, 18.5 ms in two; tools/bench_pool.py)
+    const int rc = knn_pool_impl(data, out, nullptr, nullptr, indptr, indices, w, order, C, G, ld, cell0, C_out, maximum, slab_genes, dtype, stream);
+    if (rc) return rc;
+    return knn_pool_impl(data2, out2, nullptr, nullptr, indptr, indices, w, order, C, G, ld, cell0, C_out, maximum, slab_genes, dtype, stream);
 }
 
 extern "C" int vcy_knn_pool_counts(const void *countsS, const void *countsU, const double *scaleS, const double *scaleU, void *out,
