@@ -34,6 +34,12 @@ def world():
     return dict(ops=ops, dev=dev, S=S, U=U, pcs=pcs, neigh=neigh)
 
 
+def bench_counts():
+    import bench
+    from velocyto_amd import ops
+    return bench.synth_counts(C, G, 30, ops.require_gpu())
+
+
 def _pool_inputs(w, ops):
     idx, dist = ops.knn_search(w["pcs"], K)
     conn = (dist > 0).float()
@@ -74,6 +80,15 @@ def test_fullsize_pipeline_properties_and_spot_checks(world, oracle):
         rows = S.t[indices[c].long(), :G].double().cpu().numpy()
         ref = (wrow[c].double().cpu().numpy()[:, None] * rows).sum(0)
         np.testing.assert_allclose(Sx.t[c, :G].cpu().numpy(), ref, rtol=3e-6, atol=1e-6)
+    # pooling from the integer count layers (uint8 / uint16 storage) == pooling of the float matrices they came from
+    cS, cU, fS, fU, _ = bench_counts()
+    for narrow in (True, False):
+        a8, b8 = (cS, cU) if narrow else (ops.CountMatrix(cS.t.to(torch.int16), G), ops.CountMatrix(cU.t.to(torch.int16), G))
+        Sc, Uc = ops.knn_pool_counts(a8, b8, fS, fU, indptr, indices, wrow, dtype=torch.float32, validate=False, order=ops.morton_order(pcs, 3))
+        assert (Sc.t - Sx.t).abs().max().item() <= 4e-6 * Sx.t.abs().max().item()
+        assert (Uc.t - Ux.t).abs().max().item() <= 4e-6 * Ux.t.abs().max().item()
+        del Sc, Uc
+    del cS, cU
     # ---------------- B: fit_slope spot check on sampled genes
     gam = ops.fit_slope(Ux, Sx)
     genes = rng.choice(G, 48, replace=False)
@@ -107,8 +122,13 @@ def test_fullsize_pipeline_properties_and_spot_checks(world, oracle):
                                        order=ops.morton_order(pcs[:, :2], 2))
     assert (c_scaled[fin] - corr[fin]).abs().max().item() < 2e-5
     del neg, c_neg, c_scaled
+    # velocity chain folded into the kernel == materialised dmat, bit for bit, main part and last-round tiles alike
+    fused = ops.coldeltacor_partial_fused(Sx, Ux, gam, None, neigh, ops.SQRT, ops.RULES_PARTIAL, 1e-10, validate=False)
+    assert torch.equal(torch.nan_to_num(fused, nan=7.0), torch.nan_to_num(corr, nan=7.0))
+    del fused
     # ---------------- D: spot check against the fp64 oracle on the rows the sampled cells touch
-    for c in cells[:4]:
+    # (cells C-5 and C-700 sit in the groups beyond the last full round, which run as narrow column tiles)
+    for c in list(cells[:3]) + [C - 5, C - 700]:
         nb = neigh[c].long().cpu().numpy()
         rows = np.concatenate([[c], nb])
         e_sub = Sx.t[torch.as_tensor(rows, device=w["dev"]), :G].double().cpu().numpy().T      # (G, 1 + nrndm)
