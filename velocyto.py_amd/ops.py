@@ -172,6 +172,8 @@ class CountMatrix:
         count fits a byte and `narrow`."""
         dev = require_gpu()
         a = np.asarray(a)
+        if not cls.representable(a):
+            raise ValueError("CountMatrix holds integer counts in 0..65535")
         G, C = a.shape
         if narrow and (a.size == 0 or int(a.max()) <= 255):
             src = torch.from_numpy(np.ascontiguousarray(a.astype(np.uint8, copy=False))).to(dev)
