@@ -173,9 +173,14 @@ class Pipeline:
         # pooling schedule: Morton order over the leading PCs of the kNN space (locality sort, results unchanged)
         self.pool_order = ops.morton_order(self.space[self.c0:self.c1], 3) if args.order == "embedding" else None
         # persistent outputs
-        self.Sx_loc = ops.CellMatrix.empty(nloc, G, torch.float32)
         self.Ux_loc = ops.CellMatrix.empty(nloc, G, torch.float32)
-        self.Sx_full = ops.CellMatrix(torch.zeros((C, ops.padded_ld(G)), dtype=torch.float32, device=dev), G) if self.collect else self.Sx_loc
+        if self.collect:
+            # the rank's own rows of e = Sx_sz live inside the full-height buffer the exchange fills: pooling writes them in place
+            self.Sx_full = ops.CellMatrix(torch.zeros((C, ops.padded_ld(G)), dtype=torch.float32, device=dev), G)
+            self.Sx_loc = self.Sx_full.rows(self.c0, self.c1)
+        else:
+            self.Sx_loc = ops.CellMatrix.empty(nloc, G, torch.float32)
+            self.Sx_full = self.Sx_loc
         self.plan = None
         if self.collect and args.exchange == "halo":
             need = torch.zeros(C, dtype=torch.bool, device=dev)
@@ -367,11 +372,19 @@ def main():
         }
         if not a.no_cpu_baseline and world == 1:     # reported on rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(pipe, a)
+    def flush_c_stdio():                             # RCCL writes its banner through C stdio, which is block-buffered on a pipe:
+        sys.stdout.flush()                           # push it out now, so that nothing can land after the JSON line at exit
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
     if dist.is_initialized():
+        flush_c_stdio()                              # every rank, before the last barrier
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:                                    # the ONE JSON line, last thing on stdout (after RCCL's own teardown chatter)
-        sys.stdout.flush()
+    if rank == 0:                                    # the ONE JSON line, last thing on stdout
+        flush_c_stdio()
         print(json.dumps(res), flush=True)
 
 

@@ -69,7 +69,8 @@ def all_gather_rows(local: torch.Tensor, n_total: int, out: Optional[torch.Tenso
     if not active():
         if out is None:
             return local
-        out.copy_(local)
+        if out.data_ptr() != local.data_ptr():
+            out.copy_(local)
         return out
     bounds = all_shard_bounds(n_total, ws)
     assert local.shape[0] == bounds[rank][1] - bounds[rank][0], "local shard does not match shard_bounds"
@@ -135,7 +136,8 @@ class HaloPlan:
         """local: (c1-c0, ld) rows this rank owns; out_full: (n_total, ld).  Afterwards out_full holds the
         rank's own rows and every remote row its mask asked for."""
         assert local.shape[0] == self.c1 - self.c0 and out_full.shape[0] == self.n and local.shape[1:] == out_full.shape[1:]
-        out_full[self.c0:self.c1].copy_(local)
+        if local.data_ptr() != out_full[self.c0:self.c1].data_ptr():      # callers may keep their rows inside out_full already
+            out_full[self.c0:self.c1].copy_(local)
         if not active() or self.ws == 1:
             return out_full
         tail = tuple(local.shape[1:])
