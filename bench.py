@@ -62,6 +62,7 @@ def parse():
                     help="materialise dmat with k_velocity_chain instead of folding the velocity chain into stage D")
     ap.add_argument("--exchange", choices=["halo", "allgather"], default="halo",
                     help="N > 1: how ranks obtain the rows of e = Sx_sz their neighbour lists reference")
+    ap.add_argument("--dump", default=None, help="rank 0 saves gamma and the gathered correlation rows of the last step to this .npz (tests)")
     ap.add_argument("--order", choices=["natural", "embedding"], default="embedding",
                     help="schedule order of the cells in stage D (results are order-independent)")
     return ap.parse_args()
@@ -159,6 +160,7 @@ class Pipeline:
             # cell-sharded run: relabel the cells in Morton order of the embedding so that a rank's contiguous block
             # of cells is spatially coherent and most sampled neighbours are rank-local (dataset preprocessing, untimed)
             perm = ops.morton_order(self.pcs[:, :2].contiguous(), 2).long()
+            self.perm = perm
             self.cS = ops.CountMatrix(self.cS.t.index_select(0, perm).contiguous(), G)
             self.cU = ops.CountMatrix(self.cU.t.index_select(0, perm).contiguous(), G)
             self.fS, self.fU, self.pcs = self.fS[perm].contiguous(), self.fU[perm].contiguous(), self.pcs[perm].contiguous()
@@ -243,6 +245,7 @@ class Pipeline:
             self.stage_ms += np.array([ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3]),
                                        ev[3].elapsed_time(ev[4]) + ev[5].elapsed_time(ev[6]), ev[4].elapsed_time(ev[5])])
             self.d_ms.append(ev[4].elapsed_time(ev[5]))
+        self.last_gamma = gamma
         return gamma
 
 
@@ -300,6 +303,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("VCY_SINGLE_DEVICE", "0") == "1":     # multi-process test on a one-GPU box: every rank on device 0, gloo
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("VCY_FORCE_COLLECTIVES", "0") == "1":
@@ -307,7 +312,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("VCY_DIST_BACKEND", "nccl")   # "nccl" = RCCL over xGMI; "gloo" only for the one-GPU logic test
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     import velocyto_amd  # noqa: F401
     from velocyto_amd import _lib
     _lib.lib()   # fail loudly if the HIP library is missing
@@ -332,6 +341,12 @@ def main():
         dt = float(tt.item())
     ms_per_step = dt / a.steps * 1e3
 
+    if rank == 0 and a.dump:
+        # in a sharded run the cells were relabelled (Morton order of the embedding): report in the original labels
+        perm = getattr(pipe, "perm", None)
+        corr, neigh = pipe.corr, pipe.neigh
+        np.savez(a.dump, gamma=pipe.last_gamma.cpu().numpy(), corr=corr.cpu().numpy(), neigh=neigh.cpu().numpy(),
+                 perm=(perm.cpu().numpy() if perm is not None else np.arange(a.cells)))
     if rank == 0:
         C, G, nr = a.cells, a.genes, pipe.nrndm
         nloc = pipe.c1 - pipe.c0

@@ -1,0 +1,49 @@
+"""The cell-sharded pipeline of bench.py with MORE THAN ONE RANK on a one-GPU box: every rank runs on cuda:0 and the
+collectives go through gloo (host-staged; `VCY_SINGLE_DEVICE=1 VCY_DIST_BACKEND=gloo`), so that everything except the
+RCCL transport itself is the code the 2/4/8-GPU runs execute: Morton relabelling, shard bounds, kNN queries of a shard
+against all cells, pooling of a shard, all-reduce of the fit moments, halo plan / all-gather of Sx rows, stage D with
+cell0 / u_row0 offsets on a full-height buffer, all-gather of the correlation rows.
+
+The sharded results must equal the one-rank run of the same (relabelled) problem: neighbour samples and labels
+identical, gamma to fp64-summation-order tolerance, correlations to 2e-6.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = ["--no-cpu-baseline", "--cells", "4100", "--genes", "1536", "--n-neighbors", "100", "--k", "12", "--steps", "1", "--warmup", "1"]
+
+
+def run(world, dump, extra=(), port=29611):
+    env = dict(os.environ, VCY_SINGLE_DEVICE="1", VCY_DIST_BACKEND="gloo", VCY_FORCE_COLLECTIVES="1", MASTER_PORT=str(port))
+    if world == 1:
+        cmd = [sys.executable, "bench.py", "--gpus", "1", *ARGS, "--dump", dump, *extra]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), "bench.py", "--gpus", str(world), *ARGS, "--dump", dump, *extra]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    last = [l for l in r.stdout.strip().splitlines() if l.strip()][-1]
+    assert last.startswith("{") and '"n_gpus": %d' % world in last, last[:200]      # the JSON line is the last thing on stdout
+    return dict(np.load(dump))
+
+
+@pytest.mark.parametrize("world,extra", [(2, ()), (3, ("--exchange", "allgather")), (3, ())])
+def test_sharded_pipeline_equals_one_rank(tmp_path, world, extra):
+    from velocyto_amd import ops
+    ops.require_gpu()
+    one = run(1, str(tmp_path / "one.npz"), extra, port=29611 + world)
+    many = run(world, str(tmp_path / "many.npz"), extra, port=29631 + world + len(extra))
+    assert np.array_equal(one["perm"], many["perm"]) and np.array_equal(one["neigh"], many["neigh"])
+    np.testing.assert_allclose(many["gamma"], one["gamma"], rtol=2e-6, atol=1e-9)
+    fin = np.isfinite(one["corr"])
+    assert np.array_equal(np.isfinite(many["corr"]), fin)
+    np.testing.assert_allclose(many["corr"][fin], one["corr"][fin], atol=2e-6)
+    assert one["corr"].shape == (4100, 50) and fin.mean() > 0.99

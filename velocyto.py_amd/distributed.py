@@ -55,9 +55,19 @@ def all_shard_bounds(n: int, world_size: int) -> List[Tuple[int, int]]:
     return [shard_bounds(n, world_size, r) for r in range(world_size)]
 
 
+def _host_staged(t: torch.Tensor, group=None) -> bool:
+    """gloo moves host memory: device tensors go through a host copy (multi-process tests on one GPU; RCCL never)."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
     if active():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if _host_staged(t, group):
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 
@@ -82,7 +92,8 @@ def all_gather_rows(local: torch.Tensor, n_total: int, out: Optional[torch.Tenso
         dist.all_gather_into_tensor(out, local, group=group)
         return out
     mx = max(sizes)
-    buf = torch.zeros((mx,) + tail, dtype=local.dtype, device=local.device)
+    dev = torch.device("cpu") if _host_staged(local, group) else local.device
+    buf = torch.zeros((mx,) + tail, dtype=local.dtype, device=dev)
     buf[: local.shape[0]] = local
     pieces = [torch.empty_like(buf) for _ in range(ws)]
     dist.all_gather(pieces, buf, group=group)
@@ -109,9 +120,13 @@ class HaloPlan:
         need = need.to(torch.uint8).contiguous()
         assert need.numel() == self.n
         if active():
-            masks = torch.empty((self.ws, self.n), dtype=torch.uint8, device=dev)
-            dist.all_gather_into_tensor(masks, need, group=group) if dist.get_backend(group) != "gloo" else \
-                dist.all_gather(list(masks.unbind(0)), need, group=group)
+            if dist.get_backend(group) != "gloo":
+                masks = torch.empty((self.ws, self.n), dtype=torch.uint8, device=dev)
+                dist.all_gather_into_tensor(masks, need, group=group)
+            else:
+                pieces = [torch.empty(self.n, dtype=torch.uint8) for _ in range(self.ws)]
+                dist.all_gather(pieces, need.cpu(), group=group)
+                masks = torch.stack(pieces).to(dev)
         else:
             masks = need[None, :]
         masks = masks.bool()
@@ -145,7 +160,25 @@ class HaloPlan:
             self._send = torch.empty((self.n_send,) + tail, dtype=local.dtype, device=local.device)
             self._recv = torch.empty((self.n_recv,) + tail, dtype=local.dtype, device=local.device)
         torch.index_select(local, 0, self.send_idx, out=self._send)
-        dist.all_to_all_single(self._recv, self._send, output_split_sizes=self.recv_splits, input_split_sizes=self.send_splits,
-                               group=self.group)
+        if _host_staged(local, self.group):
+            # gloo has no all_to_all for these tensors: every peer's block is one broadcast-free exchange of host copies
+            send_h = self._send.cpu()
+            recv_h = torch.empty(self._recv.shape, dtype=self._recv.dtype)
+            outs = list(recv_h.split(self.recv_splits)) if self.n_recv else [recv_h[:0] for _ in range(self.ws)]
+            ins = list(send_h.split(self.send_splits)) if self.n_send else [send_h[:0] for _ in range(self.ws)]
+            reqs = []
+            for peer in range(self.ws):
+                if peer == self.rank:
+                    continue
+                if ins[peer].numel():
+                    reqs.append(dist.isend(ins[peer].contiguous(), peer, group=self.group))
+                if outs[peer].numel():
+                    reqs.append(dist.irecv(outs[peer], peer, group=self.group))
+            for r in reqs:
+                r.wait()
+            self._recv.copy_(recv_h)
+        else:
+            dist.all_to_all_single(self._recv, self._send, output_split_sizes=self.recv_splits, input_split_sizes=self.send_splits,
+                                   group=self.group)
         out_full.index_copy_(0, self.recv_idx, self._recv)
         return out_full
