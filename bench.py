@@ -62,6 +62,8 @@ def parse():
                     help="materialise dmat with k_velocity_chain instead of folding the velocity chain into stage D")
     ap.add_argument("--exchange", choices=["halo", "allgather"], default="halo",
                     help="N > 1: how ranks obtain the rows of e = Sx_sz their neighbour lists reference")
+    ap.add_argument("--no-overlap", dest="overlap", action="store_false",
+                    help="N > 1 with the halo exchange: do not split stage D into interior cells (run while the halo moves) and the rest")
     ap.add_argument("--dump", default=None, help="rank 0 saves gamma and the gathered correlation rows of the last step to this .npz (tests)")
     ap.add_argument("--order", choices=["natural", "embedding"], default="embedding",
                     help="schedule order of the cells in stage D (results are order-independent)")
@@ -189,6 +191,12 @@ class Pipeline:
             need[self.neigh_loc.reshape(-1).long()] = True
             need[self.c0:self.c1] = True
             self.plan = distributed.HaloPlan(need, C)
+        # interior cells (all sampled neighbours rank-local) need no remote row: their stage D runs while the halo moves
+        self.sched = None
+        if self.plan is not None and args.overlap:
+            base = self.order.long() if self.order is not None else torch.arange(nloc, device=dev)
+            inter = ((self.neigh_loc >= self.c0) & (self.neigh_loc < self.c1)).all(1)
+            self.sched = (base[inter[base]].to(torch.int32).contiguous(), base[~inter[base]].to(torch.int32).contiguous())
         self.corr_loc = torch.empty((nloc, self.nrndm), dtype=torch.float32, device=dev)
         self.corr = torch.empty((C, self.nrndm), dtype=torch.float32, device=dev) if self.collect else self.corr_loc
         self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(10)]
@@ -224,27 +232,41 @@ class Pipeline:
         if not a.fuse:
             dmat = ops.velocity_chain(self.Sx_loc, self.Ux_loc, gamma, None, want=("dmat",), transform=ops.SQRT, psc=1e-10)["dmat"]
         ev[3].record()
-        # ---- D: colDeltaCorSqrtpartial; sharded: every rank needs all of e = Sx_sz
-        if self.plan is not None:
-            self.plan.exchange(self.Sx_loc.t, self.Sx_full.t)          # halo rows only (all_to_all_single)
-        elif self.collect:
-            self.D.all_gather_rows(self.Sx_loc.t, C, out=self.Sx_full.t)
-        ev[4].record()
-        if a.fuse:
-            ops.coldeltacor_partial_fused(self.Sx_full, self.Ux_loc, gamma, None, self.neigh_loc, ops.SQRT, ops.RULES_PARTIAL, 1e-10,
-                                          cell0=c0, u_row0=c0, order=self.order, out=self.corr_loc, validate=False)
+        # ---- D: colDeltaCorSqrtpartial; sharded: every rank needs the rows of e = Sx_sz its neighbour lists reference
+        def stage_d(order):
+            if a.fuse:
+                ops.coldeltacor_partial_fused(self.Sx_full, self.Ux_loc, gamma, None, self.neigh_loc, ops.SQRT, ops.RULES_PARTIAL, 1e-10,
+                                              cell0=c0, u_row0=c0, order=order, out=self.corr_loc, validate=False)
+            else:
+                ops.coldeltacor_partial(self.Sx_full, dmat, self.neigh_loc, ops.SQRT, ops.RULES_PARTIAL, 1e-10, cell0=c0,
+                                        d_row0=c0, order=order, out=self.corr_loc, validate=False)
+        if self.sched is not None:
+            handle = self.plan.begin(self.Sx_loc.t, self.Sx_full.t)    # halo rows packed, all_to_all_single started (async on RCCL)
+            ev[4].record()
+            stage_d(self.sched[0])                                      # interior cells: overlaps with the transfer
+            ev[7].record()
+            self.plan.end(handle, self.Sx_full.t)                       # stream waits for the transfer, rows scattered in place
+            ev[8].record()
+            stage_d(self.sched[1])                                      # cells with at least one remote neighbour
         else:
-            ops.coldeltacor_partial(self.Sx_full, dmat, self.neigh_loc, ops.SQRT, ops.RULES_PARTIAL, 1e-10, cell0=c0,
-                                    d_row0=c0, order=self.order, out=self.corr_loc, validate=False)
+            if self.plan is not None:
+                self.plan.exchange(self.Sx_loc.t, self.Sx_full.t)      # halo rows only (all_to_all_single)
+            elif self.collect:
+                self.D.all_gather_rows(self.Sx_loc.t, C, out=self.Sx_full.t)
+            ev[4].record()
+            ev[7].record()
+            ev[8].record()
+            stage_d(self.order)
         ev[5].record()
         if self.collect:
             self.D.all_gather_rows(self.corr_loc, C, out=self.corr)
         ev[6].record()
         if timed:
             torch.cuda.synchronize()
+            t_d = ev[4].elapsed_time(ev[7]) + ev[8].elapsed_time(ev[5])          # both parts of stage D (one part when not overlapped)
             self.stage_ms += np.array([ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3]),
-                                       ev[3].elapsed_time(ev[4]) + ev[5].elapsed_time(ev[6]), ev[4].elapsed_time(ev[5])])
-            self.d_ms.append(ev[4].elapsed_time(ev[5]))
+                                       ev[3].elapsed_time(ev[4]) + ev[7].elapsed_time(ev[8]) + ev[5].elapsed_time(ev[6]), t_d])
+            self.d_ms.append(t_d)
         self.last_gamma = gamma
         return gamma
 
@@ -369,7 +391,8 @@ def main():
                                  "(S_sz = factor*counts), pcs, sampled neighbours",
                        "parallelism": "single GPU" if world == 1 else f"cells sharded over {world} GPUs in embedding (Morton) order; RCCL "
                                       "all-reduce of fit moments, " + (f"halo exchange of Sx rows (all_to_all, {pipe.plan.n_recv} of {C} rows "
-                                      "received by rank 0)" if pipe.plan is not None else "all-gather of Sx shards") +
+                                      "received by rank 0" + (f"; overlapped with stage D of the {int(pipe.sched[0].numel())} interior cells of {nloc})"
+                                                              if pipe.sched is not None else ")") if pipe.plan is not None else "all-gather of Sx shards") +
                                       ", all-gather of correlation rows",
                        "stage_ms": {"A_knn_imputation": stage[0], "B_fit_slope": stage[1], "C_velocity_chain": stage[2],
                                     "D_exchange": stage[3], "D_coldeltacor": stage[4]},

@@ -71,9 +71,11 @@ int vcy_transpose(const void *src, void *dst, int64_t rows, int64_t cols, int64_
  * out : (C_out, nrndm) of `dtype` -- the COMPACT form of the reference's dense (C,C) `rm`
  * (use vcy_scatter_rows to materialise rm[c, ixs[c,n]] += out[c,n]).
  * Zero-variance columns give NaN exactly like the reference (0 * inf).
- * `order` (optional, may be NULL): permutation of 0..C_out-1 giving the order in which
- * cells are scheduled (locality-sorted orders raise Infinity-Cache reuse of shared
- * neighbours); results do not depend on it.
+ * `order` (optional, may be NULL): C_out cell numbers (relative to cell0) in the order in which they are
+ * scheduled (locality-sorted orders raise cache reuse of shared neighbours); results do not depend on it.
+ * With `order`, rows of ixs / out / d are addressed by the cell numbers it holds, so C_out may be SMALLER than the
+ * number of rows of ixs / out: only the listed cells are computed, the other rows of out are left untouched (a
+ * cell-sharded rank computes the cells whose neighbours are all local while the halo exchange is in flight).
  * `rules` = VCY_RULES_PARTIAL reproduces the *partial kernels, VCY_RULES_FULL the branch
  * rules of the full kernels on an explicit neighbour list.                                */
 int vcy_coldeltacor_partial(const void *e, const void *d, const int32_t *ixs, void *out, const int32_t *order,

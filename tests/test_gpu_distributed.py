@@ -2,7 +2,8 @@
 collectives go through gloo (host-staged; `VCY_SINGLE_DEVICE=1 VCY_DIST_BACKEND=gloo`), so that everything except the
 RCCL transport itself is the code the 2/4/8-GPU runs execute: Morton relabelling, shard bounds, kNN queries of a shard
 against all cells, pooling of a shard, all-reduce of the fit moments, halo plan / all-gather of Sx rows, stage D with
-cell0 / u_row0 offsets on a full-height buffer, all-gather of the correlation rows.
+cell0 / u_row0 offsets on a full-height buffer - split into the interior cells (run while the halo moves) and the cells
+with remote neighbours -, all-gather of the correlation rows.
 
 The sharded results must equal the one-rank run of the same (relabelled) problem: neighbour samples and labels
 identical, gamma to fp64-summation-order tolerance, correlations to 2e-6.
@@ -35,7 +36,7 @@ def run(world, dump, extra=(), port=29611):
     return dict(np.load(dump))
 
 
-@pytest.mark.parametrize("world,extra", [(2, ()), (3, ("--exchange", "allgather")), (3, ())])
+@pytest.mark.parametrize("world,extra", [(2, ()), (3, ("--exchange", "allgather")), (3, ()), (2, ("--no-overlap",)), (2, ("--no-fuse",))])
 def test_sharded_pipeline_equals_one_rank(tmp_path, world, extra):
     from velocyto_amd import ops
     ops.require_gpu()

@@ -150,18 +150,24 @@ class HaloPlan:
     def exchange(self, local: torch.Tensor, out_full: torch.Tensor) -> torch.Tensor:
         """local: (c1-c0, ld) rows this rank owns; out_full: (n_total, ld).  Afterwards out_full holds the
         rank's own rows and every remote row its mask asked for."""
+        return self.end(self.begin(local, out_full), out_full)
+
+    def begin(self, local: torch.Tensor, out_full: torch.Tensor):
+        """First half of exchange(): own rows in place, rows to send packed, the all-to-all STARTED (RCCL: asynchronous on
+        its own stream, so kernels launched next - work that needs no remote row - overlap with the transfer).
+        Returns the handle end() takes."""
         assert local.shape[0] == self.c1 - self.c0 and out_full.shape[0] == self.n and local.shape[1:] == out_full.shape[1:]
         if local.data_ptr() != out_full[self.c0:self.c1].data_ptr():      # callers may keep their rows inside out_full already
             out_full[self.c0:self.c1].copy_(local)
         if not active() or self.ws == 1:
-            return out_full
+            return None
         tail = tuple(local.shape[1:])
         if self._send is None or self._send.dtype != local.dtype or tuple(self._send.shape[1:]) != tail:
             self._send = torch.empty((self.n_send,) + tail, dtype=local.dtype, device=local.device)
             self._recv = torch.empty((self.n_recv,) + tail, dtype=local.dtype, device=local.device)
         torch.index_select(local, 0, self.send_idx, out=self._send)
         if _host_staged(local, self.group):
-            # gloo has no all_to_all for these tensors: every peer's block is one broadcast-free exchange of host copies
+            # gloo (one-GPU logic tests): point-to-point exchange of host copies, completed here
             send_h = self._send.cpu()
             recv_h = torch.empty(self._recv.shape, dtype=self._recv.dtype)
             outs = list(recv_h.split(self.recv_splits)) if self.n_recv else [recv_h[:0] for _ in range(self.ws)]
@@ -177,8 +183,16 @@ class HaloPlan:
             for r in reqs:
                 r.wait()
             self._recv.copy_(recv_h)
-        else:
-            dist.all_to_all_single(self._recv, self._send, output_split_sizes=self.recv_splits, input_split_sizes=self.send_splits,
-                                   group=self.group)
+            return "done"
+        return dist.all_to_all_single(self._recv, self._send, output_split_sizes=self.recv_splits, input_split_sizes=self.send_splits,
+                                      group=self.group, async_op=True)
+
+    def end(self, handle, out_full: torch.Tensor) -> torch.Tensor:
+        """Second half of exchange(): wait for the transfer (the current stream waits, not the host) and scatter the
+        received rows to their global positions."""
+        if handle is None:
+            return out_full
+        if handle != "done":
+            handle.wait()
         out_full.index_copy_(0, self.recv_idx, self._recv)
         return out_full

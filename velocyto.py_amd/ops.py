@@ -254,12 +254,16 @@ def coldeltacor_partial(e: CellMatrix, d: CellMatrix, ixs, transform: int, rules
         raise ValueError("neighbour index out of range")
     if out is None:
         out = torch.empty((C_out, nrndm), dtype=e.dtype, device=e.t.device)
+    n_sched = C_out
     if order is not None:
         order = order.to(device=e.t.device, dtype=torch.int32).contiguous()
-        assert order.numel() == C_out
+        n_sched = int(order.numel())          # a schedule over a subset of the cells: the other rows of `out` stay as they are
+        assert n_sched <= C_out
+        if n_sched == 0:
+            return out
     ix, perm, user_out = _sorted_rows(ix, out)
     _lib.check(_lib.lib().vcy_coldeltacor_partial(e.t.data_ptr(), d.t.data_ptr(), ix.data_ptr(), (out if perm is None else perm[1]).data_ptr(), _p(order),
-                                                  e.C, e.G, e.ld, cell0, C_out, d_row0, nrndm, transform, rules, float(psc),
+                                                  e.C, e.G, e.ld, cell0, n_sched, d_row0, nrndm, transform, rules, float(psc),
                                                   e.code, _stream()), "coldeltacor_partial")
     return out if perm is None else user_out.scatter_(1, perm[0], perm[1])
 
@@ -280,12 +284,19 @@ def coldeltacor_partial_fused(Sx: CellMatrix, Ux: CellMatrix, gamma: torch.Tenso
         out = torch.empty((C_out, nrndm), dtype=Sx.dtype, device=dev)
     gamma = gamma.to(device=dev, dtype=torch.float32).contiguous()
     q = None if q is None else q.to(device=dev, dtype=torch.float32).contiguous()
+    n_sched = C_out
     if order is not None:
+        # the schedule may name only SOME of the C_out cells (e.g. the cells whose neighbours are all rank-local, while the
+        # halo exchange is still in flight): rows of ixs / out are addressed by cell id, the others are left untouched
         order = order.to(device=dev, dtype=torch.int32).contiguous()
+        n_sched = int(order.numel())
+        assert n_sched <= C_out
+        if n_sched == 0:
+            return out
     ix, perm, user_out = _sorted_rows(ix, out)
     _lib.check(_lib.lib().vcy_coldeltacor_partial_fused(Sx.t.data_ptr(), Ux.t.data_ptr(), gamma.data_ptr(), _p(q), ix.data_ptr(),
                                                         (out if perm is None else perm[1]).data_ptr(),
-                                                        _p(order), Sx.C, Sx.G, Sx.ld, cell0, C_out, u_row0, nrndm, transform, rules, float(psc),
+                                                        _p(order), Sx.C, Sx.G, Sx.ld, cell0, n_sched, u_row0, nrndm, transform, rules, float(psc),
                                                         float(dt_shift), float(used_dt), Sx.code, _stream()), "coldeltacor_partial_fused")
     return out if perm is None else user_out.scatter_(1, perm[0], perm[1])
 
