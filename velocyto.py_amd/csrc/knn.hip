@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
     } else {
         sd = reinterpret_cast<double *>(smem);                        // [nsort] fp64 distances
         si = reinterpret_cast<int *>(sd + nsort);                     // [nsort] indices
-        xq = reinterpret_cast<float *>(si + nsort);                   // [QB][P]
+        xq = reinterpret_cast<float *>(si + nsort);                   // [P][QB] (16-byte aligned: nsort is a multiple of 128)
     }
     __shared__ unsigned hist[256];
     __shared__ float cand[512];
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
     const int nq = min(KNN_QB, Q - qb0);
 
     for (int t = tid; t < KNN_QB * P; t += 256) {
-        const int qq = t / P, p = t - qq * P;
+        const int p = t / KNN_QB, qq = t - p * KNN_QB;           // [P][QB]: the 8 query coordinates of one feature are 32 contiguous bytes
         xq[t] = qq < nq ? (external ? qt[(int64_t)p * ldq + q0 + qb0 + qq] : xt[(int64_t)p * ldx + q0 + qb0 + qq]) : 0.f;
     }
     __syncthreads();
@@ -107,11 +107,13 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
             float xv[KNN_NC];
 #pragma unroll
             for (int c = 0; c < KNN_NC; ++c) xv[c] = (j + 256 * c < C) ? xt[(int64_t)p * ldx + j + 256 * c] : 0.f;
+            float qv8[KNN_QB];
+            *reinterpret_cast<float4 *>(&qv8[0]) = *reinterpret_cast<const float4 *>(&xq[p * KNN_QB]);       // two broadcast ds_read_b128
+            *reinterpret_cast<float4 *>(&qv8[4]) = *reinterpret_cast<const float4 *>(&xq[p * KNN_QB + 4]);
 #pragma unroll
             for (int qq = 0; qq < KNN_QB; ++qq) {
-                const float qv = xq[qq * P + p];
 #pragma unroll
-                for (int c = 0; c < KNN_NC; ++c) { const float df = qv - xv[c]; acc[c][qq] = fmaf(df, df, acc[c][qq]); }
+                for (int c = 0; c < KNN_NC; ++c) { const float df = qv8[qq] - xv[c]; acc[c][qq] = fmaf(df, df, acc[c][qq]); }
             }
         }
         if (!ROWS) {
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
                             const int j = ot + 256 * i;
                             if (j < C && (include_self || external || (int64_t)j != qcell)) {
                                 float d = 0.f;
-                                for (int p = 0; p < P; ++p) { const float df = xq[qq * P + p] - xt[(int64_t)p * ldx + j]; d = fmaf(df, df, d); }
+                                for (int p = 0; p < P; ++p) { const float df = xq[p * KNN_QB + qq] - xt[(int64_t)p * ldx + j]; d = fmaf(df, df, d); }
                                 if (d < INFINITY && (__float_as_uint(d) >> nb) <= Tm) {
                                     const unsigned pos = atomicAdd(&s_count, 1u);
                                     if (pos < (unsigned)nsort) si[pos] = j;
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
                 for (int j = tid; j < C; j += 1024) {               // four independent load streams per thread
                     float d[4] = {0.f, 0.f, 0.f, 0.f};
                     for (int p = 0; p < P; ++p) {
-                        const float qv = xq[qq * P + p];
+                        const float qv = xq[p * KNN_QB + qq];
                         float xv[4];
 #pragma unroll
                         for (int c = 0; c < 4; ++c) xv[c] = (j + 256 * c < C) ? xt[(int64_t)p * ldx + j + 256 * c] : 0.f;
