@@ -49,3 +49,7 @@ for slab in (0, 256, 512, 1024):
         ops.knn_pool(S32, indptr, indices, wrow, out=o1, validate=False, order=order, slab_genes=slab)
         ops.knn_pool(U32, indptr, indices, wrow, out=o2, validate=False, order=order, slab_genes=slab)
     print(f"f32  slab {slab:5d}: dual {dual:6.2f} ms   two launches {timeit(two32):6.2f} ms", flush=True)
+for slab in (512, 1024, 4096, 16384, 30016):
+    t1 = timeit(lambda: ops.knn_pool_counts(cS8, None, fS, None, ip1, self_idx[:, 0].contiguous(), w1, dtype=torch.float32, out=o1, validate=False, order=order, slab_genes=slab))
+    t31 = timeit(lambda: ops.knn_pool_counts(cS8, None, fS, None, indptr, indices, wrow, dtype=torch.float32, out=o1, validate=False, order=order, slab_genes=slab))
+    print(f"u8 single layer, slab {slab:6d}: one neighbour {t1:5.2f} ms   31 neighbours {t31:5.2f} ms", flush=True)
