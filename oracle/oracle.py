@@ -590,10 +590,13 @@ def gaussian_kernel(X, mu=0.0, sigma=1.0):
     return np.exp(-(X - mu) ** 2 / (2 * sigma ** 2)) / np.sqrt(2 * np.pi * sigma ** 2)
 
 
-def prepare_markov(transition_prob, embedding, sigma_D, sigma_W, direction="forward"):
-    """VelocytoLoom.prepare_markov with cells_ixs=None (analysis.py:1818-1863); dense (C,C) result."""
-    tr = np.array(transition_prob) if direction == "forward" else np.array(transition_prob.T, order="C")
-    emb = _c64(embedding)
+def prepare_markov(transition_prob, embedding, sigma_D, sigma_W, direction="forward", cells_ixs=None):
+    """VelocytoLoom.prepare_markov (analysis.py:1818-1863); dense result over the cells of cells_ixs (default: all)."""
+    if cells_ixs is None:
+        cells_ixs = np.arange(np.asarray(transition_prob).shape[0])
+    sub = np.asarray(transition_prob)[cells_ixs, :][:, cells_ixs]
+    tr = np.array(sub) if direction == "forward" else np.array(sub.T, order="C")
+    emb = _c64(embedding)[cells_ixs, :]
     dist = np.sqrt(((emb[:, None, :] - emb[None, :, :]) ** 2).sum(-1))
     tr = tr * gaussian_kernel(dist, sigma=sigma_D)
     np.fill_diagonal(tr, tr.max(1))

@@ -313,6 +313,15 @@ def golden_next(vlm, dif, ana):
     Diffusion transition-matrix builders, filter_genes_by_phase_portrait."""
     from copy import deepcopy
     out = {}
+    # Markov chain on a SUBSET of the cells (tutorial usage: prepare_markov(..., cells_ixs=...), analysis.py:1841-1863)
+    sub = np.arange(3, vlm.S.shape[1], 2)
+    out["markov_cells_ixs"] = sub
+    for direction in ("forward", "backwards"):
+        vlm.prepare_markov(sigma_D=2.0, sigma_W=4.0, direction=direction, cells_ixs=sub)
+        out[f"tr_subset_{direction}"] = vlm.tr.toarray()
+        vlm.run_markov(n_steps=20)
+        out[f"diffused_subset_{direction}"] = np.asarray(vlm.diffused).ravel()
+    vlm.prepare_markov(sigma_D=2.0, sigma_W=4.0, direction="backwards")      # back to the state golden_pipeline left
     with np.errstate(all="ignore"):
         vlm.calculate_grid_arrows(smooth=0.8, steps=(12, 10), n_neighbors=30, n_jobs=1)
     for k in ("flow_grid", "flow", "flow_norm", "flow_norm_magnitude", "total_p_mass"):

@@ -216,6 +216,12 @@ def test_facade_embedding_shift_markov(vcy, golden, dtype):
         np.testing.assert_allclose(tr.toarray(), g[f"tr_{direction}"], rtol=1e-8 if f64 else 1e-2, atol=1e-14 if f64 else 1e-6)
         vlm.run_markov(n_steps=50)
         np.testing.assert_allclose(vlm.diffused, g[f"diffused_{direction}"], rtol=1e-8 if f64 else 1e-3)
+    nx = golden("next")                     # the chain on a subset of the cells
+    for direction in ("forward", "backwards"):
+        vlm.prepare_markov(sigma_D=2.0, sigma_W=4.0, direction=direction, cells_ixs=nx["markov_cells_ixs"])
+        np.testing.assert_allclose(vlm.tr.toarray(), nx[f"tr_subset_{direction}"], rtol=1e-8 if f64 else 1e-2, atol=1e-14 if f64 else 1e-6)
+        vlm.run_markov(n_steps=20)
+        np.testing.assert_allclose(vlm.diffused, nx[f"diffused_subset_{direction}"], rtol=1e-8 if f64 else 1e-3)
 
 
 def test_facade_randomized_control_is_statistical(vcy, golden):

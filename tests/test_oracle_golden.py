@@ -257,6 +257,12 @@ def test_pipeline_embedding_shift_and_markov(oracle, golden):
         np.testing.assert_allclose(tr, g[f"tr_{direction}"], rtol=1e-12, atol=1e-18)
         p0 = np.ones(tr.shape[0]) / tr.shape[0]
         np.testing.assert_allclose(oracle.diffuse(p0, tr, 50, "time_evolution").ravel(), g[f"diffused_{direction}"], rtol=1e-10)
+    n = golden("next")                      # Markov chain on a subset of the cells (prepare_markov(cells_ixs=...))
+    for direction in ("forward", "backwards"):
+        tr = oracle.prepare_markov(tp, g["ts"], 2.0, 4.0, direction, cells_ixs=n["markov_cells_ixs"])
+        np.testing.assert_allclose(tr, n[f"tr_subset_{direction}"], rtol=1e-12, atol=1e-18)
+        p0 = np.ones(tr.shape[0]) / tr.shape[0]
+        np.testing.assert_allclose(oracle.diffuse(p0, tr, 20, "time_evolution").ravel(), n[f"diffused_subset_{direction}"], rtol=1e-10)
     tr = g["tr_backwards"]
     np.testing.assert_allclose(oracle.diffuse(g["diffuse_p0"], tr, 7, "path_integral").ravel(), g["diffuse_path_integral"], rtol=1e-10)
     np.testing.assert_allclose(oracle.diffuse(g["diffuse_p0"], tr, 7, "time_evolution").ravel(), g["diffuse_time_evolution"], rtol=1e-10)

@@ -625,18 +625,22 @@ class VelocytoLoom(PreprocessMixin):
 
     # ------------------------------------------------------------------ stage F
     def prepare_markov(self, sigma_D: np.ndarray, sigma_W: np.ndarray, direction: str = "forward", cells_ixs: np.ndarray = None) -> None:
-        """analysis.py:1818-1863 (cells_ixs=None)."""
-        if cells_ixs is not None:
-            raise NotImplementedError("prepare_markov on a subset of cells (cells_ixs) is not on the accelerated path yet")
+        """analysis.py:1818-1863.  cells_ixs restricts the chain to a subset of the cells (rows and columns of the
+        transition probabilities and the embedding distances, as the reference slices its dense matrices)."""
         if direction not in ("forward", "backwards"):
             raise NotImplementedError(f"{direction} is not an implemented direction")
         tp, ixs = self._tp.double().cpu().numpy(), self._tp_ixs.cpu().numpy().astype(np.int64)
         C, n = tp.shape
         P = sparse.csr_matrix((tp.ravel(), ixs.ravel(), np.arange(0, C * n + 1, n)), shape=(C, C))
+        embedding = np.asarray(self.embedding, dtype=np.float64)
+        if cells_ixs is not None:
+            cells_ixs = np.asarray(cells_ixs)
+            P = sparse.csr_matrix(P[cells_ixs, :][:, cells_ixs])
+            embedding = embedding[cells_ixs, :]
         if direction == "backwards":
             P = sparse.csr_matrix(P.T)
         P.sort_indices()
-        self._tr_dev = ops.prepare_markov(P.indptr, P.indices, P.data, self.embedding, sigma_D, sigma_W, dtype=torch.float64)
+        self._tr_dev = ops.prepare_markov(P.indptr, P.indices, P.data, embedding, sigma_D, sigma_W, dtype=torch.float64)
 
     def run_markov(self, starting_p: np.ndarray = None, n_steps: int = 2500, mode: str = "time_evolution") -> None:
         """analysis.py:1865-1887."""
