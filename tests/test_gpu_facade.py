@@ -514,3 +514,28 @@ def test_small_helpers_of_the_reference_modules(vcy, golden):
     np.testing.assert_array_equal(back.S_sz, vlm.S_sz)
     np.testing.assert_allclose(back.pcs, vlm.pcs)
     np.testing.assert_allclose(back.pca.explained_variance_ratio_, vlm.pca.explained_variance_ratio_)
+
+
+def test_diffuse_trajectory_mode_follows_the_reference_rng(vcy, golden):
+    """mode="trajectory" (diffusion.py:121-135): the same numpy RNG stream as the reference on the same transition matrix."""
+    from sklearn.preprocessing import normalize
+    g = golden("pipeline")
+    tr = sparse.csr_matrix(g["tr_forward"])
+    n = tr.shape[0]
+    p0 = np.ones(n) / n
+    np.random.seed(7)
+    got = vcy.diffusion.Diffusion().diffuse(p0, tr, n_steps=25, mode="trajectory")
+    np.random.seed(7)                                   # the reference's loop, restated
+    node = np.random.choice(np.arange(n), p=p0)
+    want = [node]
+    for _ in range(25):
+        x = np.zeros(n); x[node] = 1
+        nxt = normalize(sparse.csr_matrix(x).dot(tr).toarray(), norm="l1")[0]
+        node = np.random.choice(np.arange(n), p=nxt)
+        want.append(node)
+    assert got == want and len(got) == 26
+    dense = torch.from_numpy(g["tr_forward"]).to(vcy.ops.require_gpu())
+    np.random.seed(7)
+    assert vcy.diffusion.Diffusion().diffuse(p0, dense, n_steps=25, mode="trajectory") == want
+    with pytest.raises(NotImplementedError):
+        vcy.diffusion.Diffusion().diffuse(p0, tr, mode="nope")

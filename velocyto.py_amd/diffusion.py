@@ -73,7 +73,28 @@ class Diffusion:
                 result.append(int(torch.argmax(nxt)) if mode == "map_trajectory" else int(torch.argmax((nxt + 1) / (cur + 1))))
                 cur = nxt
             return result
-        raise NotImplementedError(f"mode={mode!r} is not implemented (SURVEY.md section 8f, 'next')")
+        if mode == "trajectory":
+            # diffusion.py:121-135: a random walk, one node per step drawn from the current node's row of tr (l1-normalised),
+            # with numpy's global RNG exactly as the reference (same stream for the same seed and probabilities)
+            def row(node: int) -> np.ndarray:
+                if sparse.issparse(tr):
+                    return np.asarray(tr.getrow(node).todense()).ravel().astype(np.float64)
+                return tr[node].detach().to(torch.float64).cpu().numpy()
+            n = x.shape[0]
+            node = np.random.choice(np.arange(n), p=x)
+            trajectories = [node]
+            for _ in range(n_steps):
+                nxt = row(int(node))
+                tot = np.abs(nxt).sum()
+                if tot == 0:                                        # no way out: stay (normalize() leaves a zero row as it is)
+                    nxt = np.zeros(n)
+                    nxt[node] = 1.0
+                else:
+                    nxt = nxt / tot
+                node = np.random.choice(np.arange(n), p=nxt)
+                trajectories.append(node)
+            return trajectories
+        raise NotImplementedError(f"mode={mode!r} is not a mode of Diffusion.diffuse")
 
 
 def _l1_normalize_rows(m: sparse.csr_matrix) -> sparse.csr_matrix:
