@@ -539,3 +539,19 @@ def test_diffuse_trajectory_mode_follows_the_reference_rng(vcy, golden):
     assert vcy.diffusion.Diffusion().diffuse(p0, dense, n_steps=25, mode="trajectory") == want
     with pytest.raises(NotImplementedError):
         vcy.diffusion.Diffusion().diffuse(p0, tr, mode="nope")
+
+
+def test_balanced_knn_with_external_queries(vcy, oracle):
+    """BalancedKNN.kneighbors(X) with X other than the fitted points: sight lists among the fitted points (neighbors.py:282),
+    then the same greedy balancing - against the oracle's restatement fed the exact sight lists."""
+    rng = np.random.default_rng(21)
+    fit, qs = rng.normal(size=(300, 6)), rng.normal(size=(300, 6))
+    b = vcy.neighbors.BalancedKNN(k=8, sight_k=40, maxl=20)
+    b.fit(fit)
+    dist_new, dsi_new, l = b.kneighbors(qs)
+    od, oi = oracle.knn_query(fit, qs, 41)
+    assert np.array_equal(b.dsi, oi)
+    np.testing.assert_allclose(b.dist, od, atol=1e-12)
+    rd, ri, rl = oracle.knn_balance(oi, od, maxl=20, k=8)
+    assert np.array_equal(dsi_new, ri) and np.array_equal(l, rl)
+    np.testing.assert_allclose(dist_new, rd, atol=1e-12)

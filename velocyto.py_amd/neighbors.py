@@ -105,11 +105,18 @@ class BalancedKNN:
             self.data = X
         if maxl is not None:
             self.maxl = maxl
-        if self.data is not self.fitdata and not np.array_equal(self.data, self.fitdata):
-            raise NotImplementedError("BalancedKNN.kneighbors with query points different from the fitted data")
         sight = min(int(self.sight_k) + 1, self.fitdata.shape[0])
         logging.debug(f"First search the {self.sight_k} nearest neighbours for {self.n_samples}")
-        self.dist, self.dsi = _kneighbors(self.fitdata, sight, self.metric, include_self=True)
+        if self.data is not self.fitdata and not np.array_equal(self.data, self.fitdata):
+            # query points other than the fitted ones (neighbors.py:282 with X given): sight lists among the FITTED points
+            Xf, corr = _search_space(self.fitdata, self.metric)
+            Xq, _ = _search_space(self.data, self.metric)
+            idx, dist = ops.knn_query(Xf, Xq, sight)
+            self.dsi, self.dist = idx.cpu().numpy().astype(np.int64), dist.cpu().numpy()
+            if corr:
+                self.dist = self.dist * self.dist / 2.0
+        else:
+            self.dist, self.dsi = _kneighbors(self.fitdata, sight, self.metric, include_self=True)
         logging.debug(f"Using the initialization network to find a {self.k}-NN graph with maximum connectivity of {self.maxl}")
         self.dist_new, self.dsi_new, self.l = knn_balance(self.dsi, self.dist, maxl=self.maxl, k=self.k, constraint=self.constraint)
         if mode == "connectivity":
