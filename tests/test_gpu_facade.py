@@ -332,8 +332,9 @@ def test_diffusion_module_api(vcy, golden):
         np.testing.assert_allclose(np.ravel(d.diffuse(g["diffuse_p0"], T, n_steps=7, mode="time_evolution")), g["diffuse_time_evolution"], rtol=1e-10)
     traj = d.diffuse(g["diffuse_p0"], tr, n_steps=3, mode="map_trajectory")
     assert len(traj) == 4
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):                        # like the reference, the walk draws its start from x as given: x must sum to 1
         d.diffuse(g["diffuse_p0"], tr, mode="trajectory")
+    assert len(d.diffuse(g["diffuse_p0"] / g["diffuse_p0"].sum(), tr, n_steps=5, mode="trajectory")) == 6
 
 
 def test_facade_duplicate_cells_nan_policy(vcy, oracle, caplog):

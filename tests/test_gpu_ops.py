@@ -92,7 +92,10 @@ def test_coldeltacor_full_golden(ops, golden, dtype, key, transform, psc_key):
     np.testing.assert_allclose(rm[~degenerate], ref[~degenerate], atol=CORR_ATOL[dtype])
     # row-block + accumulate semantics (rm[c,i] += ...)
     blk = ops.coldeltacor_full(e, d, ops.TRANSFORMS[transform], psc, cell0=8, C_out=17)
-    np.testing.assert_array_equal(blk.cpu().numpy()[~degenerate[8:25]], rm[8:25][~degenerate[8:25]])
+    if transform == "linear":      # library GEMM: a row block may be tiled differently from the full product
+        np.testing.assert_allclose(blk.cpu().numpy()[~degenerate[8:25]], rm[8:25][~degenerate[8:25]], atol=1e-12 if dtype == "float64" else 1e-6)
+    else:
+        np.testing.assert_array_equal(blk.cpu().numpy()[~degenerate[8:25]], rm[8:25][~degenerate[8:25]])
     acc = torch.ones((17, C), dtype=blk.dtype, device=blk.device)
     ops.coldeltacor_full(e, d, ops.TRANSFORMS[transform], psc, cell0=8, C_out=17, rm=acc, accumulate=True)
     np.testing.assert_allclose(acc.cpu().numpy()[~degenerate[8:25]], 1 + rm[8:25][~degenerate[8:25]], atol=1e-6)
@@ -153,6 +156,34 @@ def test_coldeltacor_partial_fused_equals_two_kernels(ops, dtype, transform):
     dm8 = ops.velocity_chain(S8, U8, gam, q, want=("dmat",), transform=tr, psc=psc)["dmat"]
     ref8 = ops.coldeltacor_partial(S8, dm8, ixs[:8] % 8, tr, ops.RULES_PARTIAL, psc)
     assert torch.equal(torch.nan_to_num(small, nan=7.0), torch.nan_to_num(ref8, nan=7.0))
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_coldeltacor_full_linear_gemm_route(ops, oracle, dtype):
+    """The all-pairs linear variant as two fp64 GEMMs == the VALU kernel == the oracle, including nearly identical cells
+    (where the expanded sum of squares cancels) and exact duplicates (zero variance -> NaN)."""
+    rng = np.random.default_rng(31)
+    G, C = 700, 130
+    e, d = rng.gamma(2.0, 1.0, (G, C)), rng.normal(size=(G, C))
+    e[:, 5] = e[:, 4] + 1e-4 * rng.normal(size=G)           # near-duplicate
+    e[:, 9] = e[:, 8]                                        # exact duplicate
+    want = oracle.coldeltacor(e, d, "linear", 0.0)
+    E, D = ops.CellMatrix.from_genes_major(e, dtype), ops.CellMatrix.from_genes_major(d, dtype)
+    got = ops.coldeltacor_full(E, D, ops.LINEAR).cpu().numpy()
+    ops.FULL_LINEAR_GEMM = False
+    try:
+        kern = ops.coldeltacor_full(E, D, ops.LINEAR).cpu().numpy()
+    finally:
+        ops.FULL_LINEAR_GEMM = True
+    skip = np.eye(C, dtype=bool)
+    skip[8, 9] = skip[9, 8] = True
+    skip[4, 5] = skip[5, 4] = True                           # checked separately below (cancellation in the expanded sum of squares)
+    assert np.isnan(got[np.eye(C, dtype=bool)]).all()
+    tol = 1e-9 if dtype == "float64" else 5e-5
+    np.testing.assert_allclose(got[~skip], want[~skip], atol=tol)
+    np.testing.assert_allclose(kern[~skip], want[~skip], atol=tol * (1 if dtype == "float64" else 4))
+    # the near-duplicate pair is where an f32 expansion would fail: fp64 GEMM keeps it
+    assert abs(got[4, 5] - want[4, 5]) < (1e-6 if dtype == "float64" else 5e-3) and abs(got[5, 4] - want[5, 4]) < (1e-6 if dtype == "float64" else 5e-3)
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])

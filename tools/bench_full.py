@@ -13,3 +13,6 @@ for tr, name in ((ops.SQRT, "sqrt"), (ops.LINEAR, "linear"), (ops.LOG10, "log10"
     rm = ops.coldeltacor_full(e, d, tr, 1e-10)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"full {name:7s} C={C} G={G}: {dt*1e3:8.1f} ms  {C*C*G/dt/1e12:.2f} T pair-genes/s")
+ops.FULL_LINEAR_GEMM = False
+torch.cuda.synchronize(); t0 = time.perf_counter(); rm = ops.coldeltacor_full(e, d, ops.LINEAR); torch.cuda.synchronize()
+print(f"full linear (VALU kernel) C={C} G={G}: {(time.perf_counter()-t0)*1e3:8.1f} ms")
