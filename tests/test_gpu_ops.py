@@ -428,3 +428,34 @@ def test_velocity_chain_golden(ops, golden, dtype):
     ok = np.isfinite(ref)
     # exp(-gamma*dt) is a float32 quantity in the reference (numpy float32 exp vs device expf: 1 ulp apart, amplified by (1 - egt)/gamma for small gamma)
     np.testing.assert_allclose(out["delta_S"].to_genes_major()[ok], ref[ok], rtol=1e-5 if dtype == "float64" else 2e-4, atol=1e-5 if dtype == "float64" else 1e-4)
+
+
+@pytest.mark.parametrize("narrow", [True, False])
+@pytest.mark.parametrize("shape", [(1, 1), (5, 17), (33, 64), (70, 1000), (40, 1025)])
+def test_knn_pool_counts_ragged_graphs(ops, shape, narrow):
+    """Count-layer pooling on ragged CSR graphs (0..9 neighbours per cell, empty rows, repeated neighbours), gene counts
+    around the 16-byte / slab boundaries, both storage widths, against a dense numpy product."""
+    C, G = shape
+    rng = np.random.default_rng(C * 1000 + G)
+    S = rng.poisson(2.0, (G, C)).astype(np.uint16)
+    if not narrow:
+        S[0, 0] = 40000                                      # forces uint16 storage and exercises values above 32767
+    deg = rng.integers(0, 10, C)
+    indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    indices = rng.integers(0, C, indptr[-1]).astype(np.int32)
+    w = rng.random(indptr[-1])
+    scale = rng.random(C) + 0.5
+    W = np.zeros((C, C))
+    for c in range(C):
+        for p in range(indptr[c], indptr[c + 1]):
+            W[c, indices[p]] += w[p]
+    want = (W * scale[None, :]) @ S.T.astype(np.float64)     # (C, G)
+    cS = ops.CountMatrix.from_genes_major(S)
+    assert cS.t.dtype == (torch.uint8 if narrow else torch.int16)
+    for dtype, tol in (("float64", 1e-12), ("float32", 3e-6)):
+        for slab in (0, 16, 1024):
+            got = ops.knn_pool_counts(cS, None, scale, None, indptr, indices, w, dtype=dtype, slab_genes=slab)
+            np.testing.assert_allclose(got.to_cells_major(), want, rtol=tol, atol=tol * max(1.0, np.abs(want).max()))
+            assert float(got.t[:, G:].abs().sum()) == 0.0
+    mx = ops.knn_pool_counts(cS, None, scale, None, indptr, indices, w, dtype="float64", maximum=True).to_cells_major()
+    np.testing.assert_allclose(mx, np.maximum(want, S.T.astype(np.float64) * scale[:, None]), rtol=1e-12, atol=1e-12)
