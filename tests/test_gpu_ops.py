@@ -459,3 +459,22 @@ def test_knn_pool_counts_ragged_graphs(ops, shape, narrow):
             assert float(got.t[:, G:].abs().sum()) == 0.0
     mx = ops.knn_pool_counts(cS, None, scale, None, indptr, indices, w, dtype="float64", maximum=True).to_cells_major()
     np.testing.assert_allclose(mx, np.maximum(want, S.T.astype(np.float64) * scale[:, None]), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("C,P,k", [(2, 1, 1), (9, 3, 8), (257, 2, 5), (300, 7, 100), (300, 7, 121), (513, 1, 30), (1000, 33, 64)])
+def test_knn_search_small_and_boundary_shapes(ops, oracle, C, P, k):
+    """Both selection kernels around their limits: k + 8 <= 128 takes the row-free path, larger k the row-materialising one;
+    candidate counts near the slice width (256), k close to the number of candidates, one feature, duplicated points."""
+    rng = np.random.default_rng(C * 7 + P * 3 + k)
+    X = rng.normal(size=(C, P))
+    if P < 8:
+        X = np.round(X, 1)    # coarse grid: plenty of exact distance ties (sequential sums of rounded squares, as numpy's for < 8 terms)
+    else:
+        X[C // 2] = X[C // 3]                                # exact duplicates tie in any summation order
+    for include_self in (False, True):
+        if not include_self and k > C - 1:
+            continue
+        idx, dist = ops.knn_search(X, k, include_self=include_self)
+        od, oi = oracle.knn_search(X, k, include_self=include_self)
+        assert np.array_equal(idx.cpu().numpy(), oi)
+        np.testing.assert_allclose(dist.cpu().numpy(), od, atol=1e-12)

@@ -367,6 +367,7 @@ __global__ __launch_bounds__(256) void k_gene_quantiles(const T *__restrict__ Z,
         if ((tid & 63) == 0) { atomicAdd(&s_cnt_le, cnt); atomicMin(&s_min_gt, mg); }
         __syncthreads();
         if (tid == 0) {
+#pragma clang fp contract(off)   // hipcc would fuse the mul/add below even through the *_rn intrinsics
             T vhi = vlo;
             if (lo + 1 < nvalid && s_cnt_le < (unsigned)(lo + 2)) vhi = Key<T>::dec((U)s_min_gt);
             // numpy _lerp, without fma contraction so the rounding matches numpy's mul-then-add

@@ -23,12 +23,19 @@
 // before and then collects the tracked words within the threshold (compared on the high bits, one step of slack, so
 // everything the exact comparison would admit is in) - no row write, no row scan.  A thread whose fourth word is within
 // the threshold may hold more: that query alone recomputes its row and takes the radix-select path.
+// The exact distances are sums of ROUNDED squares in feature order (no fused multiply-add): two candidates whose
+// displacements are permutations / sign flips of each other then tie exactly, as they do in a plain C or numpy loop.
 // The fp32 pass only has to get the candidate SET right (margin of 8 near-ties); order and
 // returned distances are fp64, matching the reference's fp64 search up to exact ties (which
 // sklearn orders arbitrarily and this kernel orders by index; with include_self the query is an
 // ordinary candidate at distance 0).
 #include <math.h>
 #include "common.h"
+
+// No implicit fused multiply-adds in this file (hipcc contracts a*b+c by default, even through __dmul_rn / __dadd_rn):
+// the exact fp64 distances must be sums of ROUNDED squares so that mathematically tied candidates tie bit for bit, as
+// they do in a plain C / numpy loop.  The fp32 distance pass asks for its FMAs explicitly (fmaf).
+#pragma clang fp contract(off)
 
 namespace vcy {
 
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
             const int j = si[t];
             double d2 = 0.0;
             const double *a = (external ? q64 : x64) + qcell * P, *b = x64 + (int64_t)j * P;
-            for (int p = 0; p < P; ++p) { const double df = a[p] - b[p]; d2 = fma(df, df, d2); }
+            for (int p = 0; p < P; ++p) { const double df = a[p] - b[p]; d2 += df * df; }
             sd[t] = d2;
         }
         __syncthreads();
