@@ -478,3 +478,30 @@ def test_knn_search_small_and_boundary_shapes(ops, oracle, C, P, k):
         od, oi = oracle.knn_search(X, k, include_self=include_self)
         assert np.array_equal(idx.cpu().numpy(), oi)
         np.testing.assert_allclose(dist.cpu().numpy(), od, atol=1e-12)
+
+
+@pytest.mark.parametrize("G,C,nr", [(1535, 33, 8), (1536, 32, 9), (1537, 40, 7), (3073, 31, 12), (100, 64, 255), (64, 70, 257), (6, 35, 16)])
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_coldeltacor_partial_around_kernel_thresholds(ops, oracle, G, C, nr, dtype):
+    """Gene counts around the 1536-gene chunk (ragged tails), cell counts around the 32-cell / 8-neighbour limits of the
+    grouped kernel, list widths around one 256-column tile - plain and with a schedule over a subset of the cells."""
+    rng = np.random.default_rng(G + 31 * C + 7 * nr)
+    e, d = rng.gamma(2.0, 1.0, (G, C)) * (rng.random((G, C)) < 0.8), rng.normal(size=(G, C))
+    ixs = rng.integers(0, C, (C, nr))
+    want = oracle.coldeltacor_partial_compact(e, d, ixs, "sqrt", 1e-10)
+    E, D = ops.CellMatrix.from_genes_major(e, dtype), ops.CellMatrix.from_genes_major(d, dtype)
+    got = ops.coldeltacor_partial(E, D, ixs, ops.SQRT, ops.RULES_PARTIAL, 1e-10).cpu().numpy()
+    ok = np.isfinite(want)
+    tol = 1e-10 if dtype == "float64" else 1e-4
+    np.testing.assert_allclose(got[ok], want[ok], atol=tol)
+    assert np.isnan(got[~ok]).all()
+    # schedule over a subset: only those rows are written
+    sub = torch.from_numpy(rng.permutation(C)[: max(1, C // 3)].astype(np.int32))
+    out = torch.full((C, nr), 5.0, dtype=E.dtype, device=E.t.device)
+    ops.coldeltacor_partial(E, D, ixs, ops.SQRT, ops.RULES_PARTIAL, 1e-10, order=sub, out=out)
+    out = out.cpu().numpy()
+    rows = np.zeros(C, dtype=bool)
+    rows[sub.numpy()] = True
+    assert (out[~rows] == 5.0).all()
+    sel = ok & rows[:, None]
+    np.testing.assert_allclose(out[sel], want[sel], atol=tol)

@@ -237,7 +237,8 @@ def _sorted_rows(ix: torch.Tensor, out: torch.Tensor):
     if ix.shape[1] <= TILE_COLS or bool((ix[:, 1:] >= ix[:, :-1]).all()):
         return ix, None, out
     srt, perm = torch.sort(ix, dim=1)
-    return srt.contiguous(), (perm, torch.empty_like(out)), out
+    # the launch buffer starts as the caller's rows in sorted column order: rows the schedule does not name round-trip
+    return srt.contiguous(), (perm, out.gather(1, perm)), out
 
 
 def coldeltacor_partial(e: CellMatrix, d: CellMatrix, ixs, transform: int, rules: int = RULES_PARTIAL, psc: float = 0.0,
