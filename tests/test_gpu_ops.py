@@ -505,3 +505,34 @@ def test_coldeltacor_partial_around_kernel_thresholds(ops, oracle, G, C, nr, dty
     assert (out[~rows] == 5.0).all()
     sel = ok & rows[:, None]
     np.testing.assert_allclose(out[sel], want[sel], atol=tol)
+
+
+@pytest.mark.parametrize("G,C", [(1, 1), (3, 2), (255, 3), (257, 70), (1030, 257)])
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_stage_b_c_kernels_on_odd_shapes(ops, oracle, G, C, dtype):
+    """fit_slope, the per-gene moments, row sums and the fused velocity chain on shapes that are not multiples of the
+    vector width, the 256-gene blocks or the cell blocks - against numpy / the oracle."""
+    rng = np.random.default_rng(G * 13 + C)
+    Sx = rng.gamma(2.0, 1.0, (G, C)) * (rng.random((G, C)) < 0.8)
+    Ux = rng.gamma(1.0, 1.0, (G, C)) * (rng.random((G, C)) < 0.7)
+    S, U = ops.CellMatrix.from_genes_major(Sx, dtype), ops.CellMatrix.from_genes_major(Ux, dtype)
+    Sh, Uh = S.to_genes_major(), U.to_genes_major()              # the stored (possibly f32-rounded) values
+    rt = 1e-12 if dtype == "float64" else 2e-6
+    gam = ops.fit_slope(U, S).cpu().numpy()
+    with np.errstate(all="ignore"):
+        ref = np.maximum(0, (Sh * Uh).sum(1) / (Sh * Sh).sum(1))
+    ok = np.isfinite(ref)
+    np.testing.assert_allclose(gam[ok], ref[ok], rtol=max(rt, 2e-7), atol=1e-12)
+    assert np.isnan(gam[~ok]).all()
+    mom = ops.gene_moments(U, S).cpu().numpy()
+    for got, want in zip(mom, (Sh.sum(1), Uh.sum(1), (Sh * Sh).sum(1), (Sh * Uh).sum(1), (Uh * Uh).sum(1))):
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(ops.row_sums(S).cpu().numpy(), Sh.sum(0), rtol=1e-12, atol=1e-12)
+    g32 = np.where(ok, gam, 0.25).astype(np.float32)
+    out = ops.velocity_chain(S, U, torch.from_numpy(g32), None, want=("Upred", "velocity", "delta_S", "Sx_sz_t", "dmat"), transform=ops.SQRT, psc=1e-10)
+    Upred, vel, dS, Sxt = oracle.velocity_chain(Sh, Uh, g32, None)
+    for name, want in (("Upred", Upred), ("velocity", vel), ("delta_S", dS), ("Sx_sz_t", Sxt)):
+        np.testing.assert_allclose(out[name].to_genes_major(), want, rtol=max(rt, 1e-6 if dtype == "float32" else rt), atol=1e-6 if dtype == "float32" else 1e-12)
+    if dtype == "float64":
+        np.testing.assert_allclose(out["dmat"].to_genes_major(), oracle.delta_transform(Sh, Sh + dS, "sqrt", 1e-10), rtol=1e-9, atol=1e-12)
+    assert float(out["dmat"].t[:, G:].abs().sum()) == 0.0
