@@ -536,3 +536,37 @@ def test_stage_b_c_kernels_on_odd_shapes(ops, oracle, G, C, dtype):
     if dtype == "float64":
         np.testing.assert_allclose(out["dmat"].to_genes_major(), oracle.delta_transform(Sh, Sh + dS, "sqrt", 1e-10), rtol=1e-9, atol=1e-12)
     assert float(out["dmat"].t[:, G:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("C,n,edim", [(2, 1, 2), (9, 4, 2), (65, 7, 3), (300, 33, 2), (257, 256, 2)])
+def test_stage_e_f_kernels_on_odd_shapes(ops, oracle, C, n, edim):
+    """transition_prob / delta_embedding in neighbour-list form, the dense Markov matrix and the diffusion steps on
+    shapes around the wave and block sizes, against the oracle's dense restatement of analysis.py:1670-1733, 1818-1887."""
+    rng = np.random.default_rng(C * 17 + n)
+    corr = rng.uniform(-0.5, 0.5, (C, n))
+    ixs = np.stack([rng.choice(np.delete(np.arange(C), c), n, replace=False) for c in range(C)])
+    emb = rng.normal(size=(C, edim))
+    dense = np.zeros((C, C))
+    dense[np.arange(C)[:, None], ixs] = corr
+    tp_ref, de_ref, _ = oracle.calculate_embedding_shift(dense, ixs, emb, sigma_corr=0.07, expression_scaling=False)
+    tp, wd, de = ops.transition_prob(torch.from_numpy(corr).cuda(), ixs, emb, 0.07)
+    got = np.zeros((C, C))
+    got[np.arange(C)[:, None], ixs] = tp.cpu().numpy()
+    np.testing.assert_allclose(got, tp_ref, rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(de.cpu().numpy(), de_ref, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(wd.cpu().numpy(), tp.cpu().numpy() - 1.0 / n, rtol=1e-12, atol=1e-15)
+    if edim == 2:
+        from scipy import sparse
+        P = sparse.csr_matrix(got)
+        P.sort_indices()
+        for direction in ("forward", "backwards"):
+            Pd = P if direction == "forward" else sparse.csr_matrix(P.T)
+            Pd.sort_indices()
+            tr = ops.prepare_markov(Pd.indptr, Pd.indices, Pd.data, emb, 0.8, 1.7).cpu().numpy()
+            ref = oracle.prepare_markov(tp_ref, emb, 0.8, 1.7, direction)
+            np.testing.assert_allclose(tr, ref, rtol=1e-11, atol=1e-16)
+        x0 = rng.random(C)
+        for acc, mode in ((False, "time_evolution"), (True, "path_integral")):
+            xf, xa = ops.diffuse(x0 / x0.sum(), torch.from_numpy(ref).cuda(), 9, accumulate=acc)
+            want = oracle.diffuse(x0, ref, 9, mode).ravel()
+            np.testing.assert_allclose((xa if acc else xf).cpu().numpy(), want, rtol=1e-11)
