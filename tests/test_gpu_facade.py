@@ -556,3 +556,35 @@ def test_balanced_knn_with_external_queries(vcy, oracle):
     rd, ri, rl = oracle.knn_balance(oi, od, maxl=20, k=8)
     assert np.array_equal(dsi_new, ri) and np.array_equal(l, rl)
     np.testing.assert_allclose(dist_new, rd, atol=1e-12)
+
+
+def test_speedboosted_kernel_level_entry_points(vcy, golden):
+    """velocyto.speedboosted._colDeltaCor*: positional signatures, caller-owned rm that is accumulated into."""
+    sb = vcy.speedboosted
+    g = golden("coldeltacor")
+    e, d, ixs = g["e"], g["d"], g["ixs"]
+    C = e.shape[1]
+    deg = np.eye(C, dtype=bool)
+    deg[3, 7] = deg[7, 3] = True
+    rm = np.ones((C, C))
+    sb._colDeltaCorSqrt(np.asfortranarray(e), d, rm, 4, float(g["psc_a"]))          # any memory order; threads ignored
+    np.testing.assert_allclose(rm[~deg], 1 + g["full_sqrt_a"][~deg], atol=1e-9)
+    rm = np.zeros((C, C))
+    sb._colDeltaCor(e, d, rm, 4)
+    np.testing.assert_allclose(rm[~deg], g["full_linear"][~deg], atol=1e-9)
+    rm = np.zeros((C, C))
+    sb._colDeltaCorLog10(e, d, rm, 4, float(g["psc_b"]))
+    np.testing.assert_allclose(rm[~deg], g["full_log10_b"][~deg], atol=1e-9)
+    for fn, key, extra in ((sb._colDeltaCorpartial, "partial_linear", ()), (sb._colDeltaCorSqrtpartial, "partial_sqrt_a", (float(g["psc_a"]),)),
+                           (sb._colDeltaCorLog10partial, "partial_log10_b", (float(g["psc_b"]),))):
+        if key not in g:
+            continue
+        rm = np.zeros((C, C))
+        fn(e, d, rm, ixs, 4, *extra)
+        ref = g[key]
+        ok = ~deg & np.isfinite(ref)
+        np.testing.assert_allclose(rm[ok], ref[ok], atol=1e-9)
+    with pytest.raises(ValueError):
+        sb._colDeltaCor(e, d, np.zeros((C, C), dtype=np.float32), 4)
+    with pytest.raises(ValueError):
+        sb._colDeltaCor(e, d, np.zeros((C - 1, C)), 4)
