@@ -19,6 +19,11 @@ def __getattr__(name):  # lazy: importing the package must not need torch/GPU
     import importlib
     if name in ("ops", "estimation", "neighbors", "diffusion", "analysis", "speedboosted", "distributed", "loom_io", "serialization", "preprocess"):
         return importlib.import_module(f"velocyto_amd.{name}")
-    if name == "VelocytoLoom":
-        return importlib.import_module("velocyto_amd.analysis").VelocytoLoom
+    if name in _ROOT_NAMES:                       # the analysis-side names velocyto/__init__.py:12-15 re-exports at the package root
+        return getattr(importlib.import_module(f"velocyto_amd.{_ROOT_NAMES[name]}"), name)
     raise AttributeError(name)
+
+
+_ROOT_NAMES = {"BalancedKNN": "neighbors", "convolve_by_sparse_weights": "neighbors", "fit_slope": "estimation", "_fit1_slope": "estimation",
+               "clusters_stats": "estimation", "dump_hdf5": "serialization", "load_hdf5": "serialization", "VelocytoLoom": "analysis",
+               "ixs_thatsort_a2b": "analysis", "load_velocyto_hdf5": "analysis"}
