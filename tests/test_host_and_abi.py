@@ -118,3 +118,16 @@ def test_balance_knn_properties_hypothesis(lib):
             pos = [int(np.where(dsi[r] == m)[0][0]) for m in i[r, 1:][real[r]]]
             assert pos == sorted(pos)
     check()
+
+
+def test_package_root_mirrors_the_reference_exports():
+    """velocyto/__init__.py:12-15 re-exports these analysis-side names at the package root; so does velocyto_amd (lazily)."""
+    import velocyto_amd as v
+    for name in ("BalancedKNN", "convolve_by_sparse_weights", "fit_slope", "_fit1_slope", "clusters_stats", "dump_hdf5", "load_hdf5",
+                 "VelocytoLoom", "ixs_thatsort_a2b", "load_velocyto_hdf5"):
+        assert callable(getattr(v, name)), name
+    for mod in ("estimation", "neighbors", "diffusion", "analysis", "speedboosted", "serialization"):
+        assert getattr(v, mod).__name__ == f"velocyto_amd.{mod}"
+    sb = v.speedboosted
+    assert all(hasattr(sb, n) for n in ("_colDeltaCor", "_colDeltaCorSqrt", "_colDeltaCorLog10", "_colDeltaCorpartial",
+                                         "_colDeltaCorSqrtpartial", "_colDeltaCorLog10partial"))
