@@ -588,3 +588,45 @@ def test_speedboosted_kernel_level_entry_points(vcy, golden):
         sb._colDeltaCor(e, d, np.zeros((C, C), dtype=np.float32), 4)
     with pytest.raises(ValueError):
         sb._colDeltaCor(e, d, np.zeros((C - 1, C)), 4)
+
+
+def test_reference_quirks_reproduce_or_fix_as_documented(vcy, golden):
+    """the reference's quirks the facade had to decide on, one assertion per decision."""
+    g = golden("pipeline")
+    rng = np.random.default_rng(2)
+    S, U = g["S"], g["U"]
+    C = S.shape[1]
+    vlm = vcy.analysis.VelocytoLoom.from_arrays(S, U, dtype="float64")
+    vlm.normalize("both")
+    vlm.pcs, vlm.ts = g["pcs"], g["ts"]
+    # (1) balanced defaults: b_sight / b_maxl = max(8k, N-1) / max(4k, N-1)  (analysis.py:985-988) -> the sight is the whole dataset
+    vlm.knn_imputation(k=5, n_pca_dims=5, balanced=True, n_jobs=1)
+    assert vlm.knn.shape == (C, C) and (np.diff(vlm.knn.indptr) == 6).all()
+    # (2)(3) threads are accepted and ignored; any memory order works where the reference raises "not C-contiguous"
+    e, d = np.asfortranarray(g["Sx"][:40]), g["delta_S"][:40]
+    a = vcy.estimation.colDeltaCorpartial(e, d, g["neigh_ixs"], threads=3)
+    b = vcy.estimation.colDeltaCorpartial(np.ascontiguousarray(e), np.ascontiguousarray(d), g["neigh_ixs"], threads=None)
+    assert np.array_equal(a, b, equal_nan=True)
+    # (4) steady_state_bool: ambiguous truth value in the reference -> explicit NotImplementedError here
+    with pytest.raises(NotImplementedError):
+        vlm.fit_gammas(steady_state_bool=np.ones(C, dtype=bool))
+    # (8) knn_distance_matrix ignores `metric` unless it is "correlation" (neighbors.py:369-376)
+    sp = g["pcs"][:, :4]
+    m1 = vcy.neighbors.knn_distance_matrix(sp, metric="cosine", k=4, mode="distance")
+    m2 = vcy.neighbors.knn_distance_matrix(sp, metric="euclidean", k=4, mode="distance")
+    m3 = vcy.neighbors.knn_distance_matrix(sp, metric="correlation", k=4, mode="distance")
+    assert (m1 != m2).nnz == 0 and (m3 != m2).nnz > 0
+    # (5) full + linear + randomised control: TypeError in the reference (colDeltaCor(..., psc=psc), analysis.py:1656); works here
+    vlm.knn_imputation(k=8, n_pca_dims=5, n_jobs=1)
+    vlm.fit_gammas(fit_offset=False, weighted=False)
+    vlm.predict_U(); vlm.calculate_velocity(); vlm.calculate_shift(); vlm.extrapolate_cell_at_t()
+    vlm.estimate_transition_prob(hidim="Sx_sz", embed="ts", transform="linear", knn_random=False, n_neighbors=20, calculate_randomized=True)
+    assert vlm.corrcoef.shape == (C, C) and vlm.corrcoef_random.shape == (C, C) and vlm.corr_calc == "full"
+    # (6) gene_knn_imputation is not reproduced
+    with pytest.raises(NotImplementedError):
+        vlm.gene_knn_imputation()
+    # hidim="pcs": broken in the reference (cells sliced instead of components) -> NotImplementedError
+    with pytest.raises(NotImplementedError):
+        vlm.estimate_transition_prob(hidim="pcs", embed="ts", ndims=3)
+    with pytest.raises(ValueError):
+        vlm.estimate_transition_prob(hidim="Sx_sz", embed="ts", ndims=3)
