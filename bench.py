@@ -36,9 +36,9 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK = 8.0e12   # B/s, MI355X spec (MI355X_MICROARCH.md)
-# profiles/r01i_bench_50kx30k_pmc.csv, k_cdc_partial_grouped<float,SQRT,PARTIAL,8> (velocity chain folded in) at the default
-# workload on 1 GPU: 2 * FETCH_SIZE (80 609 687 KiB; gfx950 half-count correction) + WRITE_SIZE (50 027 KiB), in bytes per launch
-PMC_TRAFFIC_DEFAULT = 2 * 80609686.9375 * 1024 + 50026.90625 * 1024
+# profiles/r01j_bench_50kx30k_pmc.csv, k_cdc_partial_grouped<float,SQRT,PARTIAL,8> (velocity chain folded in) at the default
+# workload on 1 GPU: 2 * FETCH_SIZE (37 961 180 KiB; gfx950 half-count correction) + WRITE_SIZE (50 023 KiB), in bytes per launch
+PMC_TRAFFIC_DEFAULT = 2 * 37961179.625 * 1024 + 50022.96875 * 1024
 
 
 def parse():
@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass; the default workload "
-                         "uses the figure recorded in profiles/r01i_bench_50kx30k_pmc.csv, other workloads report null")
+                         "uses the figure recorded in profiles/r01j_bench_50kx30k_pmc.csv, other workloads report null")
     ap.add_argument("--slab", type=int, default=0, help="gene slab of the pooling kernel (0 = library default)")
     ap.add_argument("--no-fuse", dest="fuse", action="store_false",
                     help="materialise dmat with k_velocity_chain instead of folding the velocity chain into stage D")
@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--no-overlap", dest="overlap", action="store_false",
                     help="N > 1 with the halo exchange: do not split stage D into interior cells (run while the halo moves) and the rest")
     ap.add_argument("--dump", default=None, help="rank 0 saves gamma and the gathered correlation rows of the last step to this .npz (tests)")
+    ap.add_argument("--curve", choices=["morton", "hilbert"], default="hilbert",
+                    help="space-filling curve of the stage-D schedule and of the cell relabelling of sharded runs (Hilbert: no jumps, "
+                         "8-cell groups share more neighbours: 97.3 vs 98.6 ms)")
     ap.add_argument("--order", choices=["natural", "embedding"], default="embedding",
                     help="schedule order of the cells in stage D (results are order-independent)")
     return ap.parse_args()
@@ -161,7 +164,7 @@ class Pipeline:
         if self.collect:
             # cell-sharded run: relabel the cells in Morton order of the embedding so that a rank's contiguous block
             # of cells is spatially coherent and most sampled neighbours are rank-local (dataset preprocessing, untimed)
-            perm = ops.morton_order(self.pcs[:, :2].contiguous(), 2).long()
+            perm = (ops.hilbert_order(self.pcs[:, :2].contiguous()) if args.curve == "hilbert" else ops.morton_order(self.pcs[:, :2].contiguous(), 2)).long()
             self.perm = perm
             self.cS = ops.CountMatrix(self.cS.t.index_select(0, perm).contiguous(), G)
             self.cU = ops.CountMatrix(self.cU.t.index_select(0, perm).contiguous(), G)
@@ -173,7 +176,8 @@ class Pipeline:
         self.c0, self.c1 = distributed.shard_bounds(C, world, rank)
         nloc = self.c1 - self.c0
         self.neigh_loc = self.neigh[self.c0:self.c1].contiguous()
-        self.order = ops.morton_order(emb[self.c0:self.c1], 2) if args.order == "embedding" else None
+        curve = ops.hilbert_order if args.curve == "hilbert" else (lambda pts: ops.morton_order(pts, 2))
+        self.order = curve(emb[self.c0:self.c1]) if args.order == "embedding" else None
         # pooling schedule: Morton order over the leading PCs of the kNN space (locality sort, results unchanged)
         self.pool_order = ops.morton_order(self.space[self.c0:self.c1], 3) if args.order == "embedding" else None
         # persistent outputs
@@ -376,7 +380,7 @@ def main():
         alg_bytes = nloc * ((nr + 2) * G * 4 + nr * (4 + 4))          # (nrndm+2)*G*s + nrndm*(idx+out) per cell
         achieved = alg_bytes / (d_ms * 1e-3)
         stage = pipe.stage_ms / a.steps
-        default_wl = (C, G, nr, a.k, world, a.order, a.fuse) == (50000, 30000, 250, 30, 1, "embedding", True)
+        default_wl = (C, G, nr, a.k, world, a.order, a.fuse, a.curve) == (50000, 30000, 250, 30, 1, "embedding", True, "hilbert")
         traffic = a.traffic_bytes if a.traffic_bytes is not None else (PMC_TRAFFIC_DEFAULT if default_wl else None)
         res = {
             "metric": "cells/sec through knn_imputation->fit_slope->colDeltaCor, 50k cells x 30k genes",
@@ -397,14 +401,14 @@ def main():
                        "stage_ms": {"A_knn_imputation": stage[0], "B_fit_slope": stage[1], "C_velocity_chain": stage[2],
                                     "D_exchange": stage[3], "D_coldeltacor": stage[4]},
                        "velocity_chain": "folded into the staging of d[c] in the stage-D kernel" if a.fuse else "k_velocity_chain (dmat materialised)",
-                       "cell_order_D": a.order},
+                       "cell_order_D": a.order + (f" ({a.curve} curve)" if a.order == "embedding" else "")},
             "roofline": {"bound": "hbm", "kernel": "k_cdc_partial_grouped<float, SQRT, PARTIAL, 8>", "achieved": achieved / 1e9,
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": d_ms,
                          "note": "achieved = ALGORITHMIC bytes (no reuse credited: (nrndm+2)*G*4 + nrndm*8 per cell) / HIP-event "
                                  "launch time. The grouped kernel reads a neighbour row once per 8-cell group (3.5x reuse out of "
                                  "LDS) and adjacent groups share rows in the per-XCD L2, so frac > 1 means it beats the no-reuse HBM "
-                                 "roofline; `traffic` is the PMC-measured L2-miss traffic of the same launch (profiles/r01i_*). The "
+                                 "roofline; `traffic` is the PMC-measured L2-miss traffic of the same launch (profiles/r01j_*). The "
                                  "kernel is VALU-bound: 9.0 VALU instr per pair-gene (v_sqrt_f32 takes two issue slots), VALU pipes "
                                  "95 % busy (4 x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)."},
         }

@@ -808,3 +808,28 @@ def morton_order(points, dims: int = 2) -> torch.Tensor:
         for d in range(dims):
             code |= ((q[:, d] >> b) & 1) << (b * dims + d)
     return torch.argsort(code).to(torch.int32)
+
+
+def hilbert_order(points, bits: int = 16) -> torch.Tensor:
+    """Hilbert-curve permutation of the rows of `points` over their first two coordinates.  Unlike the Z-order curve it
+    has no jumps: consecutive cells are always spatial neighbours, so 8-cell groups of the stage-D schedule share more
+    of their sampled neighbours.  Scheduling only (kernels give identical results in any order)."""
+    dev = require_gpu()
+    p = (torch.from_numpy(np.ascontiguousarray(points, dtype=np.float64)) if not isinstance(points, torch.Tensor) else points).to(dev)
+    p = p[:, :2].double()
+    lo, hi = p.min(0).values, p.max(0).values
+    q = ((p - lo) / (hi - lo + 1e-300) * (2 ** bits - 1)).long()
+    x, y = q[:, 0].clone(), q[:, 1].clone()
+    d = torch.zeros_like(x)
+    s = 1 << (bits - 1)
+    while s > 0:                                      # the classic xy -> d walk, vectorised over the cells
+        rx = ((x & s) > 0).long()
+        ry = ((y & s) > 0).long()
+        d += s * s * ((3 * rx) ^ ry)
+        flip = (ry == 0) & (rx == 1)                  # rotate the quadrant
+        x = torch.where(flip, s - 1 - x, x)
+        y = torch.where(flip, s - 1 - y, y)
+        swap = ry == 0
+        x, y = torch.where(swap, y, x), torch.where(swap, x, y)
+        s >>= 1
+    return torch.argsort(d).to(torch.int32)
