@@ -178,8 +178,9 @@ class Pipeline:
         self.neigh_loc = self.neigh[self.c0:self.c1].contiguous()
         curve = ops.hilbert_order if args.curve == "hilbert" else (lambda pts: ops.morton_order(pts, 2))
         self.order = curve(emb[self.c0:self.c1]) if args.order == "embedding" else None
-        # pooling schedule: Morton order over the leading PCs of the kNN space (locality sort, results unchanged)
-        self.pool_order = ops.morton_order(self.space[self.c0:self.c1], 3) if args.order == "embedding" else None
+        # pooling schedule: a space-filling curve over the leading PCs of the kNN space (locality sort, results unchanged)
+        self.pool_order = ((ops.hilbert_order(self.space[self.c0:self.c1]) if args.curve == "hilbert" else ops.morton_order(self.space[self.c0:self.c1], 3))
+                           if args.order == "embedding" else None)
         # persistent outputs
         self.Ux_loc = ops.CellMatrix.empty(nloc, G, torch.float32)
         if self.collect:

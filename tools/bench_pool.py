@@ -53,3 +53,7 @@ for slab in (512, 1024, 4096, 16384, 30016):
     t1 = timeit(lambda: ops.knn_pool_counts(cS8, None, fS, None, ip1, self_idx[:, 0].contiguous(), w1, dtype=torch.float32, out=o1, validate=False, order=order, slab_genes=slab))
     t31 = timeit(lambda: ops.knn_pool_counts(cS8, None, fS, None, indptr, indices, wrow, dtype=torch.float32, out=o1, validate=False, order=order, slab_genes=slab))
     print(f"u8 single layer, slab {slab:6d}: one neighbour {t1:5.2f} ms   31 neighbours {t31:5.2f} ms", flush=True)
+# schedule orders for the pooling
+for name, od in (("morton 3 PCs", ops.morton_order(space, 3)), ("morton 2 PCs", ops.morton_order(space, 2)), ("hilbert 2 PCs", ops.hilbert_order(space)), ("natural", None)):
+    t = timeit(lambda: ops.knn_pool_counts(cS8, cU8, fS, fU, indptr, indices, wrow, dtype=torch.float32, out=o1, out2=o2, validate=False, order=od))
+    print(f"pool order {name:14s}: {t:5.2f} ms", flush=True)
