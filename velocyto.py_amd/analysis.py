@@ -277,10 +277,14 @@ class VelocytoLoom(PreprocessMixin):
             connectivity = (self.knn > 0).astype(float)          # :1006 (also column-sorts self.knn in place, like scipy does there)
             connectivity.setdiag(diag)
         self.knn_smoothing_w = connectivity_to_weights(connectivity)
+        # schedule the pooling along the Hilbert curve of the two leading coordinates of the search space (results do not
+        # depend on it; neighbouring cells gather overlapping rows while they are still in L2)
+        self.__dict__["_pool_order"] = ops.hilbert_order(np.ascontiguousarray(space[:, :2])) if np.shape(space)[1] >= 2 else None
         self._pool(self.knn_smoothing_w, maximum, "S_sz" if size_norm else "S", "U_sz" if size_norm else "U")
 
     def knn_imputation_precomputed(self, knn_smoothing_w: sparse.spmatrix, maximum: bool = False) -> None:
         """analysis.py:1025-1053."""
+        self.__dict__["_pool_order"] = None
         self._pool(knn_smoothing_w, maximum, "S_sz", "U_sz")
 
     def _pool(self, w: sparse.spmatrix, maximum: bool, s_name: str, u_name: str) -> None:
@@ -288,6 +292,9 @@ class VelocytoLoom(PreprocessMixin):
         assert np.allclose(np.asarray(w.sum(1)).ravel(), 1), "weight matrix need to sum to one over the columns"   # neighbors.py:422
         indptr, indices, vals = w.indptr.astype(np.int64), w.indices.astype(np.int32), np.ascontiguousarray(w.data, dtype=np.float64)
         counts, scale = self.__dict__.get("_counts", {}), self.__dict__.get("_sz_scale", {})
+        order = self.__dict__.get("_pool_order")
+        if order is not None and int(order.numel()) != w.shape[0]:
+            order = None
         if "S" in counts and "U" in counts and ((s_name, u_name) == ("S", "U") or
                                                 ((s_name, u_name) == ("S_sz", "U_sz") and "S_sz" in scale and "U_sz" in scale)):
             sS, sU = (None, None) if s_name == "S" else (scale["S_sz"], scale["U_sz"])
@@ -295,9 +302,9 @@ class VelocytoLoom(PreprocessMixin):
                 for n in ("S", "U"):
                     if counts[n].t.dtype == torch.uint8:
                         counts[n] = ops.CountMatrix(counts[n].t.to(torch.int16), counts[n].G)
-            Sx, Ux = ops.knn_pool_counts(counts["S"], counts["U"], sS, sU, indptr, indices, vals, dtype=self._dtype, maximum=maximum)
+            Sx, Ux = ops.knn_pool_counts(counts["S"], counts["U"], sS, sU, indptr, indices, vals, dtype=self._dtype, maximum=maximum, order=order)
         else:
-            Sx, Ux = ops.knn_pool2(self.dev(s_name), self.dev(u_name), indptr, indices, vals, maximum=maximum)
+            Sx, Ux = ops.knn_pool2(self.dev(s_name), self.dev(u_name), indptr, indices, vals, maximum=maximum, order=order)
         self._set_dev("Sx", Sx)
         self._set_dev("Ux", Ux)
         self._set_dev("Sx_sz", Sx.clone())                        # :1022-1023 separate copies for backwards compatibility
@@ -499,11 +506,13 @@ class VelocytoLoom(PreprocessMixin):
                                                    shape=(C, C))
             neigh = torch.from_numpy(neigh_ixs.astype(np.int32)).to(hi.t.device)
             self._neigh = neigh
-            self._corr = ops.coldeltacor_partial(e, dmat, neigh, kern, ops.RULES_PARTIAL, psc, validate=False)
+            sched = ops.hilbert_order(embedding) if embedding.shape[1] >= 2 else None      # scheduling only: same numbers in any order
+            self.__dict__["_embed_order"] = sched
+            self._corr = ops.coldeltacor_partial(e, dmat, neigh, kern, ops.RULES_PARTIAL, psc, validate=False, order=sched)
             if ops.corr_fixup(self._corr, neigh, zero_self=True, fix_nan=True, nan_to=1.0):                      # :1604-1607
                 logging.warning("Nans encountered in corrcoef and corrected to 1s. If not identical cells were present it is probably a small isolated cluster converging after imputation.")
             if calculate_randomized:
-                self._corr_random = ops.coldeltacor_partial(e, dmat_r, neigh, kern, ops.RULES_PARTIAL, psc, validate=False)
+                self._corr_random = ops.coldeltacor_partial(e, dmat_r, neigh, kern, ops.RULES_PARTIAL, psc, validate=False, order=sched)
                 if ops.corr_fixup(self._corr_random, neigh, zero_self=True, fix_nan=True, nan_to=1.0):
                     logging.warning("Nans encountered in corrcoef_random and corrected to 1s. If not identical cells were present it is probably a small isolated cluster converging after imputation.")
             else:
@@ -539,7 +548,8 @@ class VelocytoLoom(PreprocessMixin):
             if expression_scaling:
                 n = neigh.shape[1]
                 indptr = torch.arange(0, (neigh.shape[0] + 1) * n, n, dtype=torch.int64, device=dev)
-                estim = ops.knn_pool(hi, indptr, neigh.reshape(-1), wd.reshape(-1), validate=False)       # hi_dim @ (P - knn/n).T   (:1716)
+                estim = ops.knn_pool(hi, indptr, neigh.reshape(-1), wd.reshape(-1), validate=False,      # hi_dim @ (P - knn/n).T   (:1716)
+                                     order=self.__dict__.get("_embed_order") if self.corr_calc == "knn_random" else None)
                 cos_proj = ops.row_cosproj(self.dev(dS_name), estim)                                       # :1717
                 scaling = torch.clamp(cos_proj / scaling_penalty, 0, 1)                                    # NaN stays NaN, like np.clip
                 de = de * scaling[:, None]
