@@ -313,6 +313,21 @@ int vcy_diffuse_step_dense(const void *tr, const double *x, double *y, double *a
 int vcy_diffuse_step_csc(const int64_t *colptr, const int32_t *rowidx, const void *val, const double *x, double *y,
                          double *accum, int64_t n, int dtype, vcy_stream stream);
 
+/* ---------------------------------------------------------------- upstream callers: epsilon-SVR, RBF kernel, scalar inputs
+ * The noise models of score_cv_vs_mean (analysis.py:280-282, 324-326: sklearn.svm.SVR(gamma=150/G).fit(log2 mean, log2 CV), one point
+ * per gene) and adjust_totS_totU (analysis.py:844-851: SVR(C=100, kernel="rbf", gamma=1e-6) on per-cell totals).  scikit-learn
+ * delegates to libsvm: SMO with second-order working-set selection, stopping at a KKT violation < tol; vcy_svr_rbf_fit runs the
+ * same iteration on the device and agrees with it to the solver tolerance (not bit for bit: libsvm rounds kernel rows to float
+ * and shrinks).  x, t: (n) fp64 device.  coef (n) = alpha - alpha* (0 for non-support points), intercept (1),
+ * info (4, int32) = [SMO steps, converged, grid barrier failed, workgroups used].  max_iter <= 0: libsvm's own cap.
+ * workspace: vcy_svr_workspace_bytes(n).
+ * vcy_svr_rbf_predict: out[q] = sum_k coef[k] exp(-gamma (xq[q] - x[k])^2) + intercept[0]   (SVR.predict), xq / out: (m).     */
+int64_t vcy_svr_workspace_bytes(int64_t n);
+int vcy_svr_rbf_fit(const double *x, const double *t, double *coef, double *intercept, int32_t *info, void *workspace, int64_t n,
+                    double C, double epsilon, double gamma, double tol, int64_t max_iter, vcy_stream stream);
+int vcy_svr_rbf_predict(const double *x, const double *coef, const double *intercept, const double *xq, double *out, int64_t n,
+                        int64_t m, double gamma, vcy_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -147,13 +147,13 @@ def test_size_normalisations(vcy, golden, dtype):
     close(va.S_norm, g["nt_S_norm"], rt, at)
     va.adjust_totS_totU(normalize_total=True)
     close(va.S_sz, g["adj_S_sz"], max(rt, 1e-10), at)
-    close(va.U_sz, g["adj_U_sz"], max(rt, 1e-8), at)             # SVR prediction in the factor
+    close(va.U_sz, g["adj_U_sz"], max(rt, 2e-6), at)             # SVR prediction in the factor: two SMO solvers stopped at tol=1e-3 (libsvm there, csrc/svr.hip here; tests/test_gpu_svr.py)
     vb = filtered(vcy, g, dtype)
     vb.normalize_by_total(min_perc_U=5, skip_low_U_pop=False, same_size_UnS=True)
     close(vb.S_sz, g["nt2_S_sz"], rt, at)
     close(vb.U_sz, g["nt2_U_sz"], rt, at)
     vb.adjust_totS_totU(skip_low_U_pop=False, fit_with_low_U=False, normalize_total=False)
-    close(vb.U_sz, g["adj2_U_sz"], max(rt, 1e-8), at)
+    close(vb.U_sz, g["adj2_U_sz"], max(rt, 2e-6), at)
     vc = filtered(vcy, g, dtype)
     vc.normalize_by_size_factor(min_perc_U=0.5)
     close(vc.S_sz, g["sf_S_sz"], rt, at)
@@ -167,10 +167,10 @@ def test_size_normalisations(vcy, golden, dtype):
     va.knn_imputation(n_pca_dims=8, k=10, balanced=True, b_sight=80, b_maxl=40, n_jobs=1)
     va.normalize_median()
     close(va.Sx_sz, g["nm_Sx_sz"], max(rt, 1e-9), max(at, 1e-9))
-    close(va.Ux_sz, g["nm_Ux_sz"], max(rt, 1e-7), max(at, 1e-9))
+    close(va.Ux_sz, g["nm_Ux_sz"], max(rt, 2e-6), max(at, 1e-9))                 # pooled from the SVR-adjusted U_sz
     ve = deepcopy(va)
     ve.normalize_median(which="imputed", skip_low_U_pop=False)
-    close(ve.Ux_sz, g["nm2_Ux_sz"], max(rt, 1e-7), max(at, 1e-9))
+    close(ve.Ux_sz, g["nm2_Ux_sz"], max(rt, 2e-6), max(at, 1e-9))
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
@@ -218,9 +218,9 @@ def test_default_drivers(vcy, golden, dtype):
     vf.default_filter_and_norm(min_expr_counts=30, min_cells_express=15, N=180)
     assert np.array_equal(vf.ra["Gene"], g["dfn_genes"])
     close(vf.S_sz, g["dfn_S_sz"], 1e-10, 1e-11)
-    close(vf.U_sz, g["dfn_U_sz"], 1e-8, 1e-11)
+    close(vf.U_sz, g["dfn_U_sz"], 2e-6, 1e-11)                # through adjust_totS_totU's SVR
     vf.default_fit_preparation(k=12, n_comps=8)
     close(vf.pcs[:, :8], g["dfp_pcs"][:, :8], 0, 1e-7)
     close(vf.Sx_sz, g["dfp_Sx_sz"], 1e-8, 1e-9)
-    close(vf.Ux_sz, g["dfp_Ux_sz"], 1e-7, 1e-9)
+    close(vf.Ux_sz, g["dfp_Ux_sz"], 2e-6, 1e-9)
     assert int(np.where(np.diff(np.diff(np.cumsum(vf.pca.explained_variance_ratio_)) > 0.002))[0][0]) == int(g["dfp_n_comps_rule"])

@@ -1,0 +1,103 @@
+"""Device epsilon-SVR (vcy_svr_rbf_fit / vcy_svr_rbf_predict, DeviceSVR) against scikit-learn's SVR (libsvm), the third-party
+solver the reference calls in score_cv_vs_mean (analysis.py:280-282, 324-326) and adjust_totS_totU (analysis.py:844-851).
+libsvm stops at a KKT violation < tol, so two correct solvers agree to about tol in the prediction; with tol tightened on both
+sides they must agree much more closely - that is the parity statement, the default-tol comparison is the usage statement."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cv_like(n, rng):
+    x = np.log2(rng.gamma(0.5, 0.5, n) + 1e-3)
+    return x, -0.5 * x + 0.3 * rng.normal(size=n) + 0.5 * np.exp(-x * x)
+
+
+def _totals_like(n, rng):
+    x = rng.gamma(5, 2000, n)
+    return x, 0.3 * x * (1 + 0.2 * np.sin(x / 5000)) + rng.normal(0, 300, n)
+
+
+CASES = [("cv", 300, dict(C=1.0, gamma=0.5)), ("cv", 513, dict(C=1.0, gamma=150. / 513)), ("cv", 3000, dict(C=1.0, gamma=0.05)),
+         ("totals", 257, dict(C=100.0, gamma=1e-6)), ("totals", 2500, dict(C=100.0, gamma=1e-6)), ("totals", 1025, dict(C=3.0, gamma=1e-7, epsilon=25.0))]
+
+
+@pytest.mark.parametrize("kind,n,kw", CASES)
+def test_svr_matches_libsvm(kind, n, kw):
+    from sklearn.svm import SVR
+    from velocyto_amd.preprocess import DeviceSVR
+    rng = np.random.default_rng(n)
+    x, t = (_cv_like if kind == "cv" else _totals_like)(n, rng)
+    xq = np.concatenate([x[:50], np.linspace(x.min() - 1, x.max() + 1, 77)])
+    # tight tolerance on both sides: the optimum itself
+    ref = SVR(tol=1e-7, **kw).fit(x[:, None], t)
+    dev = DeviceSVR(tol=1e-7, **kw).fit(x[:, None], t)
+    assert dev.fit_status_ == 0
+    scale = max(1.0, np.abs(t).max())
+    np.testing.assert_allclose(dev.predict(xq[:, None]), ref.predict(xq[:, None]), atol=2e-6 * scale, rtol=0)
+    np.testing.assert_allclose(dev.intercept_, ref.intercept_, atol=2e-6 * scale, rtol=0)
+    # default tolerance: what the facade runs
+    ref = SVR(**kw).fit(x[:, None], t)
+    dev = DeviceSVR(**kw).fit(x[:, None], t)
+    # (the stopping rule bounds the gradient, i.e. the residuals, by tol; how far two stopped solvers sit apart grows with the
+    # box: measured 1e-3 for C = 1 and 1e-2 on targets of 4e3 for C = 100)
+    assert np.abs(dev.predict(xq[:, None]) - ref.predict(xq[:, None])).max() < 8e-3 * max(1.0, kw["C"] / 20)
+    assert abs(len(dev.support_) - len(ref.support_)) <= max(2, n // 200)
+    assert dev.dual_coef_.shape == (1, len(dev.support_)) and dev.support_vectors_.shape == (len(dev.support_), 1)
+    assert np.abs(dev.dual_coef_).max() <= kw["C"] * (1 + 1e-12) and abs(dev.dual_coef_.sum()) < 1e-9 * n * kw["C"]      # box and y'b = 0
+
+
+def test_svr_does_not_depend_on_the_number_of_workgroups(monkeypatch):
+    """Selection ties are broken by index, so the SMO trajectory is the same on 1, 3 or 64 workgroups."""
+    from velocyto_amd import ops
+    rng = np.random.default_rng(5)
+    x, t = _cv_like(4000, rng)
+    res = []
+    for wg in ("1", "3", "64", None):
+        if wg is None:
+            monkeypatch.delenv("VCY_SVR_WG", raising=False)
+        else:
+            monkeypatch.setenv("VCY_SVR_WG", wg)
+        coef, b, info = ops.svr_fit(x, t, C=1.0, gamma=150. / 4000)
+        res.append((coef.cpu().numpy(), float(b), info.cpu().numpy()))
+    assert [int(r[2][3]) for r in res] == [1, 3, 64, 8] and all(r[2][1] == 1 and r[2][2] == 0 for r in res)
+    for r in res[1:]:
+        assert r[2][0] == res[0][2][0]
+        np.testing.assert_array_equal(r[0], res[0][0])
+        assert r[1] == res[0][1]
+
+
+def test_svr_edge_cases():
+    from sklearn.svm import SVR
+    from velocyto_amd import ops
+    from velocyto_amd.preprocess import DeviceSVR
+    # every target inside the tube: no support vectors, intercept = midpoint of the bounds (libsvm's calculate_rho)
+    x = np.linspace(0, 1, 40); t = 0.05 * np.sin(7 * x)
+    ref, dev = SVR(gamma=2.0).fit(x[:, None], t), DeviceSVR(gamma=2.0).fit(x[:, None], t)
+    assert len(dev.support_) == len(ref.support_) == 0 and dev.n_iter_ == 0
+    np.testing.assert_allclose(dev.intercept_, ref.intercept_, atol=1e-12)
+    np.testing.assert_allclose(dev.predict(x[:, None]), ref.predict(x[:, None]), atol=1e-12)
+    # one point, two points, duplicated inputs with different targets (zero curvature: libsvm's tau)
+    for x, t in ((np.array([1.0]), np.array([5.0])), (np.array([0.0, 1.0]), np.array([0.0, 3.0])),
+                 (np.array([1.0, 1.0, 1.0, 2.0, 2.0]), np.array([0.0, 1.0, 2.0, -1.0, 4.0]))):
+        ref, dev = SVR(gamma=1.0, tol=1e-9).fit(x[:, None], t), DeviceSVR(gamma=1.0, tol=1e-9).fit(x[:, None], t)
+        np.testing.assert_allclose(dev.predict(x[:, None]), ref.predict(x[:, None]), atol=1e-6)
+    # gamma="scale" (sklearn's default) and a capped solver
+    rng = np.random.default_rng(2)
+    x, t = _cv_like(600, rng)
+    ref, dev = SVR(tol=1e-8).fit(x[:, None], t), DeviceSVR(tol=1e-8).fit(x[:, None], t)
+    np.testing.assert_allclose(dev.predict(x[:, None]), ref.predict(x[:, None]), atol=1e-5)
+    capped = DeviceSVR(gamma=0.3, max_iter=7).fit(x[:, None], t)
+    assert capped.n_iter_ == 7 and capped.fit_status_ == 1
+    # argument errors are the host's, before any launch
+    with pytest.raises(ValueError):
+        DeviceSVR().fit(x, t)                                    # 1-D X, as scikit-learn
+    with pytest.raises(ValueError):
+        DeviceSVR().fit(x[:, None], t[:-1])
+    with pytest.raises(ValueError):
+        ops.svr_fit(np.array([1.0, np.nan]), np.array([0.0, 1.0]))
+    with pytest.raises(ValueError):
+        ops.svr_fit(x, t, C=-1.0)
+    assert ops.svr_predict(x, np.zeros_like(x), np.zeros(1), np.zeros(0), 1.0).numel() == 0

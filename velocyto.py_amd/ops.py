@@ -583,6 +583,39 @@ def gene_stats(M, cell_scale=None, lo=None, hi=None, cell_mask=None) -> torch.Te
     return out
 
 
+def svr_fit(x, t, C: float = 1.0, epsilon: float = 0.1, gamma: float = 1.0, tol: float = 1e-3, max_iter: int = -1):
+    """epsilon-SVR (RBF kernel, scalar inputs) fitted on the device: (coef (n) = alpha - alpha*, intercept (1), info (4) int32 =
+    [SMO steps, converged, barrier failed, workgroups]).  The fit sklearn.svm.SVR(C, epsilon, gamma, tol).fit(x[:, None], t) does
+    with libsvm (analysis.py:280-282, 324-326, 844-851), to the solver tolerance."""
+    dev = require_gpu()
+    x = torch.as_tensor(x, device=dev).to(torch.float64).contiguous().ravel()
+    t = torch.as_tensor(t, device=dev).to(torch.float64).contiguous().ravel()
+    n = int(x.numel())
+    if n < 1 or int(t.numel()) != n:
+        raise ValueError("svr_fit: x and t must be non-empty vectors of the same length")
+    if not (bool(torch.isfinite(x).all()) and bool(torch.isfinite(t).all())):
+        raise ValueError("Input contains NaN, infinity or a value too large for dtype('float64').")        # sklearn's check_array
+    coef = torch.empty(n, dtype=torch.float64, device=dev)
+    intercept = torch.empty(1, dtype=torch.float64, device=dev)
+    info = torch.empty(4, dtype=torch.int32, device=dev)
+    ws = torch.empty(int(_lib.lib().vcy_svr_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib().vcy_svr_rbf_fit(x.data_ptr(), t.data_ptr(), coef.data_ptr(), intercept.data_ptr(), info.data_ptr(), ws.data_ptr(),
+                                          n, float(C), float(epsilon), float(gamma), float(tol), int(max_iter), _stream()), "svr_rbf_fit")
+    return coef, intercept, info
+
+
+def svr_predict(x, coef, intercept, xq, gamma: float) -> torch.Tensor:
+    """SVR.predict: sum_k coef[k] exp(-gamma (xq - x[k])^2) + intercept for every query."""
+    dev = require_gpu()
+    f64 = lambda v: torch.as_tensor(v, device=dev).to(torch.float64).contiguous().ravel()
+    x, coef, intercept, xq = f64(x), f64(coef), f64(intercept), f64(xq)
+    assert x.numel() == coef.numel() and intercept.numel() == 1
+    out = torch.empty(int(xq.numel()), dtype=torch.float64, device=dev)
+    _lib.check(_lib.lib().vcy_svr_rbf_predict(x.data_ptr(), coef.data_ptr(), intercept.data_ptr(), xq.data_ptr(), out.data_ptr(),
+                                              int(x.numel()), int(xq.numel()), float(gamma), _stream()), "svr_rbf_predict")
+    return out
+
+
 def select_cells(M, keep) -> "CellMatrix":
     """Cell (row) subset of a cells-major matrix (CellMatrix or CountMatrix)."""
     idx = torch.nonzero(torch.as_tensor(keep, device=M.t.device), as_tuple=False).ravel()
