@@ -570,3 +570,31 @@ def test_stage_e_f_kernels_on_odd_shapes(ops, oracle, C, n, edim):
             xf, xa = ops.diffuse(x0 / x0.sum(), torch.from_numpy(ref).cuda(), 9, accumulate=acc)
             want = oracle.diffuse(x0, ref, 9, mode).ravel()
             np.testing.assert_allclose((xa if acc else xf).cpu().numpy(), want, rtol=1e-11)
+
+
+@pytest.mark.parametrize("n", [1024, 1026, 1301, 4100])
+@pytest.mark.parametrize("tdtype", ["float32", "float64"])
+def test_diffuse_dense_wide_loads(ops, oracle, n, tdtype):
+    """The dense Markov step at sizes that take the 16-byte-load kernel (n a multiple of 4 / 2 columns per thread, aligned base)
+    and at sizes / alignments that take the one-column kernel: both against numpy, and bit-identical to each other."""
+    rng = np.random.default_rng(n)
+    tr = rng.random((n, n)) ** 8
+    tr /= tr.sum(1, keepdims=True)
+    tr = tr.astype(tdtype)
+    x0 = rng.random(n)
+    x0 /= x0.sum()
+    dev = ops.require_gpu()
+    aligned = torch.from_numpy(tr).to(dev)
+    buf = torch.empty(n * n + 1, dtype=aligned.dtype, device=dev)
+    shifted = buf[1:].view(n, n)                                     # same values, base address off by one element: one-column kernel
+    shifted.copy_(aligned)
+    assert shifted.data_ptr() % 16 != 0 and aligned.data_ptr() % 16 == 0
+    for acc, mode in ((False, "time_evolution"), (True, "path_integral")):
+        xf, xa = ops.diffuse(x0, aligned, 5, accumulate=acc)
+        xs, xsa = ops.diffuse(x0, shifted, 5, accumulate=acc)
+        got, got_s = ((xa, xsa) if acc else (xf, xs))
+        np.testing.assert_allclose(got.cpu().numpy(), oracle.diffuse(x0, tr.astype(np.float64), 5, mode).ravel(), rtol=1e-11)
+        assert torch.equal(got, got_s)
+    # the graph-replayed long loop takes the same kernels
+    xl, _ = ops.diffuse(x0, aligned, 40, accumulate=False)
+    np.testing.assert_allclose(xl.cpu().numpy(), oracle.diffuse(x0, tr.astype(np.float64), 40, "time_evolution").ravel(), rtol=1e-10)

@@ -172,6 +172,43 @@ __global__ __launch_bounds__(256) void k_vecmat_dense(const T *__restrict__ Tm, 
     for (int i = i0; i < i1; ++i) acc = fma(x[i], (double)Tm[(int64_t)i * n + j], acc);
     part[(int64_t)blockIdx.y * n + j] = acc;
 }
+// the same sums with 16-byte loads: a thread owns Vec<T>::N adjacent columns (n % N == 0 keeps every row 16-byte aligned) and
+// keeps 8 rows in flight; each column still accumulates its rows in ascending order, so the result is bit-identical to
+// k_vecmat_dense.  One step streams the whole matrix once: this is the HBM-bound kernel of run_markov.
+template <typename T>
+__global__ __launch_bounds__(256) void k_vecmat_dense_vec(const T *__restrict__ Tm, const double *__restrict__ x, double *__restrict__ part, int n)
+{
+    constexpr int N = Vec<T>::N;
+    typedef T V __attribute__((ext_vector_type(N)));
+    const int j = (blockIdx.x * blockDim.x + threadIdx.x) * N;
+    if (j >= n) return;
+    const int per = (n + gridDim.y - 1) / gridDim.y;
+    const int i0 = blockIdx.y * per, i1 = min(n, i0 + per);
+    double acc[N];
+#pragma unroll
+    for (int c = 0; c < N; ++c) acc[c] = 0.0;
+    const T *p = Tm + (int64_t)i0 * n + j;
+    int i = i0;
+    for (; i + 8 <= i1; i += 8, p += (int64_t)8 * n) {
+        V v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load((const V *)(p + (int64_t)u * n));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double xi = x[i + u];
+#pragma unroll
+            for (int c = 0; c < N; ++c) acc[c] = fma(xi, (double)v[u][c], acc[c]);
+        }
+    }
+    for (; i < i1; ++i, p += n) {
+        const V v = *(const V *)p;
+        const double xi = x[i];
+#pragma unroll
+        for (int c = 0; c < N; ++c) acc[c] = fma(xi, (double)v[c], acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < N; ++c) part[(int64_t)blockIdx.y * n + j + c] = acc[c];
+}
 __global__ void k_vecmat_reduce(const double *__restrict__ part, double *__restrict__ y, double *__restrict__ accum, int n, int nparts)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -376,9 +413,15 @@ extern "C" int vcy_diffuse_step_dense(const void *tr, const double *x, double *y
     const int nparts = n >= 4096 ? 64 : (n >= 512 ? 16 : 1);
     dim3 grid((unsigned)((n + 255) / 256), nparts);
     hipStream_t st = as_stream(stream);
-    if (dtype == VCY_F32) hipLaunchKernelGGL(k_vecmat_dense<float>, grid, dim3(256), 0, st, (const float *)tr, x, (double *)workspace, (int)n);
-    else if (dtype == VCY_F64) hipLaunchKernelGGL(k_vecmat_dense<double>, grid, dim3(256), 0, st, (const double *)tr, x, (double *)workspace, (int)n);
-    else return fail(VCY_ERR_INVALID, "%s: bad dtype", "diffuse_step_dense");
+    VCY_REQUIRE(dtype == VCY_F32 || dtype == VCY_F64, "diffuse_step_dense: bad dtype");
+    const int per_thread = dtype == VCY_F32 ? 4 : 2;
+    if (n % per_thread == 0 && ((uintptr_t)tr & 15) == 0 && n >= 1024) {
+        dim3 gv((unsigned)((n / per_thread + 255) / 256), nparts);
+        if (dtype == VCY_F32) hipLaunchKernelGGL(k_vecmat_dense_vec<float>, gv, dim3(256), 0, st, (const float *)tr, x, (double *)workspace, (int)n);
+        else hipLaunchKernelGGL(k_vecmat_dense_vec<double>, gv, dim3(256), 0, st, (const double *)tr, x, (double *)workspace, (int)n);
+    }
+    else if (dtype == VCY_F32) hipLaunchKernelGGL(k_vecmat_dense<float>, grid, dim3(256), 0, st, (const float *)tr, x, (double *)workspace, (int)n);
+    else hipLaunchKernelGGL(k_vecmat_dense<double>, grid, dim3(256), 0, st, (const double *)tr, x, (double *)workspace, (int)n);
     VCY_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_vecmat_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double *)workspace, y, accum, (int)n, nparts);
     VCY_LAUNCH_CHECK();
