@@ -19,6 +19,10 @@
 #include "common.h"
 #include <stdlib.h>
 
+// the register-resident and the global-memory variants of the solver must round alike (same trajectory on any launch shape):
+// no mul+add fusion beyond the explicit fma calls
+#pragma clang fp contract(off)
+
 namespace vcy {
 
 constexpr int SVR_TPB = 256;
@@ -96,6 +100,10 @@ __device__ __forceinline__ unsigned char svr_flags(unsigned char st, int part, d
 }
 
 // info: [0] SMO steps taken, [1] converged, [2] a grid barrier failed, [3] workgroups used.
+// E > 0: a thread owns at most E points (k0 + e * step) and keeps their x, r, alpha, alpha* and bound flags in registers for the
+// whole solve (n <= gridDim.x * 256 * E), so a sweep touches no memory at all; E == 0: any n, state in global memory (L2).
+// Both run the same arithmetic in the same order: the trajectory is the same.
+template <int E>
 __global__ __launch_bounds__(SVR_TPB) void k_svr_smo(const double *__restrict__ x, const double *__restrict__ t, double *__restrict__ r,
                                                       double *__restrict__ alpha /* (2, n) */, unsigned char *__restrict__ status,
                                                       SvrShared *__restrict__ sh, int *__restrict__ info, int n, double Cbox, double eps,
@@ -110,11 +118,20 @@ __global__ __launch_bounds__(SVR_TPB) void k_svr_smo(const double *__restrict__ 
     const int step = nwg * SVR_TPB, k0 = wg * SVR_TPB + tid;
     unsigned epoch = 0;
 
-    for (int k = k0; k < n; k += step) {           // b = 0: f = 0, r = t, every variable at its lower bound
-        r[k] = t[k];
-        alpha[k] = 0.0;
-        alpha[(size_t)n + k] = 0.0;
-        status[k] = SVR_A_LO | SVR_S_LO;
+    constexpr bool REG = E > 0;
+    constexpr int EE = REG ? E : 1;
+    double xs[EE], rs[EE], a0[EE], a1[EE];
+    unsigned char ss[EE];
+#define SVR_FOR_OWNED(e, k) for (int e = 0, k = k0; (!REG || e < E) && k < n; ++e, k += step)
+#pragma unroll
+    SVR_FOR_OWNED(e, k) {                          // b = 0: f = 0, r = t, every variable at its lower bound
+        if (REG) { xs[e] = x[k]; rs[e] = t[k]; a0[e] = 0.0; a1[e] = 0.0; ss[e] = SVR_A_LO | SVR_S_LO; }
+        else {
+            r[k] = t[k];
+            alpha[k] = 0.0;
+            alpha[(size_t)n + k] = 0.0;
+            status[k] = SVR_A_LO | SVR_S_LO;
+        }
     }
     bool pending = false, ok = true, converged = false;
     int pi = -1, pj = -1, parti = 0, partj = 0;
@@ -163,29 +180,38 @@ __global__ __launch_bounds__(SVR_TPB) void k_svr_smo(const double *__restrict__ 
     while (true) {
         // ---- sweep 1: apply the previous step to the residuals, then i = argmax over I_up of -y G and min over I_low
         SvrCand up{-INFINITY, -1};
-        double low = INFINITY, ux = 0.0, ur = 0.0;
-        for (int k = k0; k < n; k += step) {
-            const double xk = x[k];
-            double rk = r[k];
-            unsigned char st = status[k];
+        double low = INFINITY, ux = 0.0, ur = 0.0, ub = 0.0;
+#pragma unroll
+        SVR_FOR_OWNED(e, k) {
+            const double xk = REG ? xs[e] : x[k];
+            double rk = REG ? rs[e] : r[k];
+            unsigned char st = REG ? ss[e] : status[k];
             if (pending) {
                 const double di = xk - xi, dj = xk - xj;
                 rk -= dci * exp(-gamma * di * di) + dcj * exp(-gamma * dj * dj);
-                r[k] = rk;
-                if (k == pi) { st = svr_flags(st, parti, bi_new, Cbox); alpha[(size_t)parti * n + k] = bi_new; status[k] = st; }
-                if (k == pj) { st = svr_flags(st, partj, bj_new, Cbox); alpha[(size_t)partj * n + k] = bj_new; status[k] = st; }
+                if (k == pi) st = svr_flags(st, parti, bi_new, Cbox);
+                if (k == pj) st = svr_flags(st, partj, bj_new, Cbox);
+                if (REG) {
+                    rs[e] = rk; ss[e] = st;
+                    if (k == pi) { if (parti == 0) a0[e] = bi_new; else a1[e] = bi_new; }
+                    if (k == pj) { if (partj == 0) a0[e] = bj_new; else a1[e] = bj_new; }
+                } else {
+                    r[k] = rk;
+                    if (k == pi) { alpha[(size_t)parti * n + k] = bi_new; status[k] = st; }
+                    if (k == pj) { alpha[(size_t)partj * n + k] = bj_new; status[k] = st; }
+                }
             }
             const double vA = rk - eps, vS = rk + eps;
             const long long before = up.idx;
             if (!(st & SVR_A_HI)) up = better_max(up, SvrCand{vA, (long long)k});
             if (!(st & SVR_S_LO)) up = better_max(up, SvrCand{vS, (long long)k + n});
-            if (up.idx != before) { ux = xk; ur = rk; }
+            if (up.idx != before) { ux = xk; ur = rk; if (REG) ub = up.idx >= n ? a1[e] : a0[e]; }
             if (!(st & SVR_A_LO)) low = fmin(low, vA);
             if (!(st & SVR_S_HI)) low = fmin(low, vS);
         }
         {
             const SvrCand mine = up;
-            const double ub = mine.idx >= 0 ? alpha[mine.idx] : 0.0;           // alpha is (2, n): variable idx lives at alpha[idx]
+            if (!REG) ub = mine.idx >= 0 ? alpha[mine.idx] : 0.0;              // alpha is (2, n): variable idx lives at alpha[idx]
             up = wave_best<true>(up);
             low = wave_min_d(low);
             if (lane == 0) { s_c[wv] = up; s_m[wv] = low; }
@@ -205,21 +231,22 @@ __global__ __launch_bounds__(SVR_TPB) void k_svr_smo(const double *__restrict__ 
 
         // ---- sweep 2: j = argmin over I_low, -y G < Gmax, of -(Gmax + y G)^2 / (K_ii + K_jj - 2 K_ij)
         SvrCand best{INFINITY, -1};
-        double jx = 0.0, jr = 0.0;
-        for (int k = k0; k < n; k += step) {
-            const double xk = x[k], d = xk - xi, rk = r[k];
-            const unsigned char st = status[k];
+        double jx = 0.0, jr = 0.0, jb = 0.0;
+#pragma unroll
+        SVR_FOR_OWNED(e, k) {
+            const double xk = REG ? xs[e] : x[k], d = xk - xi, rk = REG ? rs[e] : r[k];
+            const unsigned char st = REG ? ss[e] : status[k];
             double a = 2.0 - 2.0 * exp(-gamma * d * d);
             if (!(a > 0.0)) a = SVR_TAU;
             const double bA = Gmax - (rk - eps), bS = Gmax - (rk + eps), ninv = -1.0 / a;
             const long long before = best.idx;
             if (!(st & SVR_A_LO) && bA > 0.0) best = better_min(best, SvrCand{bA * bA * ninv, (long long)k});
             if (!(st & SVR_S_HI) && bS > 0.0) best = better_min(best, SvrCand{bS * bS * ninv, (long long)k + n});
-            if (best.idx != before) { jx = xk; jr = rk; }
+            if (best.idx != before) { jx = xk; jr = rk; if (REG) jb = best.idx >= n ? a1[e] : a0[e]; }
         }
         {
             const SvrCand mine = best;
-            const double jb = mine.idx >= 0 ? alpha[mine.idx] : 0.0;
+            if (!REG) jb = mine.idx >= 0 ? alpha[mine.idx] : 0.0;
             best = wave_best<false>(best);
             if (lane == 0) s_c[wv] = best;
             __syncthreads();
@@ -267,6 +294,11 @@ __global__ __launch_bounds__(SVR_TPB) void k_svr_smo(const double *__restrict__ 
         pending = true;
         ++it;
     }
+    if (REG) {                                        // hand the state to k_svr_finish
+#pragma unroll
+        SVR_FOR_OWNED(e, k) { r[k] = rs[e]; alpha[k] = a0[e]; alpha[(size_t)n + k] = a1[e]; status[k] = ss[e]; }
+    }
+#undef SVR_FOR_OWNED
     if (wg == 0 && tid == 0) {
         info[0] = (int)(it > 0x7fffffffll ? 0x7fffffffll : it);
         info[1] = converged ? 1 : 0;
@@ -366,15 +398,18 @@ extern "C" int vcy_svr_rbf_fit(const double *x, const double *t, double *coef, d
     long long mi = max_iter;
     void *args[] = {(void *)&x, (void *)&t, (void *)&r, (void *)&alpha, (void *)&status, (void *)&sh, (void *)&info,
                     (void *)&ni, (void *)&C, (void *)&epsilon, (void *)&gamma, (void *)&tol, (void *)&mi};
+    auto kernel_for = [&](int wgs) -> const void * {         // points per thread -> register-resident variant, else the generic one
+        const int64_t per = (n + (int64_t)wgs * SVR_TPB - 1) / ((int64_t)wgs * SVR_TPB);
+        if (getenv("VCY_SVR_GLOBAL")) return (const void *)k_svr_smo<0>;
+        return per <= 1 ? (const void *)k_svr_smo<1> : per <= 2 ? (const void *)k_svr_smo<2> : per <= 4 ? (const void *)k_svr_smo<4>
+             : per <= 8 ? (const void *)k_svr_smo<8> : (const void *)k_svr_smo<0>;
+    };
     if (nwg > 1) {
         // co-residency of the workgroups is what makes the grid barrier safe: ask the runtime for it
-        hipError_t e = hipLaunchCooperativeKernel((const void *)k_svr_smo, dim3(nwg), dim3(SVR_TPB), args, 0, s);
+        hipError_t e = hipLaunchCooperativeKernel(kernel_for(nwg), dim3(nwg), dim3(SVR_TPB), args, 0, s);
         if (e != hipSuccess) { (void)hipGetLastError(); nwg = 1; }
     }
-    if (nwg == 1) {
-        hipLaunchKernelGGL(k_svr_smo, dim3(1), dim3(SVR_TPB), 0, s, x, t, r, alpha, status, sh, info, ni, C, epsilon, gamma, tol, mi);
-        VCY_LAUNCH_CHECK();
-    }
+    if (nwg == 1) VCY_CHECK_HIP(hipLaunchKernel(kernel_for(1), dim3(1), dim3(SVR_TPB), args, 0, s));
     hipLaunchKernelGGL(k_svr_finish, dim3(1), dim3(1024), 0, s, r, alpha, status, coef, intercept, ni, epsilon);
     VCY_LAUNCH_CHECK();
     return VCY_OK;
