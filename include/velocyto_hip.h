@@ -328,6 +328,14 @@ int vcy_svr_rbf_fit(const double *x, const double *t, double *coef, double *inte
 int vcy_svr_rbf_predict(const double *x, const double *coef, const double *intercept, const double *xq, double *out, int64_t n,
                         int64_t m, double gamma, vcy_stream stream);
 
+/* ---------------------------------------------------------------- host helper: neighbour sampling of estimate_transition_prob
+ * analysis.py:1561-1564 draws, per cell, np.random.choice(n, size, replace=False, p=p) from numpy's legacy global RNG.  This is
+ * RandomState.choice(replace=False, p) restated over a pool of uniforms the caller drew from the same RandomState in one call
+ * (host pointers, no device work): out (cells, size) int64 gets what the per-cell calls would have returned, *cells_done the
+ * number of cells whose draws fitted in the pool and *consumed the uniforms they used (advance the RandomState by that).     */
+int vcy_choice_stream_host(const double *pool, int64_t pool_len, const double *p, int64_t n, int64_t size, int64_t cells,
+                           int64_t *out, int64_t *cells_done, int64_t *consumed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -131,3 +131,48 @@ def test_package_root_mirrors_the_reference_exports():
     sb = v.speedboosted
     assert all(hasattr(sb, n) for n in ("_colDeltaCor", "_colDeltaCorSqrt", "_colDeltaCorLog10", "_colDeltaCorpartial",
                                          "_colDeltaCorSqrtpartial", "_colDeltaCorLog10partial"))
+
+
+def _rng_state_equal(a, b):
+    return a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+
+
+@pytest.mark.parametrize("n,size,cells,kind", [(101, 50, 40, "ramp"), (501, 250, 64, "ramp"), (30, 30, 25, "ramp"), (64, 20, 30, "zeros"),
+                                               (17, 1, 50, "uniform"), (200, 199, 12, "steep"), (12, 0, 5, "uniform"), (9, 4, 0, "uniform")])
+def test_choice_stream_host_replays_numpy(lib, n, size, cells, kind):
+    """The neighbour sampling of estimate_transition_prob (analysis.py:1561-1564): the block helper must return what the
+    reference's per-cell np.random.choice(n, size, replace=False, p=p) calls return, draw for draw, and leave numpy's global
+    RNG in the same state - whatever the block / pool sizes (refill path, cells that do not fit the pool)."""
+    from velocyto_amd import ops
+    p = {"ramp": np.linspace(0.5, 0.1, n), "uniform": np.ones(n), "steep": np.geomspace(1.0, 1e-6, n),
+         "zeros": np.where(np.arange(n) % 3 == 0, 0.0, np.linspace(1, 2, n))}[kind]
+    p = p / p.sum()
+    np.random.seed(15071990 + n)
+    want = np.stack([np.random.choice(n, size=(size,), replace=False, p=p) for _ in range(cells)], 0) if cells else np.empty((0, size), dtype=np.int64)
+    after = np.random.get_state()
+    tail = np.random.random_sample(3)
+    for block, factor in ((4096, 1.5), (7, 1.5), (3, 0.2), (1, 0.01)):
+        np.random.seed(15071990 + n)
+        got = ops.choice_stream_host(n, size, p, cells, block=block, pool_factor=factor)
+        assert got.dtype == np.int64 and got.shape == (cells, size)
+        assert np.array_equal(got, want)
+        assert _rng_state_equal(np.random.get_state(), after)
+        assert np.array_equal(np.random.random_sample(3), tail)
+
+
+def test_choice_stream_host_argument_errors(lib):
+    from velocyto_amd import ops
+    p = np.ones(10) / 10
+    with pytest.raises(ValueError):
+        ops.choice_stream_host(10, 11, p, 3)                       # larger sample than population
+    with pytest.raises(ValueError):
+        ops.choice_stream_host(10, 3, p * 0.9, 3)                  # does not sum to 1
+    with pytest.raises(ValueError):
+        ops.choice_stream_host(10, 3, p[:9], 3)
+    q = np.zeros(10); q[:2] = 0.5
+    with pytest.raises(ValueError):
+        ops.choice_stream_host(10, 3, q, 3)                        # fewer non-zero entries in p than size
+    state = np.random.get_state()
+    q = p.copy(); q[0], q[1] = -0.1, 0.3
+    with pytest.raises(ValueError):
+        ops.choice_stream_host(10, 3, q, 3)                        # negative probability

@@ -449,7 +449,7 @@ class VelocytoLoom(PreprocessMixin):
         self.which_hidim = hidim
         n_neighbors = kwargs.pop("n_neighbors", None)
         # extension (not in the reference): draw the neighbour subsample on the device instead of replaying numpy's
-        # legacy RNG stream cell by cell (3 s at 50k cells); same distribution, different random numbers
+        # legacy RNG stream (0.3 s at 50k cells); same distribution, different random numbers
         device_sampling = bool(kwargs.pop("device_sampling", False))
         if kwargs:
             logging.warning(f"keyword arguments were passed but could not be interpreted {kwargs}")
@@ -498,7 +498,7 @@ class VelocytoLoom(PreprocessMixin):
                 sampling_ixs = torch.topk(keys, size, dim=1).indices.cpu().numpy()
             else:
                 # identical numpy legacy-RNG stream to the reference (:1561-1564)
-                sampling_ixs = np.stack([np.random.choice(neigh_ixs.shape[1], size=(size,), replace=False, p=p) for _ in range(C)], 0)
+                sampling_ixs = ops.choice_stream_host(neigh_ixs.shape[1], size, p, C)
             self.sampling_ixs = sampling_ixs
             neigh_ixs = neigh_ixs[np.arange(C)[:, None], sampling_ixs]
             nonzero = neigh_ixs.shape[0] * neigh_ixs.shape[1]

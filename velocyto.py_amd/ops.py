@@ -523,6 +523,48 @@ def balance_knn_host(dsi: np.ndarray, dist: Optional[np.ndarray], lsi: np.ndarra
     return dist_new, dsi_new, l
 
 
+def choice_stream_host(n: int, size: int, p: np.ndarray, cells: int, block: int = 4096, pool_factor: float = 1.5) -> np.ndarray:
+    """``np.stack([np.random.choice(n, size=size, replace=False, p=p) for _ in range(cells)])`` - the neighbour sampling of
+    estimate_transition_prob (analysis.py:1561-1564) - with the same draws from numpy's global legacy RNG and the same RNG
+    state afterwards, without the per-cell trips through RandomState.choice: the uniforms of a block of cells are drawn in one
+    call and vcy_choice_stream_host replays choice's rounds over them."""
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    n, size, cells = int(n), int(size), int(cells)
+    if p.shape != (n,):
+        raise ValueError("'a' and 'p' must have same size")
+    if abs(float(p.sum()) - 1.0) > np.sqrt(np.finfo(np.float64).eps):
+        raise ValueError("probabilities do not sum to 1")
+    if size > n:
+        raise ValueError("Cannot take a larger sample than population when 'replace=False'")
+    out = np.empty((cells, size), dtype=np.int64)
+    done_total = 0
+    cd, used = ctypes.c_int64(0), ctypes.c_int64(0)
+    pending = np.empty(0, dtype=np.float64)                  # uniforms drawn but not consumed yet (carried to the next block)
+    draws = []                                               # (RNG state before the draw, number drawn), to hand back the unused tail
+    while done_total < cells and size > 0:
+        todo = min(int(block), cells - done_total)
+        want = max(int(todo * size * pool_factor) + size - pending.size, size)
+        draws.append((np.random.get_state(), want))
+        pool = np.concatenate([pending, np.random.random_sample(want)])
+        _lib.check(_lib.lib().vcy_choice_stream_host(pool.ctypes.data, pool.size, p.ctypes.data, n, size, todo, out[done_total:].ctypes.data,
+                                                     ctypes.byref(cd), ctypes.byref(used)), "choice_stream")
+        pending = pool[used.value:]
+        if cd.value == 0:
+            pool_factor *= 2                                 # a cell needed more rounds than the pool held: draw more
+        done_total += cd.value
+    left = pending.size                                      # leave the RNG where the per-cell calls would have left it
+    while left > 0:
+        state, drawn = draws.pop()
+        np.random.set_state(state)
+        if drawn >= left:
+            if drawn > left:
+                np.random.random_sample(drawn - left)
+            left = 0
+        else:
+            left -= drawn
+    return out
+
+
 # --------------------------------------------------------------------------- stage B
 _fit_ws = {}
 
