@@ -303,6 +303,22 @@ int vcy_row_cosproj(const void *A, const void *B, double *out, int64_t C, int64_
 int vcy_prepare_markov(const int64_t *indptr, const int32_t *indices, const double *pval, const double *embedding, int edim,
                        void *tr, int64_t n, double sigma_D, double sigma_W, int dtype, vcy_stream stream);
 
+/* The same chain in factored form, for when the dense (n, n) matrix is the problem (10-20 GB at 50 000 cells, read once per step):
+ * tr[c,j] = (0.2 K_W(c,j) / kw[c] + s[c,j]) / tot[c] with s sparse (pattern of P plus the diagonal) and K_W the Gaussian of the
+ * embedding distance (analysis.py:1853-1862 regrouped).  vcy_prepare_markov_factored writes sval (nnz of P, CSR order; 0 where P
+ * stores a diagonal entry), sdiag (n), kw (n), tot (n) and es (n, edim) of `compute_dtype` (VCY_F32 / VCY_F64) = embedding scaled so
+ * that K_W = g exp2(-|es_c - es_j|^2).  vcy_diffuse_step_factored is one step y = x . tr (+ accum += y) of Diffusion.diffuse
+ * (diffusion.py:93-105) from those factors: colptr / rowidx / scsc = s including its diagonal in CSC form; the Gauss transform is
+ * evaluated on the fly in `compute_dtype` (8 terms folded before they reach the fp64 accumulator), the rest in fp64.
+ * workspace: vcy_markov_factored_workspace_bytes(n).                                                                             */
+size_t vcy_markov_factored_workspace_bytes(int64_t n);
+int vcy_prepare_markov_factored(const int64_t *indptr, const int32_t *indices, const double *pval, const double *embedding, int edim,
+                                double *sval, double *sdiag, double *kw, double *tot, void *es, int64_t n, double sigma_D, double sigma_W,
+                                int compute_dtype, vcy_stream stream);
+int vcy_diffuse_step_factored(const double *x, double *y, double *accum, const int64_t *colptr, const int32_t *rowidx, const double *scsc,
+                              const double *tot, const double *kw, const void *es, int edim, double sigma_W, void *workspace, int64_t n,
+                              int compute_dtype, vcy_stream stream);
+
 /* ---------------------------------------------------------------- stage F: Diffusion.diffuse step
  * (diffusion.py:93-105): y = x . tr, optionally accum += y (path_integral).  tr dense row-major
  * (n, n) of `dtype`, or CSC (column pointers / row indices / values) for sparse matrices;

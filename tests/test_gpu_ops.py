@@ -598,3 +598,42 @@ def test_diffuse_dense_wide_loads(ops, oracle, n, tdtype):
     # the graph-replayed long loop takes the same kernels
     xl, _ = ops.diffuse(x0, aligned, 40, accumulate=False)
     np.testing.assert_allclose(xl.cpu().numpy(), oracle.diffuse(x0, tr.astype(np.float64), 40, "time_evolution").ravel(), rtol=1e-10)
+
+
+@pytest.mark.parametrize("edim", [1, 2, 3])
+@pytest.mark.parametrize("compute", ["float64", "float32"])
+def test_markov_factored_matches_dense_chain(ops, oracle, edim, compute):
+    """prepare_markov / Diffusion.diffuse without the (n, n) matrix: the factors of vcy_prepare_markov_factored stepped by
+    vcy_diffuse_step_factored (sparse product + Gauss transform on the fly) against the oracle's dense chain - both directions,
+    a P that stores diagonal entries (replaced by the row maximum, analysis.py:1856), short loops and the graph-replayed long one,
+    time evolution and path integral."""
+    from scipy import sparse
+    rng = np.random.default_rng(40 + edim)
+    n, k = 700, 23
+    emb = rng.normal(size=(n, edim)) * 3.0
+    ix = np.stack([rng.choice(n, k, replace=False) for _ in range(n)])
+    ix[::7, 0] = np.arange(n)[::7]                                    # some stored diagonal entries
+    tp = np.zeros((n, n))
+    np.put_along_axis(tp, ix, rng.random((n, k)) + 0.01, axis=1)
+    tp /= tp.sum(1, keepdims=True)
+    x0 = rng.random(n)
+    cdt = torch.float64 if compute == "float64" else torch.float32
+    rt = 1e-11 if compute == "float64" else 5e-5
+    for direction in ("forward", "backwards"):
+        ref = oracle.prepare_markov(tp, emb, 0.9, 1.6, direction)
+        P = sparse.csr_matrix(tp if direction == "forward" else tp.T)
+        P.sort_indices()
+        fac = ops.prepare_markov_factored(P.indptr, P.indices, P.data, emb, 0.9, 1.6, compute_dtype=cdt)
+        assert fac.shape == (n, n)
+        np.testing.assert_allclose(fac.dense().cpu().numpy(), ref, rtol=1e-11, atol=1e-16)
+        # the factors reassemble to the same matrix: tr = (0.2 K_W / kw + s) / tot
+        d = np.sqrt(((emb[:, None, :] - emb[None, :, :]) ** 2).sum(-1))
+        kw_full = np.exp(-d ** 2 / (2 * 1.6 ** 2)) / np.sqrt(2 * np.pi * 1.6 ** 2)
+        s = sparse.csc_matrix((fac.scsc.cpu().numpy(), fac.rowidx.cpu().numpy(), fac.colptr.cpu().numpy()), shape=(n, n)).toarray()
+        rebuilt = (0.2 * kw_full / fac.kw.cpu().numpy()[:, None] + s) / fac.tot.cpu().numpy()[:, None]
+        np.testing.assert_allclose(rebuilt, ref, rtol=1e-11, atol=1e-16)
+        for acc, mode in ((False, "time_evolution"), (True, "path_integral")):
+            for steps in (3, 41):
+                xf, xa = ops.diffuse(x0 / x0.sum(), fac, steps, accumulate=acc)
+                want = oracle.diffuse(x0, ref, steps, mode).ravel()
+                np.testing.assert_allclose((xa if acc else xf).cpu().numpy(), want, rtol=rt)

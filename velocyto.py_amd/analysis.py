@@ -148,7 +148,7 @@ class VelocytoLoom(PreprocessMixin):
         if name == "tr":
             if "_tr_dev" not in st:
                 raise AttributeError(name)
-            return sparse.csr_matrix(st["_tr_dev"].double().cpu().numpy())
+            return sparse.csr_matrix(st["_tr_dev"].dense(torch.float64).cpu().numpy())
         raise AttributeError(name)
 
     # ------------------------------------------------------------------ a1 normalisation
@@ -650,9 +650,9 @@ class VelocytoLoom(PreprocessMixin):
         if direction == "backwards":
             P = sparse.csr_matrix(P.T)
         P.sort_indices()
-        # the dense (n, n) chain is kept in the facade's storage type: every diffusion step streams it once (HBM-bound), so f32
-        # storage halves both its footprint (10 instead of 20 GB at 50 000 cells) and the step time; the iterates stay fp64
-        self._tr_dev = ops.prepare_markov(P.indptr, P.indices, P.data, embedding, sigma_D, sigma_W, dtype=self._dtype)
+        # the chain is kept in factored form (sparse part + Gaussian of the embedding distance evaluated on the fly, in the
+        # facade's storage type): no (n, n) matrix - 20 GB in fp64 at 50 000 cells - unless `tr` is asked for
+        self._tr_dev = ops.prepare_markov_factored(P.indptr, P.indices, P.data, embedding, sigma_D, sigma_W, compute_dtype=self._dtype)
 
     def run_markov(self, starting_p: np.ndarray = None, n_steps: int = 2500, mode: str = "time_evolution") -> None:
         """analysis.py:1865-1887."""

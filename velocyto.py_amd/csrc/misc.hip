@@ -326,6 +326,143 @@ __global__ __launch_bounds__(256) void k_prepare_markov(const int64_t *__restric
     (void)s_vals;
 }
 
+// ---------------------------------------------------------------- the same chain in factored form
+// tr[c,j] = (0.2 K_W(c,j) / kw[c] + s[c,j]) / tot[c]: a Gaussian of the embedding distance plus a sparse matrix s with the
+// pattern of P and a diagonal.  Nothing in it needs n^2 memory: a step x <- x . tr is
+//     y[j] = sum_c (x[c] / tot[c]) s[c,j]  +  sum_c u[c] exp2(-|es[c] - es[j]|^2),     u[c] = 0.2 g x[c] / (tot[c] kw[c]),
+// es = embedding * sqrt(log2(e) / (2 sigma_W^2)), g = 1 / sqrt(2 pi sigma_W^2): a sparse product (k_vecmat_csc) and a discrete
+// Gauss transform evaluated on the fly - n^2 exp2 per step (VALU-bound, 0.5 ms at 50 000 cells in f32) instead of n^2 matrix
+// elements from HBM (1.6 ms from f32, 3.0 ms from f64 storage), and no 10-20 GB matrix.
+// k_prepare_markov_factored: one workgroup per row c, same reductions as k_prepare_markov; sval in the CSR order of P
+// (0 where P stores the diagonal), sdiag = 0.8 max / sm, kw, tot.
+__global__ __launch_bounds__(256) void k_prepare_markov_factored(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                                  const double *__restrict__ pval, const double *__restrict__ emb, int edim,
+                                                                  double *__restrict__ sval, double *__restrict__ sdiag, double *__restrict__ kw_out,
+                                                                  double *__restrict__ tot_out, int n, double sigma_D, double sigma_W)
+{
+    __shared__ double red[8];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double ec[4];
+    for (int a = 0; a < edim; ++a) ec[a] = emb[(int64_t)c * edim + a];
+    auto dist_to = [&](int j) {
+        double d2 = 0.0;
+        for (int a = 0; a < edim; ++a) { const double df = emb[(int64_t)j * edim + a] - ec[a]; d2 += df * df; }
+        return sqrt(d2);
+    };
+    double kw = 0.0;
+    for (int j = tid; j < n; j += 256) kw += gauss_k(dist_to(j), sigma_W);
+    kw = block_sum(kw, red);
+    const int64_t p0 = indptr[c], p1 = indptr[c + 1];
+    double mx = 0.0, sm = 0.0;
+    for (int64_t p = p0 + tid; p < p1; p += 256) {
+        const int j = indices[p];
+        const double v = pval[p] * gauss_k(dist_to(j), sigma_D);
+        mx = fmax(mx, v);
+        if (j != c) sm += v;
+    }
+    mx = wave_max(mx);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    sm = block_sum(sm, red) + mx;      // diagonal := row maximum
+    double tot = 0.0;
+    for (int j = tid; j < n; j += 256) tot += 0.2 * gauss_k(dist_to(j), sigma_W) / kw;
+    for (int64_t p = p0 + tid; p < p1; p += 256) {
+        const int j = indices[p];
+        const double v = j != c ? 0.8 * (pval[p] * gauss_k(dist_to(j), sigma_D)) / sm : 0.0;
+        sval[p] = v;
+        tot += v;
+    }
+    tot = block_sum(tot, red) + 0.8 * mx / sm;
+    if (tid == 0) { sdiag[c] = 0.8 * mx / sm; kw_out[c] = kw; tot_out[c] = tot; }
+}
+
+template <typename CT>
+__global__ void k_markov_scale_coords(const double *__restrict__ emb, CT *__restrict__ es, int64_t total, double scale)
+{
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t < total) es[t] = (CT)(emb[t] * scale);
+}
+template <typename CT>
+__global__ void k_markov_scale_x(const double *__restrict__ x, const double *__restrict__ tot, const double *__restrict__ kw, double *__restrict__ v,
+                                 CT *__restrict__ u, int n, double coef)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const double vc = x[c] / tot[c];
+    v[c] = vc;
+    u[c] = (CT)(coef * vc / kw[c]);
+}
+
+__device__ __forceinline__ float exp2_neg(float d2) { return __builtin_amdgcn_exp2f(-d2); }
+__device__ __forceinline__ double exp2_neg(double d2) { return exp2(-d2); }
+
+// part[blockIdx.y][j] = sum over this block's source range of u[c] exp2(-|es[c] - es[j]|^2).  A thread owns JPT targets; the source
+// index is uniform over the block (scalar loads).  8 terms are folded in CT before they are added to the fp64 accumulator.
+template <typename CT, int EDIM, int JPT>
+__global__ __launch_bounds__(256) void k_gauss_transform(const CT *__restrict__ es, const CT *__restrict__ u, double *__restrict__ part, int n)
+{
+    const int j0 = blockIdx.x * 256 * JPT + threadIdx.x;
+    CT ej[JPT][EDIM];
+#pragma unroll
+    for (int t = 0; t < JPT; ++t) {
+        const int j = min(j0 + t * 256, n - 1);
+#pragma unroll
+        for (int a = 0; a < EDIM; ++a) ej[t][a] = es[(int64_t)j * EDIM + a];
+    }
+    const int per = (n + gridDim.y - 1) / gridDim.y;
+    const int c0 = blockIdx.y * per, c1 = min(n, c0 + per);
+    double acc[JPT];
+#pragma unroll
+    for (int t = 0; t < JPT; ++t) acc[t] = 0.0;
+    auto term = [&](int c, CT (&fold)[JPT]) {
+        CT ec[EDIM];
+#pragma unroll
+        for (int a = 0; a < EDIM; ++a) ec[a] = es[(int64_t)c * EDIM + a];
+        const CT uc = u[c];
+#pragma unroll
+        for (int t = 0; t < JPT; ++t) {
+            CT d2 = CT(0);
+#pragma unroll
+            for (int a = 0; a < EDIM; ++a) { const CT df = ej[t][a] - ec[a]; d2 = fma(df, df, d2); }
+            fold[t] = fma(uc, exp2_neg(d2), fold[t]);
+        }
+    };
+    int c = c0;
+    for (; c + 8 <= c1; c += 8) {
+        CT fold[JPT];
+#pragma unroll
+        for (int t = 0; t < JPT; ++t) fold[t] = CT(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) term(c + q, fold);
+#pragma unroll
+        for (int t = 0; t < JPT; ++t) acc[t] += (double)fold[t];
+    }
+    {
+        CT fold[JPT];
+#pragma unroll
+        for (int t = 0; t < JPT; ++t) fold[t] = CT(0);
+        for (; c < c1; ++c) term(c, fold);
+#pragma unroll
+        for (int t = 0; t < JPT; ++t) acc[t] += (double)fold[t];
+    }
+#pragma unroll
+    for (int t = 0; t < JPT; ++t)
+        if (j0 + t * 256 < n) part[(int64_t)blockIdx.y * n + j0 + t * 256] = acc[t];
+}
+// y[j] += the folded partials (fixed order); path_integral: accum += y
+__global__ void k_gauss_reduce(const double *__restrict__ part, double *__restrict__ y, double *__restrict__ accum, int n, int nparts)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double s = 0.0;
+    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * n + j];
+    s += y[j];
+    y[j] = s;
+    if (accum) accum[j] += s;
+}
+
 static inline int grid_for(int64_t total) { const int64_t b = (total + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
 }  // namespace vcy
 
@@ -464,4 +601,66 @@ extern "C" int vcy_prepare_markov(const int64_t *indptr, const int32_t *indices,
     else return fail(VCY_ERR_INVALID, "%s: bad dtype", "prepare_markov");
     VCY_LAUNCH_CHECK();
     return VCY_OK;
+}
+
+// ---- factored chain (see k_prepare_markov_factored)
+static inline int gauss_parts(int64_t n) { const int64_t bx = (n + 511) / 512; int p = (int)((3072 + bx - 1) / bx); return p < 1 ? 1 : (p > 64 ? 64 : p); }
+
+extern "C" size_t vcy_markov_factored_workspace_bytes(int64_t n) { return (size_t)(64 + 2) * (size_t)(n > 0 ? n : 0) * sizeof(double); }
+
+extern "C" int vcy_prepare_markov_factored(const int64_t *indptr, const int32_t *indices, const double *pval, const double *embedding, int edim,
+                                           double *sval, double *sdiag, double *kw, double *tot, void *es, int64_t n, double sigma_D,
+                                           double sigma_W, int compute_dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(indptr && indices && pval && embedding && sval && sdiag && kw && tot && es, "prepare_markov_factored: null pointer");
+    VCY_REQUIRE(n > 0 && n < (1ll << 31) && edim > 0 && edim <= 4 && sigma_D > 0 && sigma_W > 0, "prepare_markov_factored: bad arguments");
+    VCY_REQUIRE(compute_dtype == VCY_F32 || compute_dtype == VCY_F64, "prepare_markov_factored: bad dtype");
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(k_prepare_markov_factored, dim3((unsigned)n), dim3(256), 0, st, indptr, indices, pval, embedding, edim, sval, sdiag, kw, tot,
+                       (int)n, sigma_D, sigma_W);
+    VCY_LAUNCH_CHECK();
+    const double scale = sqrt(1.4426950408889634 / (2.0 * sigma_W * sigma_W));          // exp(-d^2 / (2 s^2)) = exp2(-(scale d)^2)
+    const int64_t total = n * edim;
+    if (compute_dtype == VCY_F32) hipLaunchKernelGGL(k_markov_scale_coords<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, embedding, (float *)es, total, scale);
+    else hipLaunchKernelGGL(k_markov_scale_coords<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, embedding, (double *)es, total, scale);
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}
+
+template <typename CT>
+static int diffuse_step_factored(const double *x, double *y, double *accum, const int64_t *colptr, const int32_t *rowidx, const double *scsc,
+                                 const double *tot, const double *kw, const CT *es, int edim, double sigma_W, void *workspace, int64_t n,
+                                 hipStream_t st)
+{
+    double *v = (double *)workspace;
+    CT *u = (CT *)(v + n);
+    double *part = v + 2 * n;
+    const double coef = 0.2 / sqrt(2.0 * 3.14159265358979323846 * sigma_W * sigma_W);
+    hipLaunchKernelGGL(k_markov_scale_x<CT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, tot, kw, v, u, (int)n, coef);
+    VCY_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_vecmat_csc<double>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, colptr, rowidx, scsc, (const double *)v, y, (double *)nullptr, (int)n);
+    VCY_LAUNCH_CHECK();
+    const int nparts = gauss_parts(n);
+    dim3 grid((unsigned)((n + 511) / 512), nparts);
+    switch (edim) {
+    case 1: hipLaunchKernelGGL((k_gauss_transform<CT, 1, 2>), grid, dim3(256), 0, st, es, (const CT *)u, part, (int)n); break;
+    case 2: hipLaunchKernelGGL((k_gauss_transform<CT, 2, 2>), grid, dim3(256), 0, st, es, (const CT *)u, part, (int)n); break;
+    case 3: hipLaunchKernelGGL((k_gauss_transform<CT, 3, 2>), grid, dim3(256), 0, st, es, (const CT *)u, part, (int)n); break;
+    default: hipLaunchKernelGGL((k_gauss_transform<CT, 4, 2>), grid, dim3(256), 0, st, es, (const CT *)u, part, (int)n); break;
+    }
+    VCY_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_gauss_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double *)part, y, accum, (int)n, nparts);
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}
+
+extern "C" int vcy_diffuse_step_factored(const double *x, double *y, double *accum, const int64_t *colptr, const int32_t *rowidx, const double *scsc,
+                                         const double *tot, const double *kw, const void *es, int edim, double sigma_W, void *workspace, int64_t n,
+                                         int compute_dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(x && y && colptr && rowidx && scsc && tot && kw && es && workspace && x != y, "diffuse_step_factored: bad arguments");
+    VCY_REQUIRE(n > 0 && n < (1ll << 31) && edim > 0 && edim <= 4 && sigma_W > 0, "diffuse_step_factored: bad arguments");
+    if (compute_dtype == VCY_F32) return diffuse_step_factored<float>(x, y, accum, colptr, rowidx, scsc, tot, kw, (const float *)es, edim, sigma_W, workspace, n, as_stream(stream));
+    if (compute_dtype == VCY_F64) return diffuse_step_factored<double>(x, y, accum, colptr, rowidx, scsc, tot, kw, (const double *)es, edim, sigma_W, workspace, n, as_stream(stream));
+    return fail(VCY_ERR_INVALID, "%s: bad dtype", "diffuse_step_factored");
 }

@@ -57,7 +57,10 @@ class Diffusion:
         tr: (n, n) scipy sparse / numpy / torch right-stochastic matrix."""
         x = np.asarray(x, dtype=np.float64)
         x0 = x / x.sum()
-        if not sparse.issparse(tr):
+        if isinstance(tr, ops.MarkovFactors):
+            if mode == "trajectory":
+                tr = tr.dense()                                     # the random walk reads single rows of tr
+        elif not sparse.issparse(tr):
             tr = tr if isinstance(tr, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(tr, dtype=np.float64))
         if mode == "path_integral":
             _, acc = ops.diffuse(x0, tr, n_steps, accumulate=True)

@@ -794,9 +794,34 @@ def row_cosproj(A: CellMatrix, B: CellMatrix) -> torch.Tensor:
     return out
 
 
+def _run_steps(step, x: torch.Tensor, y: torch.Tensor, n_steps: int) -> torch.Tensor:
+    """n_steps of step(src, dst) ping-ponging between x and y; returns the buffer that holds the last iterate.  Long loops are
+    launch-bound (a few tiny kernels per step, thousands of steps): an x -> y -> x pair of steps is captured into a hipGraph once
+    and replayed (the kernels take raw pointers and never allocate or sync)."""
+    done = 0
+    if n_steps >= 32:
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step(x, y); step(y, x)                      # warm-up outside capture
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                step(x, y); step(y, x)
+        torch.cuda.current_stream().wait_stream(side)
+        done = 2
+        for _ in range((n_steps - done) // 2):
+            graph.replay()
+        done += 2 * ((n_steps - done) // 2)
+    for _ in range(n_steps - done):
+        step(x, y)
+        x, y = y, x
+    return x
+
+
 def diffuse(x0, tr, n_steps: int, accumulate: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """n_steps of x <- x . tr on device.  tr: dense torch (n,n) f32/f64 or a scipy sparse matrix.
-    Returns (x_final, sum of the iterates if accumulate)."""
+    """n_steps of x <- x . tr on device.  tr: dense torch (n,n) f32/f64, a scipy sparse matrix, or the MarkovFactors of
+    prepare_markov_factored.  Returns (x_final, sum of the iterates if accumulate)."""
     import scipy.sparse as sp
     dev = require_gpu()
     L = _lib.lib()
@@ -804,15 +829,25 @@ def diffuse(x0, tr, n_steps: int, accumulate: bool) -> Tuple[torch.Tensor, Optio
     n = x.numel()
     y = torch.empty_like(x)
     acc = torch.zeros_like(x) if accumulate else None
-    if sp.issparse(tr):
+    if isinstance(tr, MarkovFactors):
+        assert tr.n == n
+        ws = torch.empty(int(L.vcy_markov_factored_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+
+        def step(src, dst):
+            _lib.check(L.vcy_diffuse_step_factored(src.data_ptr(), dst.data_ptr(), _p(acc), tr.colptr.data_ptr(), tr.rowidx.data_ptr(), tr.scsc.data_ptr(),
+                                                   tr.tot.data_ptr(), tr.kw.data_ptr(), tr.es.data_ptr(), tr.edim, tr.sigma_W, ws.data_ptr(), n,
+                                                   _DT[tr.compute_dtype], _stream()), "diffuse_step_factored")
+        x = _run_steps(step, x, y, n_steps)
+    elif sp.issparse(tr):
         csc = sp.csc_matrix(tr)
         csc.sort_indices()
         colptr = torch.from_numpy(csc.indptr.astype(np.int64)).to(dev)
         rowidx = torch.from_numpy(csc.indices.astype(np.int32)).to(dev)
         val = torch.from_numpy(np.ascontiguousarray(csc.data, dtype=np.float64)).to(dev)
-        for _ in range(n_steps):
-            _lib.check(L.vcy_diffuse_step_csc(colptr.data_ptr(), rowidx.data_ptr(), val.data_ptr(), x.data_ptr(), y.data_ptr(), _p(acc), n, F64, _stream()), "diffuse_step_csc")
-            x, y = y, x
+
+        def step(src, dst):
+            _lib.check(L.vcy_diffuse_step_csc(colptr.data_ptr(), rowidx.data_ptr(), val.data_ptr(), src.data_ptr(), dst.data_ptr(), _p(acc), n, F64, _stream()), "diffuse_step_csc")
+        x = _run_steps(step, x, y, n_steps)
     else:
         T = tr.to(dev).contiguous()
         assert T.shape == (n, n) and T.dtype in _DT
@@ -821,26 +856,7 @@ def diffuse(x0, tr, n_steps: int, accumulate: bool) -> Tuple[torch.Tensor, Optio
         def step(src, dst):
             _lib.check(L.vcy_diffuse_step_dense(T.data_ptr(), src.data_ptr(), dst.data_ptr(), _p(acc), ws.data_ptr(), n, _DT[T.dtype], _stream()), "diffuse_step_dense")
 
-        done = 0
-        if n_steps >= 32:
-            # launch-bound loop (2 tiny kernels per step, thousands of steps): capture an x -> y -> x pair of
-            # steps into a hipGraph once and replay it (the kernels take raw pointers and never allocate or sync)
-            torch.cuda.synchronize()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step(x, y); step(y, x)                      # warm-up outside capture
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=side):
-                    step(x, y); step(y, x)
-            torch.cuda.current_stream().wait_stream(side)
-            done = 2
-            for _ in range((n_steps - done) // 2):
-                graph.replay()
-            done += 2 * ((n_steps - done) // 2)
-        for _ in range(n_steps - done):
-            step(x, y)
-            x, y = y, x
+        x = _run_steps(step, x, y, n_steps)
     return x, acc
 
 
@@ -853,6 +869,50 @@ def gamma_weights(S: CellMatrix, U: Optional[CellMatrix], mode: int, pa, pb, pc=
     _lib.check(_lib.lib().vcy_gamma_weights(S.t.data_ptr(), None if U is None else U.t.data_ptr(), W.t.data_ptr(), _p(pa), _p(pb), _p(pc), _p(pd),
                                             _p(sa), _p(sb), S.C, S.G, S.ld, int(mode), float(power), S.code, _stream()), "gamma_weights")
     return W
+
+
+class MarkovFactors:
+    """The Markov chain of prepare_markov (analysis.py:1853-1862) without its dense (n, n) matrix:
+    tr[c, j] = (0.2 K_W(c, j) / kw[c] + s[c, j]) / tot[c], s sparse (CSC, diagonal included), K_W the Gaussian of the embedding
+    distance - what vcy_diffuse_step_factored steps through.  `dense()` materialises tr (vcy_prepare_markov) when it is asked for."""
+
+    def __init__(self, csr, embedding, sigma_D, sigma_W, colptr, rowidx, scsc, tot, kw, es, compute_dtype):
+        self._csr, self.embedding, self.sigma_D, self.sigma_W = csr, embedding, float(sigma_D), float(sigma_W)
+        self.colptr, self.rowidx, self.scsc, self.tot, self.kw, self.es, self.compute_dtype = colptr, rowidx, scsc, tot, kw, es, compute_dtype
+        self.n, self.edim = int(embedding.shape[0]), int(embedding.shape[1])
+        self.shape = (self.n, self.n)
+
+    def dense(self, dtype=torch.float64) -> torch.Tensor:
+        ip, ix, pv = self._csr
+        return prepare_markov(ip, ix, pv, self.embedding, self.sigma_D, self.sigma_W, dtype=dtype)
+
+
+def prepare_markov_factored(indptr, indices, pval, embedding, sigma_D: float, sigma_W: float, compute_dtype=torch.float32) -> MarkovFactors:
+    """Factors of the Markov matrix from CSR transition probabilities (vcy_prepare_markov_factored); O(nnz + n) memory."""
+    dev = require_gpu()
+    ip = torch.as_tensor(np.ascontiguousarray(indptr, dtype=np.int64)).to(dev) if not isinstance(indptr, torch.Tensor) else indptr.to(dev, torch.int64).contiguous()
+    ix = _as_i32(indices, dev)
+    pv = (torch.as_tensor(np.ascontiguousarray(pval, dtype=np.float64)) if not isinstance(pval, torch.Tensor) else pval.double()).to(dev).contiguous()
+    emb = (torch.from_numpy(np.ascontiguousarray(embedding, dtype=np.float64)) if not isinstance(embedding, torch.Tensor) else embedding.double()).to(dev).contiguous()
+    n, edim = int(emb.shape[0]), int(emb.shape[1])
+    nnz = int(ix.numel())
+    sval = torch.empty(nnz, dtype=torch.float64, device=dev)
+    sdiag, kw, tot = (torch.empty(n, dtype=torch.float64, device=dev) for _ in range(3))
+    es = torch.empty((n, edim), dtype=compute_dtype, device=dev)
+    _lib.check(_lib.lib().vcy_prepare_markov_factored(ip.data_ptr(), ix.data_ptr(), pv.data_ptr(), emb.data_ptr(), edim, sval.data_ptr(), sdiag.data_ptr(),
+                                                      kw.data_ptr(), tot.data_ptr(), es.data_ptr(), n, float(sigma_D), float(sigma_W),
+                                                      _DT[compute_dtype], _stream()), "prepare_markov_factored")
+    # s in CSC form, diagonal included (index plumbing: one sort of the nnz + n coordinates by (column, row))
+    rows = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64), ip[1:] - ip[:-1])
+    cols = ix.to(torch.int64)
+    keep = rows != cols                                     # a diagonal entry stored by P is replaced by the row maximum
+    ar = torch.arange(n, device=dev, dtype=torch.int64)
+    rows, cols, vals = torch.cat([rows[keep], ar]), torch.cat([cols[keep], ar]), torch.cat([sval[keep], sdiag])
+    order = torch.argsort(cols * n + rows)
+    colptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    colptr[1:] = torch.cumsum(torch.bincount(cols, minlength=n), 0)
+    return MarkovFactors((ip, ix, pv), emb, sigma_D, sigma_W, colptr, rows[order].to(torch.int32).contiguous(), vals[order].contiguous(),
+                         tot, kw, es, compute_dtype)
 
 
 def prepare_markov(indptr, indices, pval, embedding, sigma_D: float, sigma_W: float, dtype=torch.float64) -> torch.Tensor:
