@@ -639,20 +639,33 @@ class VelocytoLoom(PreprocessMixin):
         transition probabilities and the embedding distances, as the reference slices its dense matrices)."""
         if direction not in ("forward", "backwards"):
             raise NotImplementedError(f"{direction} is not an implemented direction")
-        tp, ixs = self._tp.double().cpu().numpy(), self._tp_ixs.cpu().numpy().astype(np.int64)
-        C, n = tp.shape
-        P = sparse.csr_matrix((tp.ravel(), ixs.ravel(), np.arange(0, C * n + 1, n)), shape=(C, C))
         embedding = np.asarray(self.embedding, dtype=np.float64)
-        if cells_ixs is not None:
+        if cells_ixs is None:
+            # all cells: the CSR of transition_prob is the compact (C, n) layout itself, its transpose one device sort
+            tp, ixs = self._tp.double().contiguous(), self._tp_ixs.to(torch.int64).contiguous()
+            C, n = tp.shape
+            if direction == "forward":
+                indptr, indices, data = torch.arange(0, C * n + 1, n, device=tp.device), ixs.ravel(), tp.ravel()
+            else:
+                rows, cols = ixs.ravel(), torch.arange(C, device=tp.device).repeat_interleave(n)
+                order = torch.argsort(rows * C + cols)
+                indptr = torch.zeros(C + 1, dtype=torch.int64, device=tp.device)
+                indptr[1:] = torch.cumsum(torch.bincount(rows, minlength=C), 0)
+                indices, data = cols[order], tp.ravel()[order]
+        else:
+            tp, ixs = self._tp.double().cpu().numpy(), self._tp_ixs.cpu().numpy().astype(np.int64)
+            C, n = tp.shape
+            P = sparse.csr_matrix((tp.ravel(), ixs.ravel(), np.arange(0, C * n + 1, n)), shape=(C, C))
             cells_ixs = np.asarray(cells_ixs)
             P = sparse.csr_matrix(P[cells_ixs, :][:, cells_ixs])
             embedding = embedding[cells_ixs, :]
-        if direction == "backwards":
-            P = sparse.csr_matrix(P.T)
-        P.sort_indices()
+            if direction == "backwards":
+                P = sparse.csr_matrix(P.T)
+            P.sort_indices()
+            indptr, indices, data = P.indptr, P.indices, P.data
         # the chain is kept in factored form (sparse part + Gaussian of the embedding distance evaluated on the fly, in the
         # facade's storage type): no (n, n) matrix - 20 GB in fp64 at 50 000 cells - unless `tr` is asked for
-        self._tr_dev = ops.prepare_markov_factored(P.indptr, P.indices, P.data, embedding, sigma_D, sigma_W, compute_dtype=self._dtype)
+        self._tr_dev = ops.prepare_markov_factored(indptr, indices, data, embedding, sigma_D, sigma_W, compute_dtype=self._dtype)
 
     def run_markov(self, starting_p: np.ndarray = None, n_steps: int = 2500, mode: str = "time_evolution") -> None:
         """analysis.py:1865-1887."""
