@@ -140,3 +140,36 @@ def test_fullsize_pipeline_properties_and_spot_checks(world, oracle):
         got = corr[c].cpu().numpy()
         okc = np.isfinite(ref)
         np.testing.assert_allclose(got[okc], ref[okc], atol=5e-5)
+
+
+def test_fullsize_markov_chain_factored_vs_dense(world):
+    """prepare_markov / run_markov at 50 000 cells: the factored chain (no (n, n) matrix) against the dense matrix it stands for
+    (10 GB in f32, streamed by k_vecmat_dense_vec), plus what must hold at any size: every iterate is a probability vector
+    (tr is row-stochastic), time evolution and path integral agree with each other, and the result does not depend on whether the
+    steps are replayed from a hipGraph."""
+    ops, dev = world["ops"], world["dev"]
+    emb = world["pcs"][:, :2].double().contiguous()
+    neigh = world["neigh"].to(torch.int64)
+    n, m = neigh.shape
+    gen = torch.Generator(device=dev).manual_seed(7)
+    tp = torch.rand((n, m), generator=gen, device=dev, dtype=torch.float64) + 0.05
+    tp /= tp.sum(1, keepdim=True)
+    indptr = torch.arange(0, n * m + 1, m, device=dev)
+    sd = float(emb.std()) * 0.05
+    fac = ops.prepare_markov_factored(indptr, neigh.ravel(), tp.ravel(), emb, sd, 2 * sd, compute_dtype=torch.float32)
+    x0 = torch.rand(n, generator=gen, device=dev, dtype=torch.float64)
+    x0 /= x0.sum()
+    x5, _ = ops.diffuse(x0, fac, 5, accumulate=False)
+    assert abs(float(x5.sum()) - 1.0) < 5e-6 and float(x5.min()) >= 0.0
+    x40, acc40 = ops.diffuse(x0, fac, 40, accumulate=True)                  # graph-replayed
+    x35, _ = ops.diffuse(x5, fac, 35, accumulate=False)                     # 5 + 35 eager/graph mix
+    assert torch.allclose(x40, x35, rtol=1e-12, atol=0)
+    assert abs(float(acc40.sum()) - 40.0) < 2e-4
+    dense = fac.dense(torch.float32)                                         # the (n, n) matrix the reference builds
+    assert dense.shape == (n, n)
+    rows = dense[:: n // 64].double().sum(1)
+    assert float((rows - 1).abs().max()) < 1e-5
+    d5, _ = ops.diffuse(x0, dense, 5, accumulate=False)
+    rel = ((x5 - d5).abs() / d5.clamp_min(1e-300)).max()
+    assert float(rel) < 5e-5, float(rel)
+    del dense
