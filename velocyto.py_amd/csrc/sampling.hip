@@ -37,6 +37,8 @@ extern "C" int vcy_choice_stream_host(const double *pool, int64_t pool_len, cons
     VCY_REQUIRE(positive >= size, "choice_stream: Fewer non-zero entries in p than size");
     std::vector<double> pw((size_t)n), cdf((size_t)n);
     std::vector<int64_t> stamp((size_t)n, -1);
+    constexpr int64_t LUT = 128;                                 // power of two: v * LUT and b / LUT are exact
+    std::vector<int32_t> lut((size_t)LUT);
     int64_t pos = 0, done = 0, used = 0, round_id = 0;
     for (int64_t c = 0; c < cells; ++c) {
         for (int64_t i = 0; i < n; ++i) pw[(size_t)i] = p[i];
@@ -53,18 +55,22 @@ extern "C" int vcy_choice_stream_host(const double *pool, int64_t pool_len, cons
             for (int64_t i = 0; i < n; ++i) { acc = acc + pw[(size_t)i]; cdf[(size_t)i] = acc; }
             const double total = cdf[(size_t)(n - 1)];
             for (int64_t i = 0; i < n; ++i) cdf[(size_t)i] = cdf[(size_t)i] / total;
+            // searchsorted(cdf, v, side="right") = first index with cdf > v.  A bucket table over [0, 1) gives a lower bound of that
+            // index (first index with cdf > b / LUT for the bucket b = floor(v * LUT) <= v * LUT); the few remaining steps are a scan.
+            {
+                int64_t i = 0;
+                for (int64_t b = 0; b < LUT; ++b) {
+                    const double edge = (double)b * (1.0 / LUT);
+                    while (cdf[(size_t)i] <= edge && i < n - 1) ++i;
+                    lut[(size_t)b] = (int32_t)i;
+                }
+            }
             ++round_id;
             int64_t added = 0;
             for (int64_t k = 0; k < need; ++k) {
                 const double v = x[k];
-                const double *base = cdf.data();                  // first index with cdf > v  (searchsorted side="right"),
-                for (int64_t len = n; len > 1;) {                 // branch-free: the comparisons are coin flips
-                    const int64_t half = len >> 1;
-                    base += base[half - 1] <= v ? half : 0;
-                    len -= half;
-                }
-                int64_t lo = (base - cdf.data()) + (base[0] <= v ? 1 : 0);
-                if (lo >= n) lo = n - 1;                          // cannot happen for v < 1 (cdf[-1] == 1); numpy would index out of range
+                int64_t lo = lut[(size_t)(int64_t)(v * (double)LUT)];
+                while (lo < n - 1 && cdf[(size_t)lo] <= v) ++lo;      // cdf[n-1] == 1 > v: numpy cannot run past the end either
                 if (stamp[(size_t)lo] != round_id) { stamp[(size_t)lo] = round_id; found[n_uniq + added++] = lo; }
             }
             n_uniq += added;
