@@ -15,11 +15,13 @@ which = os.environ.get("WHICH", "knn_imputation")
 calls = {"knn_imputation": lambda: vlm.knn_imputation(k=30, n_pca_dims=30),
          "shift": lambda: (vlm.calculate_shift(), vlm.extrapolate_cell_at_t()),
          "embedding_shift": lambda: vlm.calculate_embedding_shift(),
-         "prepare_markov": lambda: vlm.prepare_markov(2.0, 4.0)}
-if which in ("shift", "embedding_shift", "prepare_markov"):
+         "prepare_markov": lambda: vlm.prepare_markov(2.0, 4.0),
+         "etp": lambda: vlm.estimate_transition_prob(hidim="Sx_sz", embed="ts", n_neighbors=500, sampled_fraction=0.5)}
+if which in ("shift", "embedding_shift", "prepare_markov", "etp"):
     vlm.knn_imputation(k=30, n_pca_dims=30); vlm.fit_gammas(fit_offset=False, weighted=False); vlm.predict_U(); vlm.calculate_velocity()
-if which in ("embedding_shift", "prepare_markov"):
+if which in ("embedding_shift", "prepare_markov", "etp"):
     vlm.calculate_shift(); vlm.extrapolate_cell_at_t()
+if which in ("embedding_shift", "prepare_markov"):
     vlm.estimate_transition_prob(hidim="Sx_sz", embed="ts", n_neighbors=500, sampled_fraction=0.5, device_sampling=True)
 if which == "prepare_markov":
     vlm.calculate_embedding_shift()

@@ -40,7 +40,7 @@ from .preprocess import PreprocessMixin, colormap_fun  # noqa: F401  (colormap_f
 
 _MATRIX_ATTRS = frozenset(["S", "U", "A", "S_sz", "U_sz", "S_norm", "U_norm", "Sx", "Ux", "Sx_sz", "Ux_sz", "Sx_norm", "Ux_norm",
                            "Upred", "velocity", "delta_S", "delta_S_rndm", "Sx_sz_t", "Sx_t"])
-_LAZY_DENSE = frozenset(["corrcoef", "corrcoef_random", "transition_prob", "transition_prob_random", "tr"])
+_LAZY_DENSE = frozenset(["corrcoef", "corrcoef_random", "transition_prob", "transition_prob_random", "tr", "embedding_knn"])
 
 
 class VelocytoLoom(PreprocessMixin):
@@ -145,6 +145,16 @@ class VelocytoLoom(PreprocessMixin):
             if key not in st:
                 raise AttributeError(name)
             return ops.scatter_rows(st[key], st["_tp_ixs"], st[key].shape[0]).double().cpu().numpy()
+        if name == "embedding_knn":
+            # estimate_transition_prob's neighbour graph (analysis.py:1551, 1565-1568) as the reference exposes it; the kernels
+            # use the compact device list, so the 0/1 CSR is only assembled when somebody reads it
+            if "_neigh" not in st:
+                raise AttributeError(name)
+            ix = st["_neigh"].cpu().numpy().astype(np.int64)
+            if st.get("corr_calc") == "full":
+                ix = np.sort(ix, axis=1)                                          # sklearn's connectivity graph: canonical CSR
+            C, k1 = ix.shape
+            return sparse.csr_matrix((np.ones(C * k1), ix.ravel(), np.arange(0, C * k1 + 1, k1)), shape=(C, C))
         if name == "tr":
             if "_tr_dev" not in st:
                 raise AttributeError(name)
@@ -486,25 +496,24 @@ class VelocytoLoom(PreprocessMixin):
         knn_ix, _ = ops.knn_search(embedding, n_neighbors + 1, include_self=False)
         if knn_random:
             self.corr_calc = "knn_random"
-            neigh_ixs = knn_ix.cpu().numpy().astype(np.int64)
-            p = np.linspace(sampling_probs[0], sampling_probs[1], neigh_ixs.shape[1])
+            n_cand = int(knn_ix.shape[1])
+            p = np.linspace(sampling_probs[0], sampling_probs[1], n_cand)
             p = p / p.sum()
             size = int(sampled_fraction * (n_neighbors + 1))
             if device_sampling:
                 # weighted sampling without replacement (Efraimidis-Spirakis keys u^(1/p), top `size`) with torch's device RNG
                 gen = torch.Generator(device=hi.t.device).manual_seed(int(random_seed))
-                keys = torch.log(torch.rand((C, neigh_ixs.shape[1]), generator=gen, device=hi.t.device, dtype=torch.float64)) / \
+                keys = torch.log(torch.rand((C, n_cand), generator=gen, device=hi.t.device, dtype=torch.float64)) / \
                     torch.as_tensor(p, device=hi.t.device)[None, :]
-                sampling_ixs = torch.topk(keys, size, dim=1).indices.cpu().numpy()
+                picks = torch.topk(keys, size, dim=1).indices
+                sampling_ixs = picks.cpu().numpy()
             else:
                 # identical numpy legacy-RNG stream to the reference (:1561-1564)
-                sampling_ixs = ops.choice_stream_host(neigh_ixs.shape[1], size, p, C)
+                sampling_ixs = ops.choice_stream_host(n_cand, size, p, C)
+                picks = torch.from_numpy(sampling_ixs).to(hi.t.device)
             self.sampling_ixs = sampling_ixs
-            neigh_ixs = neigh_ixs[np.arange(C)[:, None], sampling_ixs]
-            nonzero = neigh_ixs.shape[0] * neigh_ixs.shape[1]
-            self.embedding_knn = sparse.csr_matrix((np.ones(nonzero), neigh_ixs.ravel(), np.arange(0, nonzero + 1, neigh_ixs.shape[1])),
-                                                   shape=(C, C))
-            neigh = torch.from_numpy(neigh_ixs.astype(np.int32)).to(hi.t.device)
+            neigh = torch.gather(knn_ix, 1, picks).to(torch.int32).contiguous()       # neigh_ixs[arange(C)[:, None], sampling_ixs]  (:1565)
+            self.__dict__.pop("embedding_knn", None)
             self._neigh = neigh
             sched = ops.hilbert_order(embedding) if embedding.shape[1] >= 2 else None      # scheduling only: same numbers in any order
             self.__dict__["_embed_order"] = sched
@@ -519,10 +528,7 @@ class VelocytoLoom(PreprocessMixin):
                 self.__dict__.pop("_corr_random", None)
         else:
             self.corr_calc = "full"
-            k1 = n_neighbors + 1
-            ix = knn_ix.cpu().numpy().astype(np.int64)
-            order = np.argsort(ix, axis=1)                                          # sklearn's connectivity graph is what it is; keep CSR canonical
-            self.embedding_knn = sparse.csr_matrix((np.ones(C * k1), np.take_along_axis(ix, order, 1).ravel(), np.arange(0, C * k1 + 1, k1)), shape=(C, C))
+            self.__dict__.pop("embedding_knn", None)
             self._neigh = knn_ix
             self._corr = ops.coldeltacor_full(e, dmat, kern, psc)
             _fill_diagonal_zero(self._corr)                                          # :1666 (off-diagonal NaNs are kept)
@@ -688,7 +694,10 @@ class VelocytoLoom(PreprocessMixin):
         for name in self._dev:
             if name not in exclude:
                 out[name] = np.ascontiguousarray(getattr(self, name))
-        for name, val in self.__dict__.items():
+        items = dict(self.__dict__)
+        if "_neigh" in items and "embedding_knn" not in exclude:
+            items["embedding_knn"] = self.embedding_knn               # assembled on demand; a plain attribute in the reference
+        for name, val in items.items():
             if name.startswith("_") or name in exclude or isinstance(val, torch.Tensor):
                 continue                                              # device-side caches are rebuilt on demand
             if isinstance(val, np.ndarray) and val.dtype.kind in "fiub":
