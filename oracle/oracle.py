@@ -23,7 +23,11 @@ Third-party arithmetic the reference delegates to (all unpinned in its setup.py:
     -> called exactly as the reference calls them (SciPy 1.15.3 is in the image on both
     boxes) AND restated as exact closed-form box-constrained least squares
     (``*_exact``), which is what the GPU path implements;
-  * ``numpy.percentile`` (linear interpolation), ``numpy.random`` legacy stream -> used as is.
+  * ``numpy.percentile`` (linear interpolation), ``numpy.random`` legacy stream -> used as is;
+  * scikit-learn ``SVR`` (libsvm 3.x epsilon-SVR, RBF kernel; analysis.py:280-282, 324-326, 844-851) -> called as the reference
+    calls it (scikit-learn 1.7.2 is in the image on both boxes) AND restated as libsvm's published iteration (SMO with
+    second-order working-set selection, Fan, Chen & Lin 2005) in ``svr_rbf_fit``, which is what the GPU path implements;
+    ``tests/test_oracle_golden.py`` pins the restatement on scikit-learn.
 """
 from __future__ import annotations
 
@@ -834,3 +838,89 @@ def pca(X, n_components=None):
     k = min(A.shape) if n_components is None else n_components
     var = s**2 / (A.shape[0] - 1)
     return (Uu * s)[:, :k], Vt[:k], (var / var.sum())[:k]
+
+
+# --------------------------------------------------------------------------- libsvm's epsilon-SVR (third party, restated)
+def svr_rbf_fit(x, t, C=1.0, epsilon=0.1, gamma=1.0, tol=1e-3, max_iter=10_000_000):
+    """What ``sklearn.svm.SVR(kernel="rbf", C, epsilon, gamma, tol).fit(x[:, None], t)`` hands to libsvm, restated from the
+    published algorithm (Chang & Lin, "LIBSVM", sect. 4; Fan, Chen & Lin, JMLR 2005): the dual over b = [alpha; alpha*],
+    y = [+1; -1], p = [eps - t; eps + t], SMO with working-set selection "WSS 2" (i = argmax over I_up of -y G, j = argmin over
+    I_low of -(b_ij)^2 / a_ij), the two-variable update with libsvm's clipping order, stop at m(b) - M(b) < tol, rho from the free
+    variables.  Ties go to the lowest variable index.  fp64 kernel rows (libsvm rounds them to float and shrinks: same optimum
+    within tol).  Returns (coef = alpha - alpha*, intercept = -rho, SMO steps)."""
+    x, t = np.asarray(x, dtype=np.float64).ravel(), np.asarray(t, dtype=np.float64).ravel()
+    n = len(x)
+    y = np.concatenate([np.ones(n), -np.ones(n)])
+    beta = np.zeros(2 * n)
+    r = t.copy()                                          # residual t - f(x): -y G = r - eps (alpha part), r + eps (alpha* part)
+    tau = 1e-12
+    it = 0
+    while True:
+        mG = np.concatenate([r - epsilon, r + epsilon])
+        up = ((y > 0) & (beta < C)) | ((y < 0) & (beta > 0))
+        low = ((y > 0) & (beta > 0)) | ((y < 0) & (beta < C))
+        vi = np.where(up, mG, -np.inf)
+        i = int(np.argmax(vi))                            # first maximum = lowest index
+        Gmax = vi[i]
+        Gmin = np.min(np.where(low, mG, np.inf)) if low.any() else np.inf
+        if not up.any() or not (Gmax - Gmin >= tol) or it >= max_iter:
+            break
+        Ki = np.exp(-gamma * (x - x[i % n]) ** 2)
+        a = 2.0 - 2.0 * np.concatenate([Ki, Ki])
+        a = np.where(a > 0, a, tau)
+        b = Gmax - mG
+        cand = low & (b > 0)
+        if not cand.any():
+            break
+        obj = np.where(cand, b * b * (-1.0 / a), np.inf)
+        j = int(np.argmin(obj))
+        pi_, pj = i % n, j % n
+        Gi = epsilon - r[pi_] if i < n else r[pi_] + epsilon
+        Gj = epsilon - r[pj] if j < n else r[pj] + epsilon
+        Kij = np.exp(-gamma * (x[pi_] - x[pj]) ** 2)
+        quad = 2.0 - 2.0 * Kij
+        if not quad > 0:
+            quad = tau
+        ai, aj = beta[i], beta[j]
+        if (i < n) != (j < n):
+            delta, diff = (-Gi - Gj) / quad, ai - aj
+            ai, aj = ai + delta, aj + delta
+            if diff > 0:
+                if aj < 0: aj, ai = 0.0, diff
+            else:
+                if ai < 0: ai, aj = 0.0, -diff
+            if diff > 0:
+                if ai > C: ai, aj = C, C - diff
+            else:
+                if aj > C: aj, ai = C, C + diff
+        else:
+            delta, sm = (Gi - Gj) / quad, ai + aj
+            ai, aj = ai - delta, aj + delta
+            if sm > C:
+                if ai > C: ai, aj = C, sm - C
+            else:
+                if aj < 0: aj, ai = 0.0, sm
+            if sm > C:
+                if aj > C: aj, ai = C, sm - C
+            else:
+                if ai < 0: ai, aj = 0.0, sm
+        dci = (1.0 if i < n else -1.0) * (ai - beta[i])
+        dcj = (1.0 if j < n else -1.0) * (aj - beta[j])
+        beta[i], beta[j] = ai, aj
+        r -= dci * Ki + dcj * np.exp(-gamma * (x - x[pj]) ** 2)
+        it += 1
+    yG = np.concatenate([epsilon - r, -(r + epsilon)])
+    free = (beta > 0) & (beta < C)
+    if free.any():
+        rho = yG[free].sum() / free.sum()
+    else:
+        ub = np.min(np.where(((y > 0) & (beta <= 0)) | ((y < 0) & (beta >= C)), yG, np.inf))
+        lb = np.max(np.where(((y > 0) & (beta >= C)) | ((y < 0) & (beta <= 0)), yG, -np.inf))
+        rho = 0.5 * (ub + lb)
+    return beta[:n] - beta[n:], -rho, it
+
+
+def svr_rbf_predict(x, coef, intercept, xq, gamma):
+    """SVR.predict: sum_k coef_k exp(-gamma (xq - x_k)^2) + intercept."""
+    x, xq = np.asarray(x, dtype=np.float64).ravel(), np.asarray(xq, dtype=np.float64).ravel()
+    return (coef[None, :] * np.exp(-gamma * (xq[:, None] - x[None, :]) ** 2)).sum(1) + intercept

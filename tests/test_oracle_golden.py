@@ -396,3 +396,29 @@ def test_pre_normalize_median(oracle, pre):
     S1, U1 = oracle.normalize_median_imputed(Sx_sz * np.linspace(0.5, 2, Sx_sz.shape[1]), Ux_sz * np.linspace(2, 0.5, Sx_sz.shape[1]), small)
     np.testing.assert_allclose(S1.sum(0), np.median((Sx_sz * np.linspace(0.5, 2, Sx_sz.shape[1])).sum(0)), rtol=1e-9)
     np.testing.assert_allclose(U1[:, small], (Ux_sz * np.linspace(2, 0.5, Sx_sz.shape[1]))[:, small], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("kind,n,kw", [("cv", 300, dict(C=1.0, gamma=0.5)), ("cv", 900, dict(C=1.0, gamma=150. / 900)),
+                                       ("totals", 400, dict(C=100.0, gamma=1e-6)), ("totals", 600, dict(C=3.0, gamma=1e-7, epsilon=25.0))])
+def test_svr_restatement_pinned_on_scikit_learn(oracle, kind, n, kw):
+    """The reference fits sklearn.svm.SVR (libsvm) in score_cv_vs_mean (analysis.py:280-282, 324-326) and adjust_totS_totU
+    (analysis.py:844-851); oracle.svr_rbf_fit restates libsvm's iteration.  Pin: with the stopping tolerance tightened on both
+    sides the two solvers must meet at the optimum; at the default tolerance they sit within it of each other."""
+    from sklearn.svm import SVR
+    rng = np.random.default_rng(n)
+    if kind == "cv":
+        x = np.log2(rng.gamma(0.5, 0.5, n) + 1e-3)
+        t = -0.5 * x + 0.3 * rng.normal(size=n) + 0.5 * np.exp(-x * x)
+    else:
+        x = rng.gamma(5, 2000, n)
+        t = 0.3 * x * (1 + 0.2 * np.sin(x / 5000)) + rng.normal(0, 300, n)
+    xq = np.concatenate([x[:40], np.linspace(x.min() - 1, x.max() + 1, 33)])
+    scale = max(1.0, np.abs(t).max())
+    ref = SVR(tol=1e-7, **kw).fit(x[:, None], t)
+    coef, b, it = oracle.svr_rbf_fit(x, t, tol=1e-7, **kw)
+    np.testing.assert_allclose(oracle.svr_rbf_predict(x, coef, b, xq, kw["gamma"]), ref.predict(xq[:, None]), atol=2e-6 * scale, rtol=0)
+    assert abs(b - ref.intercept_[0]) < 2e-6 * scale and np.abs(coef).max() <= kw["C"] * (1 + 1e-12) and abs(coef.sum()) < 1e-9 * n * kw["C"]
+    ref = SVR(**kw).fit(x[:, None], t)
+    coef, b, it = oracle.svr_rbf_fit(x, t, **kw)
+    assert np.abs(oracle.svr_rbf_predict(x, coef, b, xq, kw["gamma"]) - ref.predict(xq[:, None])).max() < 8e-3 * max(1.0, kw["C"] / 20)
+    assert abs(int((coef != 0).sum()) - len(ref.support_)) <= max(2, n // 200) and 0 < it < 20 * n
