@@ -36,9 +36,9 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK = 8.0e12   # B/s, MI355X spec (MI355X_MICROARCH.md)
-# profiles/r01j_bench_50kx30k_pmc.csv, k_cdc_partial_grouped<float,SQRT,PARTIAL,8> (velocity chain folded in) at the default
+# profiles/r01k_bench_50kx30k_pmc.csv, k_cdc_partial_grouped<float,SQRT,PARTIAL,8> (velocity chain folded in) at the default
 # workload on 1 GPU: 2 * FETCH_SIZE (37 961 180 KiB; gfx950 half-count correction) + WRITE_SIZE (50 023 KiB), in bytes per launch
-PMC_TRAFFIC_DEFAULT = 2 * 37961179.625 * 1024 + 50022.96875 * 1024
+PMC_TRAFFIC_DEFAULT = 2 * 38573338.3125 * 1024 + 50023.84375 * 1024
 
 
 def parse():
@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass; the default workload "
-                         "uses the figure recorded in profiles/r01j_bench_50kx30k_pmc.csv, other workloads report null")
+                         "uses the figure recorded in profiles/r01k_bench_50kx30k_pmc.csv, other workloads report null")
     ap.add_argument("--slab", type=int, default=0, help="gene slab of the pooling kernel (0 = library default)")
     ap.add_argument("--no-fuse", dest="fuse", action="store_false",
                     help="materialise dmat with k_velocity_chain instead of folding the velocity chain into stage D")
@@ -409,7 +409,7 @@ def main():
                          "note": "achieved = ALGORITHMIC bytes (no reuse credited: (nrndm+2)*G*4 + nrndm*8 per cell) / HIP-event "
                                  "launch time. The grouped kernel reads a neighbour row once per 8-cell group (3.5x reuse out of "
                                  "LDS) and adjacent groups share rows in the per-XCD L2, so frac > 1 means it beats the no-reuse HBM "
-                                 "roofline; `traffic` is the PMC-measured L2-miss traffic of the same launch (profiles/r01j_*). The "
+                                 "roofline; `traffic` is the PMC-measured L2-miss traffic of the same launch (profiles/r01k_*). The "
                                  "kernel is VALU-bound: 9.0 VALU instr per pair-gene (v_sqrt_f32 takes two issue slots), VALU pipes "
                                  "95 % busy (4 x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)."},
         }
