@@ -394,7 +394,7 @@ def main():
                        "cells": C, "genes": G, "k": a.k, "nrndm": nr,
                        "inputs": f"spliced/unspliced count layers ({'uint8, no count above 255' if pipe.cS.t.dtype == torch.uint8 else 'uint16'}) + per-cell size factors "
                                  "(S_sz = factor*counts), pcs, sampled neighbours",
-                       "parallelism": "single GPU" if world == 1 else f"cells sharded over {world} GPUs in embedding (Morton) order; RCCL "
+                       "parallelism": "single GPU" if world == 1 else f"cells sharded over {world} GPUs in embedding ({a.curve} curve) order; RCCL "
                                       "all-reduce of fit moments, " + (f"halo exchange of Sx rows (all_to_all, {pipe.plan.n_recv} of {C} rows "
                                       "received by rank 0" + (f"; overlapped with stage D of the {int(pipe.sched[0].numel())} interior cells of {nloc})"
                                                               if pipe.sched is not None else ")") if pipe.plan is not None else "all-gather of Sx shards") +
