@@ -176,3 +176,26 @@ def test_choice_stream_host_argument_errors(lib):
     q = p.copy(); q[0], q[1] = -0.1, 0.3
     with pytest.raises(ValueError):
         ops.choice_stream_host(10, 3, q, 3)                        # negative probability
+
+
+def test_module_level_helpers_of_analysis():
+    """analysis.py:2392-2420 under the reference's names (host functions): the sparse-array loop of scale_to_match_median and
+    the numba-seeded row permutation, which without numba is the same sequence of numpy legacy draws."""
+    import scipy.sparse as sp
+    from velocyto_amd import analysis
+    rng = np.random.default_rng(3)
+    m = sp.random(30, 30, density=0.3, random_state=4, format="csr")
+    tot = rng.random(30) + 0.1
+    want = analysis.scale_to_match_median(m, tot)
+    np.testing.assert_array_equal(analysis._scale_to_match_median(m.data, m.indices, m.indptr, tot), want.data)
+    A = rng.normal(size=(7, 40))
+    B = A.copy()
+    analysis.numba_random_seed(11)
+    analysis.permute_rows_nsign(A)
+    np.random.seed(11)
+    plmi = np.array([+1, -1])
+    for i in range(B.shape[0]):
+        np.random.shuffle(B[i, :])
+        B[i, :] = B[i, :] * np.random.choice(plmi, size=B.shape[1])
+    np.testing.assert_array_equal(A, B)
+    np.testing.assert_allclose(np.sort(np.abs(A), 1), np.sort(np.abs(B), 1))

@@ -740,6 +740,31 @@ def scale_to_match_median(sparse_matrix: sparse.csr_matrix, genes_total: np.ndar
     return sparse.csc_matrix((new, m.indices, m.indptr), shape=m.shape, copy=True)
 
 
+def _scale_to_match_median(data: np.ndarray, indices: np.ndarray, indptr: np.ndarray, genes_total: np.ndarray) -> np.ndarray:
+    """analysis.py:2392-2404: the loop of scale_to_match_median on the raw arrays of a sparse matrix."""
+    new_data = np.zeros(data.shape)
+    for i in range(genes_total.shape[0]):
+        t = genes_total[indices[indptr[i]:indptr[i + 1]]]
+        new_data[indptr[i]:indptr[i + 1]] = np.minimum(1, np.median(t) / t) * data[indptr[i]:indptr[i + 1]]
+    return new_data
+
+
+def numba_random_seed(value: int) -> None:
+    """analysis.py:2407-2410: the reference seeds numba's private copy of numpy's legacy generator; there is no numba here, the
+    module-level helpers below draw from numpy's global generator, which this seeds."""
+    np.random.seed(value)
+
+
+def permute_rows_nsign(A: np.ndarray) -> None:
+    """analysis.py:2413-2420: in place, shuffle every row of A and flip the sign of its entries at random (host helper kept under
+    the reference's name; estimate_transition_prob itself permutes on the device, `_permute_rows_nsign`).  Same draws as the
+    reference's loop run without numba: np.random.shuffle, then np.random.choice([+1, -1]) per row."""
+    plmi = np.array([+1, -1])
+    for i in range(A.shape[0]):
+        np.random.shuffle(A[i, :])
+        A[i, :] = A[i, :] * np.random.choice(plmi, size=A.shape[1])
+
+
 def _fill_diagonal_zero(m: torch.Tensor) -> None:
     m.diagonal().zero_()
 
