@@ -199,3 +199,17 @@ def test_module_level_helpers_of_analysis():
         B[i, :] = B[i, :] * np.random.choice(plmi, size=B.shape[1])
     np.testing.assert_array_equal(A, B)
     np.testing.assert_allclose(np.sort(np.abs(A), 1), np.sort(np.abs(B), 1))
+
+
+def test_serialization_object_codec():
+    """serialization.py:9-41: non-array attributes travel as pickled + zlib-compressed uint8 datasets (same bytes as the reference
+    writes: protocol 2, level 9)."""
+    import pickle
+    import zlib
+    from velocyto_amd import serialization
+    obj = {"a": [1, 2, 3], "b": ("x", 2.5), "c": np.arange(5)}
+    u = serialization._obj2uint(obj)
+    assert u.dtype == np.uint8 and u.ndim == 1
+    assert u.tobytes() == zlib.compress(pickle.dumps(obj, protocol=2), 9)
+    back = serialization._uint2obj(u)
+    assert back["a"] == obj["a"] and back["b"] == obj["b"] and np.array_equal(back["c"], obj["c"])

@@ -686,9 +686,8 @@ class VelocytoLoom(PreprocessMixin):
         Every ndarray attribute (device matrices are downloaded) becomes a dataset under its name, everything else is
         pickled (protocol 2) + zlib-compressed into a uint8 dataset called "&name" - the reference's container format
         (written uncompressed here; `load_velocyto_hdf5` reads both)."""
-        import pickle
-        import zlib
         from .loom_io import hdf5_dump
+        from .serialization import _obj2uint
         exclude = set(kwargs.get("exclude", ()) or ())
         out = {}
         for name in self._dev:
@@ -703,7 +702,7 @@ class VelocytoLoom(PreprocessMixin):
             if isinstance(val, np.ndarray) and val.dtype.kind in "fiub":
                 out[name] = val
             else:
-                out["&" + name] = np.frombuffer(zlib.compress(pickle.dumps(val, protocol=2), 9), dtype=np.uint8)
+                out["&" + name] = _obj2uint(val, compression=9, protocol=2)
         hdf5_dump(filename, out)
 
 

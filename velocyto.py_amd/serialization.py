@@ -3,14 +3,29 @@ ctypes-bound libhdf5 of ``loom_io`` (no h5py in the image).  Device matrices are
 (genes, cells) float64 datasets, so files round-trip between the two implementations."""
 from __future__ import annotations
 
+import pickle
+import zlib
 from typing import Any
+
+import numpy as np
 
 __all__ = ["dump_hdf5", "load_hdf5"]
 
 
-def dump_hdf5(obj: Any, filename: str, data_compression: int = 7, chunks=(2048, 2048), noarray_compression: int = 9, exclude_attributes=None) -> None:
+def _obj2uint(obj: object, compression: int = 9, protocol: int = 2) -> np.ndarray:
+    """serialization.py:9-26: a python object as a uint8 array (pickle, then zlib)."""
+    return np.frombuffer(zlib.compress(pickle.dumps(obj, protocol=protocol), compression), dtype=np.uint8)
+
+
+def _uint2obj(uint: np.ndarray) -> object:
+    """serialization.py:29-41."""
+    return pickle.loads(zlib.decompress(np.asarray(uint, dtype=np.uint8).tobytes()))
+
+
+def dump_hdf5(obj: Any, filename: str, data_compression: int = 7, chunks=(2048, 2048), noarray_compression: int = 9, pickle_protocol: int = 2,
+              exclude_attributes=None) -> None:
     """serialization.py:44-97 for a VelocytoLoom of this package (compression arguments are accepted; libhdf5 is driven with
-    its defaults)."""
+    its defaults; `exclude_attributes` is an extension)."""
     obj.to_hdf5(filename, exclude=set(exclude_attributes or ()))
 
 
