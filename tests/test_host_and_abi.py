@@ -213,3 +213,30 @@ def test_serialization_object_codec():
     assert u.tobytes() == zlib.compress(pickle.dumps(obj, protocol=2), 9)
     back = serialization._uint2obj(u)
     assert back["a"] == obj["a"] and back["b"] == obj["b"] and np.array_equal(back["c"], obj["c"])
+
+
+def test_choice_stream_host_hypothesis(lib):
+    """Random shapes, probability vectors (with zeros, heavy tails, near-ties) and block sizes: always numpy's own draws."""
+    from hypothesis import given, settings, strategies as st
+    from velocyto_amd import ops
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(1, 70), st.integers(0, 9), st.integers(0, 2 ** 31 - 1), st.sampled_from(["flat", "ramp", "spiky", "zeros"]),
+           st.integers(1, 9), st.floats(0.01, 2.0))
+    def run(n, cells, seed, kind, block, factor):
+        rng = np.random.default_rng(seed)
+        p = {"flat": np.ones(n), "ramp": np.linspace(1.0, 0.05, n), "spiky": rng.random(n) ** 12 + 1e-12,
+             "zeros": np.where(rng.random(n) < 0.4, 0.0, rng.random(n) + 1e-3)}[kind]
+        if not (p > 0).any():
+            p[0] = 1.0
+        p = p / p.sum()
+        size = int(rng.integers(0, int((p > 0).sum()) + 1))
+        np.random.seed(seed % (2 ** 32))
+        want = np.stack([np.random.choice(n, size=(size,), replace=False, p=p) for _ in range(cells)], 0) if cells else np.empty((0, size), dtype=np.int64)
+        after = np.random.get_state()
+        np.random.seed(seed % (2 ** 32))
+        got = ops.choice_stream_host(n, size, p, cells, block=block, pool_factor=factor)
+        assert np.array_equal(got, want)
+        assert _rng_state_equal(np.random.get_state(), after)
+
+    run()
