@@ -35,42 +35,51 @@ extern "C" int vcy_choice_stream_host(const double *pool, int64_t pool_len, cons
         positive += p[i] > 0.0;
     }
     VCY_REQUIRE(positive >= size, "choice_stream: Fewer non-zero entries in p than size");
-    std::vector<double> pw((size_t)n), cdf((size_t)n);
+    std::vector<double> pw((size_t)n), cdf((size_t)n), cdf0((size_t)n);
     std::vector<int64_t> stamp((size_t)n, -1);
     constexpr int64_t LUT = 128;                                 // power of two: v * LUT and b / LUT are exact
-    std::vector<int32_t> lut((size_t)LUT);
+    std::vector<int32_t> lut((size_t)LUT), lut0((size_t)LUT);
+    // cdf = cumsum(w) / cumsum(w)[-1] exactly as numpy forms it (sequential fp64 accumulation, elementwise division), plus a
+    // bucket table over [0, 1): table[b] = first index with cdf > b / LUT, a lower bound of searchsorted(cdf, v, "right") for
+    // every v in bucket b = floor(v * LUT); the few remaining steps are a scan.
+    auto build = [&](const double *w, double *cd, int32_t *table) {
+        double acc = 0.0;
+        for (int64_t i = 0; i < n; ++i) { acc = acc + w[i]; cd[i] = acc; }
+        const double total = cd[n - 1];
+        for (int64_t i = 0; i < n; ++i) cd[i] = cd[i] / total;
+        int64_t i = 0;
+        for (int64_t b = 0; b < LUT; ++b) {
+            const double edge = (double)b * (1.0 / LUT);
+            while (cd[i] <= edge && i < n - 1) ++i;
+            table[b] = (int32_t)i;
+        }
+    };
+    build(p, cdf0.data(), lut0.data());                           // the first round of every cell sees the untouched p
     int64_t pos = 0, done = 0, used = 0, round_id = 0;
     for (int64_t c = 0; c < cells; ++c) {
-        for (int64_t i = 0; i < n; ++i) pw[(size_t)i] = p[i];
         int64_t *found = out + c * size;
-        int64_t n_uniq = 0;
+        int64_t n_uniq = 0, zeroed = 0;
         bool fits = true;
         while (n_uniq < size) {
             const int64_t need = size - n_uniq;
             if (pos + need > pool_len) { fits = false; break; }
             const double *x = pool + pos;
             pos += need;
-            for (int64_t u = 0; u < n_uniq; ++u) pw[(size_t)found[u]] = 0.0;
-            double acc = 0.0;
-            for (int64_t i = 0; i < n; ++i) { acc = acc + pw[(size_t)i]; cdf[(size_t)i] = acc; }
-            const double total = cdf[(size_t)(n - 1)];
-            for (int64_t i = 0; i < n; ++i) cdf[(size_t)i] = cdf[(size_t)i] / total;
-            // searchsorted(cdf, v, side="right") = first index with cdf > v.  A bucket table over [0, 1) gives a lower bound of that
-            // index (first index with cdf > b / LUT for the bucket b = floor(v * LUT) <= v * LUT); the few remaining steps are a scan.
-            {
-                int64_t i = 0;
-                for (int64_t b = 0; b < LUT; ++b) {
-                    const double edge = (double)b * (1.0 / LUT);
-                    while (cdf[(size_t)i] <= edge && i < n - 1) ++i;
-                    lut[(size_t)b] = (int32_t)i;
-                }
+            const double *cd = cdf0.data();
+            const int32_t *table = lut0.data();
+            if (n_uniq > 0) {
+                if (zeroed == 0) for (int64_t i = 0; i < n; ++i) pw[(size_t)i] = p[i];
+                for (; zeroed < n_uniq; ++zeroed) pw[(size_t)found[zeroed]] = 0.0;
+                build(pw.data(), cdf.data(), lut.data());
+                cd = cdf.data();
+                table = lut.data();
             }
             ++round_id;
             int64_t added = 0;
             for (int64_t k = 0; k < need; ++k) {
                 const double v = x[k];
-                int64_t lo = lut[(size_t)(int64_t)(v * (double)LUT)];
-                while (lo < n - 1 && cdf[(size_t)lo] <= v) ++lo;      // cdf[n-1] == 1 > v: numpy cannot run past the end either
+                int64_t lo = table[(int64_t)(v * (double)LUT)];
+                while (lo < n - 1 && cd[lo] <= v) ++lo;              // cdf[n-1] == 1 > v: numpy cannot run past the end either
                 if (stamp[(size_t)lo] != round_id) { stamp[(size_t)lo] = round_id; found[n_uniq + added++] = lo; }
             }
             n_uniq += added;
