@@ -12,8 +12,10 @@
 //     to float; fp64 rows make the gradient exact and the result agree with libsvm to the solver tolerance);
 //   * one SMO step = two sweeps over the points (apply the previous step + select i; select j), spread over up to 64
 //     co-resident workgroups (cooperative launch) that meet at two grid barriers per step; every workgroup reduces the
-//     per-workgroup winners redundantly, so no workgroup ever waits for a broadcast.  n <= 1024 points run on one
-//     workgroup with plain __syncthreads.
+//     per-workgroup winners redundantly, so no workgroup ever waits for a broadcast.  n <= 512 points run on one
+//     workgroup with plain __syncthreads;
+//   * up to 8 points per thread (131 072 points on 64 workgroups) live in registers for the whole solve (k_svr_smo<E>);
+//     larger problems keep the same state in global memory (L2).
 // A grid barrier that is not met within ~2 s sets the `failed` flag and every workgroup leaves (the host reports it): the
 // kernel cannot hang the device.
 #include "common.h"
