@@ -92,6 +92,24 @@ int vcy_coldeltacor_partial_fused(const void *Sx_sz, const void *Ux_sz, const fl
                                   int64_t u_row0, int64_t nrndm, int transform, int rules, double psc, double dt_shift,
                                   double used_dt, int dtype, vcy_stream stream);
 
+/* The real and the randomised-control correlations of estimate_transition_prob(calculate_randomized=True), the
+ * reference's default (analysis.py:1539-1542: delta_S_rndm = permute_rows_nsign(delta_S); :1578-1601: the second
+ * colDeltaCor*partial call with dmat_rndm on the SAME e and neighbour lists), in ONE pass: A = f(e_i - e_c) is evaluated
+ * once per pair and gene and correlated against both d[c] and d_rndm[c].  out_rndm has the shape of out; d_rndm the row
+ * range of d.  Each output equals what vcy_coldeltacor_partial returns for that d alone up to the rounding of the moment
+ * sums (the dual kernel walks the genes in shorter chunks; f32 1e-6, f64 1e-13 absolute on the correlations); problems
+ * too small for the grouped kernel (< 8 neighbours or < 32 cells) run the single kernel twice.                          */
+int vcy_coldeltacor_partial_dual(const void *e, const void *d, const void *d_rndm, const int32_t *ixs, void *out, void *out_rndm,
+                                 const int32_t *order, int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int64_t d_row0,
+                                 int64_t nrndm, int transform, int rules, double psc, int dtype, vcy_stream stream);
+
+/* vcy_coldeltacor_partial_fused + the randomised control in the same pass: d[c] from the velocity chain on the fly,
+ * d_rndm (rows u_row0..) the materialised transform of the permuted delta_S (analysis.py:1540-1541, 1575-1601).        */
+int vcy_coldeltacor_partial_fused_dual(const void *Sx_sz, const void *Ux_sz, const float *gamma, const float *q, const void *d_rndm,
+                                       const int32_t *ixs, void *out, void *out_rndm, const int32_t *order, int64_t C, int64_t G,
+                                       int64_t ld, int64_t cell0, int64_t C_out, int64_t u_row0, int64_t nrndm, int transform, int rules,
+                                       double psc, double dt_shift, double used_dt, int dtype, vcy_stream stream);
+
 /* speedboosted._colDeltaCor / _colDeltaCorSqrt / _colDeltaCorLog10 (speedboosted.pyx:13-257,
  * 542-572; wrappers estimation.py:11-33, 65-87, 119-141): all pairs.
  * rm is the dense (C_out, ld_rm) row block for cells cell0..cell0+C_out-1, columns 0..C-1;

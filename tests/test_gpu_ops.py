@@ -67,9 +67,8 @@ def test_coldeltacor_partial_golden(ops, golden, dtype, key, transform, psc_key)
     degenerate |= np.eye(ref.shape[0], dtype=bool)   # columns: exact NaN for sqrt/linear, NaN-or-rounding-noise for log10
     if transform in ("sqrt", "linear"):
         assert np.isnan(dense[3, 7]) and np.isnan(dense[5, 5])
-    # f32 cannot resolve psc = 1e-10 against O(1) values in log10(|t| + psc) when t == 0 exactly -> only compare f64 there
-    if dtype == "float32" and transform == "log10" and psc < 1e-6:
-        pytest.skip("log10(0 + 1e-10) = -10 dominates; f32 parity for this fixture is covered at psc=1")
+    # (f32, log10, psc = 1e-10: log10(0 + 1e-10) = -10 on every agreeing gene used to swamp the f32 raw moments; the
+    #  kernels now accumulate A - f(0), csrc/coldeltacor.hip "Shifted moments", and the case is held to the f32 tolerance)
     np.testing.assert_allclose(dense[~degenerate], ref[~degenerate], atol=CORR_ATOL[dtype])
     assert (dense[(ref == 0) & ~degenerate] == 0).all()        # cells that were never listed stay exactly zero
 
@@ -81,8 +80,6 @@ def test_coldeltacor_partial_golden(ops, golden, dtype, key, transform, psc_key)
 def test_coldeltacor_full_golden(ops, golden, dtype, key, transform, psc_key):
     g = golden("coldeltacor")
     psc = float(g[psc_key]) if psc_key else 0.0
-    if dtype == "float32" and transform == "log10" and psc < 1e-6:
-        pytest.skip("see test_coldeltacor_partial_golden")
     e, d = ops.CellMatrix.from_genes_major(g["e"], dtype), ops.CellMatrix.from_genes_major(g["d"], dtype)
     rm = ops.coldeltacor_full(e, d, ops.TRANSFORMS[transform], psc).cpu().numpy()
     ref = g[key]
@@ -637,3 +634,55 @@ def test_markov_factored_matches_dense_chain(ops, oracle, edim, compute):
                 xf, xa = ops.diffuse(x0 / x0.sum(), fac, steps, accumulate=acc)
                 want = oracle.diffuse(x0, ref, steps, mode).ravel()
                 np.testing.assert_allclose((xa if acc else xf).cpu().numpy(), want, rtol=rt)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("transform,psc", [("sqrt", 1e-10), ("log10", 1e-10), ("linear", 0.0)])
+@pytest.mark.parametrize("C,G,nr", [(200, 3100, 24), (40, 700, 9), (20, 500, 5)])
+def test_coldeltacor_partial_dual_equals_two_launches(ops, dtype, transform, psc, C, G, nr):
+    """vcy_coldeltacor_partial_dual (real + randomised control in one pass, analysis.py:1539-1542, 1578-1601) returns
+    what two single launches return - on the grouped path (first two shapes: full and ragged chunks) and on the
+    small-problem fallback (third)."""
+    rng = np.random.default_rng(C * 7 + G)
+    e = rng.gamma(2.0, 1.0, (G, C)) * (rng.random((G, C)) < 0.5)
+    d = rng.normal(size=(G, C))
+    d2 = np.sign(rng.normal(size=(G, C))) * rng.permuted(d, axis=1)          # the control: rows shuffled over cells, random sign
+    d2[:, 3] = 0.0                                                           # a zero-variance control column -> NaN there only
+    ixs = np.stack([rng.choice(C, nr, replace=False) for _ in range(C)])
+    E, D, D2 = (ops.CellMatrix.from_genes_major(a, dtype) for a in (e, d, d2))
+    tr = ops.TRANSFORMS[transform]
+    a1 = ops.coldeltacor_partial(E, D, ixs, tr, ops.RULES_PARTIAL, psc)
+    a2 = ops.coldeltacor_partial(E, D2, ixs, tr, ops.RULES_PARTIAL, psc)
+    b1, b2 = ops.coldeltacor_partial_dual(E, D, D2, ixs, tr, ops.RULES_PARTIAL, psc)
+    for x, y in ((a1, b1), (a2, b2)):
+        x, y = x.cpu().numpy(), y.cpu().numpy()
+        assert np.array_equal(np.isnan(x), np.isnan(y))
+        # same arithmetic per element; the dual kernel sums a pair's moments in chunks of 1024 instead of 1536 genes
+        np.testing.assert_allclose(x[~np.isnan(x)], y[~np.isnan(y)], rtol=0, atol=2e-6 if dtype == "float32" else 1e-13)
+    assert bool(torch.isnan(b2[3]).all()) and not bool(torch.isnan(b1[3]).any())
+    # a schedule over a subset leaves the other rows of both outputs untouched
+    o1 = torch.full_like(b1, 7.0)
+    o2 = torch.full_like(b2, 9.0)
+    sub = torch.arange(0, C, 2, dtype=torch.int32)
+    ops.coldeltacor_partial_dual(E, D, D2, ixs, tr, ops.RULES_PARTIAL, psc, order=sub, out=o1, out_rndm=o2)
+    assert bool((o1[1::2] == 7.0).all()) and bool((o2[1::2] == 9.0).all())
+    m = ~torch.isnan(b1[0::2])          # (half the cells may fall below the grouped kernel's minimum: another summation order)
+    assert torch.allclose(o1[0::2][m], b1[0::2][m], atol=CORR_ATOL[dtype], rtol=0)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_coldeltacor_partial_fused_dual(ops, dtype):
+    """Velocity chain folded into the staging + randomised control, one launch == the three-kernel route."""
+    rng = np.random.default_rng(77)
+    C, G, nr = 96, 2000, 16
+    S = rng.gamma(2.0, 1.0, (G, C)) * (rng.random((G, C)) < 0.6)
+    U = rng.gamma(1.0, 1.0, (G, C)) * (rng.random((G, C)) < 0.6)
+    d2 = rng.normal(size=(G, C))
+    gam = torch.as_tensor(rng.gamma(2.0, 0.3, G), dtype=torch.float32)
+    q = torch.as_tensor(rng.gamma(1.0, 0.05, G), dtype=torch.float32)
+    ixs = np.stack([rng.choice(C, nr, replace=False) for _ in range(C)])
+    Sx, Ux, D2 = (ops.CellMatrix.from_genes_major(a, dtype) for a in (S, U, d2))
+    dmat = ops.velocity_chain(Sx, Ux, gam, q, want=("dmat",), transform=ops.SQRT, psc=1e-10)["dmat"]
+    r1, r2 = ops.coldeltacor_partial_dual(Sx, dmat, D2, ixs, ops.SQRT, ops.RULES_PARTIAL, 1e-10)
+    f1, f2 = ops.coldeltacor_partial_fused_dual(Sx, Ux, gam, q, D2, ixs, ops.SQRT, ops.RULES_PARTIAL, 1e-10)
+    assert torch.equal(r1, f1) and torch.equal(r2, f2)           # same kernel, d[c] staged from dmat or evaluated on the fly

@@ -32,6 +32,10 @@ SIGNATURES = {
                                         c_int, c_int, c_dbl, c_int, c_vp]),
     "vcy_coldeltacor_partial_fused": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                                               c_int, c_int, c_dbl, c_dbl, c_dbl, c_int, c_vp]),
+    "vcy_coldeltacor_partial_dual": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
+                                             c_int, c_int, c_dbl, c_int, c_vp]),
+    "vcy_coldeltacor_partial_fused_dual": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64,
+                                                   c_i64, c_i64, c_int, c_int, c_dbl, c_dbl, c_dbl, c_int, c_vp]),
     "vcy_coldeltacor_full": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_dbl,
                                      c_int, c_int, c_vp]),
     "vcy_scatter_rows": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]),

@@ -63,6 +63,19 @@ template <> __device__ __forceinline__ float xform<float, VCY_SQRT, VCY_RULES_PA
     return copysignf(fast_sqrt<float>(fmaf(psc, c, fabsf(t))), t);
 }
 
+// Shifted moments.  Pearson's r does not change when a constant is subtracted from every A[g], so the log10 variants
+// accumulate A[g] - K with K = f(0), the value of the transform where the two cells agree (log10(psc) = -10 for the
+// default psc of 1e-10).  On count data most genes of a pair agree, so without the shift sum A^2 and (sum A)^2 / n are
+// two numbers near 100 n whose difference - the variance - sits in the last digits of an f32 accumulator; with it the
+// agreeing genes contribute exact zeros and the single-pass raw moments keep their accuracy in f32.  sqrt and linear
+// have f(0) = 0 (or -sqrt(psc), 1e-5) and need no shift.
+template <typename T, int TR, int RULES> __device__ __forceinline__ T xform_shift(T psc)
+{
+    if (TR != VCY_LOG10) return T(0);
+    const T k = xform<T, TR, RULES>(T(0), psc);
+    return (k - k == T(0)) ? k : T(0);             // psc = 0 gives -inf: every agreeing gene is NaN in the reference as well
+}
+
 template <typename T> __device__ __forceinline__ T pearson_from_moments(double sA, double sAA, double sAb, double sb, double sbb, double n)
 {
     const double cov = sAb - sA * sb / n;
@@ -125,6 +138,7 @@ __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, c
 
     for (int n = tid; n < 3 * nrndm; n += blockDim.x) acc[n] = T(0);
     double sb = 0.0, sbb = 0.0;
+    const T K = xform_shift<T, TR, RULES>(psc);
 
     for (int g0 = 0; g0 < G; g0 += gchunk) {
         const int gl = min(gchunk, G - g0);
@@ -177,7 +191,8 @@ __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, c
                     const T *bp = reinterpret_cast<const T *>(&dcv);
 #pragma unroll
                     for (int k = 0; k < N; ++k) {
-                        const T a = xform<T, TR, RULES>(xp[k] - ep[k], psc);
+                        T a = xform<T, TR, RULES>(xp[k] - ep[k], psc);
+                        if (TR == VCY_LOG10) a -= K;
                         sA[k] += a;
                         sAA[k] = fma(a, a, sAA[k]);
                         sAb[k] = fma(a, bp[k], sAb[k]);
@@ -193,7 +208,8 @@ __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, c
                 const T *bp = reinterpret_cast<const T *>(&dcv);
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
-                    const T a = xform<T, TR, RULES>(xp[k] - ep[k], psc);
+                    T a = xform<T, TR, RULES>(xp[k] - ep[k], psc);
+                    if (TR == VCY_LOG10) a -= K;
                     sA[k] += a;
                     sAA[k] = fma(a, a, sAA[k]);
                     sAb[k] = fma(a, bp[k], sAb[k]);
@@ -202,7 +218,8 @@ __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, c
             {
                 const int g = nvec * N + lane;
                 if (g < gl) {
-                    const T a = xform<T, TR, RULES>(row[g] - ec[g], psc);
+                    T a = xform<T, TR, RULES>(row[g] - ec[g], psc);
+                    if (TR == VCY_LOG10) a -= K;
                     sA[0] += a;
                     sAA[0] = fma(a, a, sAA[0]);
                     sAb[0] = fma(a, dc[g], sAb[0]);
@@ -239,30 +256,50 @@ __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, c
 //   3. wave w takes rows r = w, w+nwaves, ...: loads the row chunk ONCE into registers, then for each
 //      pair of the segment accumulates the three raw moments against member m's LDS copy, reduces
 //      over the wave and adds into acc[pair] (owned by that wave: deterministic, no atomics).
-constexpr int GRP_MAX_NV = 6;
+// Dual control (DUAL): estimate_transition_prob's default computes every correlation twice, against d and against the
+// randomised control d2 = f(permute_rows_nsign(delta_S)) (analysis.py:1539-1542, 1578-1601).  Both passes share e, the
+// neighbour lists and therefore every A = f(e_i - e_c); the dual kernel stages d2[c] beside d[c] and keeps a fourth
+// running moment sum A*b2 per pair: one more FMA and one more LDS read per element instead of a second launch.
+// Shape of a workgroup: GC cells, chunks of NV 16-byte vectors per lane (NV * 64 * 4 f32 genes).  The dual variant stages
+// three arrays per member in the same 160 KiB, so its chunk is 1024 genes instead of 1536 (30 instead of 20 chunks at 30k
+// genes); measured at 50k x 30k, nrndm 250: 8 cells x 1024 genes 110.0 ms, 6 cells x 1536 genes 118.5 ms, one single-control
+// launch 95.1 ms, i.e. the second correlation costs 16 % instead of 100 % (tools/bench_dual.py).  The chunking sets the
+// order in which a pair's moments are summed: dual results equal those of two single launches to rounding, not bit for bit.
+constexpr int GRP_NV = 6, GRP_NV_DUAL = 4;
+constexpr int GRP_GC = 8;
 
-template <typename T, int TR, int RULES, int GC>
-__global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restrict__ e, const T *__restrict__ d,
-                                                               const int32_t *__restrict__ ixs, T *__restrict__ out,
+// dynamic LDS of one workgroup: staged rows, sort keys, per-pair accumulators, segment heads, scalars (also used by the host)
+template <typename T> __host__ __device__ inline size_t grouped_lds_bytes(int gc, int nv, bool dual, int64_t maxpairs, int npad)
+{
+    const int as = dual ? 4 : 3;
+    return (size_t)(dual ? 3 : 2) * gc * nv * 64 * 16 + (size_t)npad * 8 + sizeof(T) * (size_t)as * ((maxpairs + 1) & ~(int64_t)1) +
+           sizeof(int) * (size_t)((maxpairs + 3) & ~(int64_t)1) + (size_t)(64 + 4 * gc) * sizeof(double) + (size_t)(gc + 18) * sizeof(int) + 16;
+}
+
+template <typename T, int TR, int RULES, int GC, int NV, bool DUAL>
+__global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restrict__ e, const T *__restrict__ d, const T *__restrict__ d2,
+                                                               const int32_t *__restrict__ ixs, T *__restrict__ out, T *__restrict__ out2,
                                                                const int32_t *__restrict__ order, int G, int64_t ld, int64_t cell0,
                                                                int64_t d_row0, int C_main, int tile_main, int C_tail, int tile_tail, int nrndm_all, int stride, int npad, T psc,
                                                                FuseArgs<T> fuse)
 {
     using V = typename Vec<T>::type;
     constexpr int N = Vec<T>::N;
-    constexpr int NV = GRP_MAX_NV;
     constexpr int GCHUNK = NV * 64 * N;                         // genes per chunk
+    constexpr int AS = DUAL ? 4 : 3;                            // running moments per pair: sum A, sum A^2, sum A b [, sum A b2]
+    constexpr int PW = DUAL ? 4 : 2;                            // d-moment partials per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int maxpairs = GC * max(tile_main, tile_tail);        // LDS layout is sized for the widest tile
     T *ec = reinterpret_cast<T *>(smem);                        // [GC][GCHUNK]
     T *dc = ec + GC * GCHUNK;                                   // [GC][GCHUNK]
-    unsigned long long *keys = reinterpret_cast<unsigned long long *>(dc + GC * GCHUNK);   // [npad]
-    T *acc = reinterpret_cast<T *>(keys + npad);                // [3 * maxpairs]
-    int *seg = reinterpret_cast<int *>(acc + 3 * ((maxpairs + 1) & ~1));   // [maxpairs + 2]
+    T *dc2 = dc + GC * GCHUNK;                                  // [GC][GCHUNK] (DUAL only)
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(dc + (DUAL ? 2 : 1) * GC * GCHUNK);   // [npad]
+    T *acc = reinterpret_cast<T *>(keys + npad);                // [AS * maxpairs]
+    int *seg = reinterpret_cast<int *>(acc + AS * ((maxpairs + 1) & ~1));   // [maxpairs + 2]
     double *part = reinterpret_cast<double *>(seg + ((maxpairs + 3) & ~1)); // [64] per-wave d-moment partials
     // (no static __shared__: statics would precede the dynamic region and break its 16-byte alignment)
-    double *s_sb = part + 64, *s_sbb = s_sb + GC;               // [GC] each
-    int *s_cells = reinterpret_cast<int *>(s_sbb + GC);         // [GC]
+    double *s_sb = part + 64, *s_sbb = s_sb + GC, *s_sb2 = s_sbb + GC, *s_sbb2 = s_sb2 + GC;   // [GC] each
+    int *s_cells = reinterpret_cast<int *>(s_sbb2 + GC);        // [GC]
     int *s_wavetot = s_cells + GC;                              // [16]
     int &s_U = s_wavetot[16];
     int *s_next = s_wavetot + 17;                               // dynamic row counter
@@ -286,6 +323,7 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
     const int nrndm = min(tilew, nrndm_all - n0);
     ixs += n0;
     out += n0;
+    if (DUAL) out2 += n0;
     const int g0cell = gpos * GC;
     const int gcount = min(GC, C_out - g0cell);
     const int npairs = gcount * nrndm;
@@ -333,13 +371,14 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
         __syncthreads();
         if (tid == 0) seg[s_U] = npairs;
     }
-    for (int t = tid; t < 3 * npairs; t += blockDim.x) acc[t] = T(0);
+    for (int t = tid; t < AS * npairs; t += blockDim.x) acc[t] = T(0);
     if (tid < 64) part[tid] = 0.0;
     __syncthreads();
     const int U = s_U;
+    const T K = xform_shift<T, TR, RULES>(psc);
     // staging roles: wave w stages member (w % GC), interleaved with the other waves of that member
     const int sm = wave % GC, sh = wave / GC, snh = max(1, nwaves / GC);
-    double psb = 0.0, psbb = 0.0;
+    double psb = 0.0, psbb = 0.0, psb2 = 0.0, psbb2 = 0.0;
 
     for (int g0 = 0; g0 < G; g0 += GCHUNK) {
         const int gl = min(GCHUNK, G - g0);
@@ -351,10 +390,14 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
             const int64_t c = cell0 + s_cells[sm];
             const T *er = e + c * ld + g0;
             const T *dr = (fuse.Ux ? fuse.Ux : d) + (c - d_row0) * ld + g0;     // fused: the member's Ux row
+            const T *dr2 = DUAL ? d2 + (c - d_row0) * ld + g0 : nullptr;
             for (int v = sh * 64 + lane; v < nvec; v += 64 * snh) {
                 V ev = reinterpret_cast<const V *>(er)[v];
                 V dv = reinterpret_cast<const V *>(dr)[v];
+                V dv2;
+                if (DUAL) dv2 = reinterpret_cast<const V *>(dr2)[v];
                 T *dp = reinterpret_cast<T *>(&dv);
+                T *dp2 = reinterpret_cast<T *>(&dv2);
                 T *ep = reinterpret_cast<T *>(&ev);
                 if (fuse.Ux) {
 #pragma unroll
@@ -365,12 +408,16 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
                 }
                 if (ragged && v == nvec - 1) {
 #pragma unroll
-                    for (int k = 0; k < N; ++k) if (k >= gl - v * N) { dp[k] = T(0); ep[k] = T(0); }
+                    for (int k = 0; k < N; ++k) if (k >= gl - v * N) { dp[k] = T(0); ep[k] = T(0); if (DUAL) dp2[k] = T(0); }
                 }
                 reinterpret_cast<V *>(ec + sm * GCHUNK)[v] = ev;
                 reinterpret_cast<V *>(dc + sm * GCHUNK)[v] = dv;
+                if (DUAL) reinterpret_cast<V *>(dc2 + sm * GCHUNK)[v] = dv2;
 #pragma unroll
-                for (int k = 0; k < N; ++k) { psb += (double)dp[k]; psbb += (double)dp[k] * (double)dp[k]; }
+                for (int k = 0; k < N; ++k) {
+                    psb += (double)dp[k]; psbb += (double)dp[k] * (double)dp[k];
+                    if (DUAL) { psb2 += (double)dp2[k]; psbb2 += (double)dp2[k] * (double)dp2[k]; }
+                }
             }
         }
         __syncthreads();
@@ -389,32 +436,36 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
         // compiler batches the 2*NV ds_read_b128 ahead of the arithmetic instead of exposing one LDS
         // latency per vector; two pairs of a row are evaluated together (independent chains -> ILP for
         // the DPP reductions and the LDS accumulator updates).
-        auto pair_moments = [&](const V (&x)[NV], int m, bool full, T &tA, T &tAA, T &tAb) {
-            const T *em = ec + m * GCHUNK, *bm = dc + m * GCHUNK;
-            T sA[N], sAA[N], sAb[N];
+        auto pair_moments = [&](const V (&x)[NV], int m, bool full, T &tA, T &tAA, T &tAb, T &tAb2) {
+            const T *em = ec + m * GCHUNK, *bm = dc + m * GCHUNK, *bm2 = dc2 + m * GCHUNK;
+            T sA[N], sAA[N], sAb[N], sAb2[N];
 #pragma unroll
-            for (int k = 0; k < N; ++k) { sA[k] = T(0); sAA[k] = T(0); sAb[k] = T(0); }
+            for (int k = 0; k < N; ++k) { sA[k] = T(0); sAA[k] = T(0); sAb[k] = T(0); sAb2[k] = T(0); }
             if (full) {
-                constexpr int HB = 2;                            // LDS reads batched: 2*HB b128 in flight per batch
+                constexpr int HB = DUAL ? 1 : 2;                 // LDS reads batched: 2*HB (dual: 3*HB) b128 in flight per batch
 #pragma unroll
                 for (int h = 0; h < NV / HB; ++h) {
-                    V ecv[HB], dcv[HB];
+                    V ecv[HB], dcv[HB], dcv2[HB];
 #pragma unroll
                     for (int u = 0; u < HB; ++u) {
                         ecv[u] = reinterpret_cast<const V *>(em)[lane + 64 * (h * HB + u)];
                         dcv[u] = reinterpret_cast<const V *>(bm)[lane + 64 * (h * HB + u)];
+                        if (DUAL) dcv2[u] = reinterpret_cast<const V *>(bm2)[lane + 64 * (h * HB + u)];
                     }
 #pragma unroll
                     for (int u = 0; u < HB; ++u) {
                         const T *xp = reinterpret_cast<const T *>(&x[h * HB + u]);
                         const T *ep = reinterpret_cast<const T *>(&ecv[u]);
                         const T *bp = reinterpret_cast<const T *>(&dcv[u]);
+                        const T *bp2 = reinterpret_cast<const T *>(&dcv2[u]);
 #pragma unroll
                         for (int k = 0; k < N; ++k) {
-                            const T a = xform<T, TR, RULES>(xp[k] - ep[k], psc);
+                            T a = xform<T, TR, RULES>(xp[k] - ep[k], psc);
+                            if (TR == VCY_LOG10) a -= K;
                             sA[k] += a;
                             sAA[k] = fma(a, a, sAA[k]);
                             sAb[k] = fma(a, bp[k], sAb[k]);
+                            if (DUAL) sAb2[k] = fma(a, bp2[k], sAb2[k]);
                         }
                     }
                 }
@@ -425,34 +476,42 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
                     if (v < nvec) {
                         const V ecv = reinterpret_cast<const V *>(em)[v];
                         const V dcv = reinterpret_cast<const V *>(bm)[v];
+                        V dcv2;
+                        if (DUAL) dcv2 = reinterpret_cast<const V *>(bm2)[v];
                         const T *xp = reinterpret_cast<const T *>(&x[u]);
                         const T *ep = reinterpret_cast<const T *>(&ecv);
                         const T *bp = reinterpret_cast<const T *>(&dcv);
+                        const T *bp2 = reinterpret_cast<const T *>(&dcv2);
                         const int valid = (ragged && v == nvec - 1) ? (gl - v * N) : N;
 #pragma unroll
                         for (int k = 0; k < N; ++k) {
                             T a = xform<T, TR, RULES>(xp[k] - ep[k], psc);
+                            if (TR == VCY_LOG10) a -= K;
                             if (k >= valid) a = T(0);
                             sA[k] += a;
                             sAA[k] = fma(a, a, sAA[k]);
                             sAb[k] = fma(a, bp[k], sAb[k]);
+                            if (DUAL) sAb2[k] = fma(a, bp2[k], sAb2[k]);
                         }
                     }
                 }
             }
-            tA = sA[0]; tAA = sAA[0]; tAb = sAb[0];
+            tA = sA[0]; tAA = sAA[0]; tAb = sAb[0]; tAb2 = sAb2[0];
 #pragma unroll
-            for (int k = 1; k < N; ++k) { tA += sA[k]; tAA += sAA[k]; tAb += sAb[k]; }
+            for (int k = 1; k < N; ++k) { tA += sA[k]; tAA += sAA[k]; tAb += sAb[k]; tAb2 += sAb2[k]; }
         };
         const bool fullchunk = (gl == GCHUNK);
         auto eval_row = [&](const V (&x)[NV], int r) {
             const int p0 = seg[r], p1 = seg[r + 1];
             for (int p = p0; p < p1; ++p) {
                 const int m0 = (int)((keys[p] >> 12) & 15);
-                T a0, b0, c0;
-                pair_moments(x, m0, fullchunk, a0, b0, c0);
-                a0 = wave_sum(a0); b0 = wave_sum(b0); c0 = wave_sum(c0);
-                if (lane == 0) { acc[3 * p] += a0; acc[3 * p + 1] += b0; acc[3 * p + 2] += c0; }
+                T a0, b0, c0, d0;
+                pair_moments(x, m0, fullchunk, a0, b0, c0, d0);
+                // the three (dual: four) wave totals in one transposing reduction: row r of `tot` holds moment r; lane 16 r
+                // adds it to acc[AS p + r] (the single-control kernel feeds a fourth value nobody reads, so that both
+                // variants sum in the same order: the dual outputs equal those of two single launches bit for bit)
+                const T tot = wave_sum_rows(a0, b0, c0, d0);
+                if ((lane & 15) == 0 && (lane >> 4) < AS) acc[AS * p + (lane >> 4)] += tot;
             }
         };
         {
@@ -480,19 +539,27 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
         }
     }
     psb = wave_sum(psb); psbb = wave_sum(psbb);
-    if (lane == 0) { part[2 * wave] = psb; part[2 * wave + 1] = psbb; }
+    if (DUAL) { psb2 = wave_sum(psb2); psbb2 = wave_sum(psbb2); }
+    if (lane == 0) {
+        part[PW * wave] = psb; part[PW * wave + 1] = psbb;
+        if (DUAL) { part[PW * wave + 2] = psb2; part[PW * wave + 3] = psbb2; }
+    }
     __syncthreads();
     if (tid < gcount) {
-        double a = 0.0, b = 0.0;
-        for (int h = 0; h < snh; ++h) { const int w = tid + h * GC; if (w < nwaves) { a += part[2 * w]; b += part[2 * w + 1]; } }
-        s_sb[tid] = a; s_sbb[tid] = b;
+        double a = 0.0, b = 0.0, a2 = 0.0, b2 = 0.0;
+        for (int h = 0; h < snh; ++h) {
+            const int w = tid + h * GC;
+            if (w < nwaves) { a += part[PW * w]; b += part[PW * w + 1]; if (DUAL) { a2 += part[PW * w + 2]; b2 += part[PW * w + 3]; } }
+        }
+        s_sb[tid] = a; s_sbb[tid] = b; s_sb2[tid] = a2; s_sbb2[tid] = b2;
     }
     __syncthreads();
     for (int p = tid; p < npairs; p += blockDim.x) {
         const unsigned long long key = keys[p];
         const int m = (int)((key >> 12) & 15), n = (int)(key & 4095);
-        out[(int64_t)s_cells[m] * stride + n] = pearson_from_moments<T>((double)acc[3 * p], (double)acc[3 * p + 1], (double)acc[3 * p + 2],
-                                                                     s_sb[m], s_sbb[m], (double)G);
+        const double mA = (double)acc[AS * p], mAA = (double)acc[AS * p + 1];
+        out[(int64_t)s_cells[m] * stride + n] = pearson_from_moments<T>(mA, mAA, (double)acc[AS * p + 2], s_sb[m], s_sbb[m], (double)G);
+        if (DUAL) out2[(int64_t)s_cells[m] * stride + n] = pearson_from_moments<T>(mA, mAA, (double)acc[AS * p + 3], s_sb2[m], s_sbb2[m], (double)G);
     }
 }
 
@@ -523,6 +590,7 @@ __global__ __launch_bounds__(256) void k_cdc_full(const T *__restrict__ e, const
     const int sg = tid & 31, sr = tid >> 5;
     double sb = 0.0, sbb = 0.0;  // partial sums of d for row (sr) and (sr + 8), kept by the loader
     double sb2 = 0.0, sbb2 = 0.0;
+    const T K = xform_shift<T, TR, VCY_RULES_FULL>(psc);
     for (int g0 = 0; g0 < G; g0 += FULL_GK) {
         const int glen = min(FULL_GK, G - g0);
         __syncthreads();
@@ -549,7 +617,8 @@ __global__ __launch_bounds__(256) void k_cdc_full(const T *__restrict__ e, const
             const T x = ei[il][g];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const T a = xform<T, TR, VCY_RULES_FULL>(x - ecs[cg * 4 + k][g], psc);
+                T a = xform<T, TR, VCY_RULES_FULL>(x - ecs[cg * 4 + k][g], psc);
+                if (TR == VCY_LOG10) a -= K;
                 sA[k] += a;
                 sAA[k] = fma(a, a, sAA[k]);
                 sAb[k] = fma(a, dcs[cg * 4 + k][g], sAb[k]);
@@ -590,82 +659,81 @@ __global__ void k_scatter_rows(const T *__restrict__ vals, const int32_t *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
-static int g_lds_budget = 0;   // usable dynamic LDS per workgroup
-static int g_cus = 0;
-
-static int query_device()
+template <typename T, int TR, int RULES, int GC, int NV, bool DUAL>
+static int launch_grouped(const void *e, const void *d, const void *d2, const int32_t *ixs, void *out, void *out2, const int32_t *order, int64_t G,
+                          int64_t ld, int64_t cell0, int64_t C_out, int64_t d_row0, int64_t nrndm, double psc, hipStream_t st,
+                          FuseArgs<T> fuse, const DevInfo &dev, bool *done)
 {
-    if (g_cus) return VCY_OK;
-    int dev = 0;
-    VCY_CHECK_HIP(hipGetDevice(&dev));
-    hipDeviceProp_t p;
-    VCY_CHECK_HIP(hipGetDeviceProperties(&p, dev));
-    g_cus = p.multiProcessorCount;
-    g_lds_budget = (int)p.sharedMemPerBlock;   // 64 KiB default; opt-in up to 160 KiB on gfx950
-    int maxopt = 0;
-    if (hipDeviceGetAttribute(&maxopt, hipDeviceAttributeSharedMemPerBlockOptin, dev) == hipSuccess && maxopt > g_lds_budget)
-        g_lds_budget = maxopt;
+    // Cells adjacent in the schedule order share neighbour rows out of LDS.  Neighbour lists wider than one workgroup's LDS
+    // budget (8 x 256 pairs) are walked in column TILES of equal width, block -> (group, tile), each writing its own columns
+    // of `out` (the reference default n_neighbors = C/5, sampled_fraction 0.3 gives nrndm = 3000: 12 tiles; rows of ixs
+    // sorted by neighbour index make the tiles of adjacent cells overlap)
+    constexpr int64_t TILE_MAX = 256;
+    *done = false;
+    const size_t budget_g = (size_t)(dev.lds_optin > 163840 ? 163840 : dev.lds_optin);
+    int64_t ntiles = (nrndm + TILE_MAX - 1) / TILE_MAX, tile = 0;
+    int npad = 2;
+    size_t lds_g = 0;
+    for (;; ++ntiles) {                                  // fewest equal-width tiles whose sort keys + accumulators fit (f64 needs narrower ones)
+        tile = (nrndm + ntiles - 1) / ntiles;
+        const int64_t maxpairs = GC * tile;
+        for (npad = 2; npad < maxpairs; npad <<= 1) {}
+        lds_g = grouped_lds_bytes<T>(GC, NV, DUAL, maxpairs, npad);
+        if (lds_g <= budget_g || tile <= 16) break;
+    }
+    if (!(nrndm >= 8 && C_out >= 4 * GC && nrndm <= 0x7fffffff / 2 && lds_g <= budget_g)) return VCY_OK;
+    auto kern = k_cdc_partial_grouped<T, TR, RULES, GC, NV, DUAL>;
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_g);
+    if (rc) return rc;
+    // One workgroup per CU is resident (LDS), every group costs the same, so the last round of a launch would leave
+    // most CUs idle for a whole group time (6250 groups on 256 CUs: 24.4 rounds; a 6250-cell shard of an 8-GPU run:
+    // 3.05 rounds -> 4).  The groups beyond the last full round therefore run as the last blocks of the launch with their
+    // neighbour lists cut into narrower tiles, as many (group, tile) blocks as there are CUs.
+    const int64_t groups = (C_out + GC - 1) / GC, W = dev.cus > 0 ? dev.cus : 256;
+    const int64_t full = groups >= 2 * W ? groups / W * W : 0;
+    const int64_t c_main = full * GC, c_tail = C_out - c_main;
+    int64_t tw = tile;
+    if (c_tail > 0) {
+        const int64_t left = groups - full;
+        int64_t split = W / (left * ntiles);                       // how many pieces each base tile can be cut into
+        if (split < 1) split = 1;
+        tw = (tile + split - 1) / split;
+        if (tw < 16) tw = tile < 16 ? tile : 16;
+    }
+    auto nblocks = [&](int64_t ncell, int64_t w) { return ncell > 0 ? ((ncell + GC - 1) / GC + 7) / 8 * 8 * ((nrndm + w - 1) / w) : (int64_t)0; };
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nblocks(c_main, tile) + nblocks(c_tail, tw))), dim3(1024), lds_g, st, (const T *)e, (const T *)d,
+                       (const T *)d2, ixs, (T *)out, (T *)out2, order, (int)G, ld, cell0, d_row0, (int)c_main, (int)tile, (int)c_tail, (int)tw,
+                       (int)nrndm, (int)nrndm, npad, (T)psc, fuse);
+    VCY_LAUNCH_CHECK();
+    *done = true;
     return VCY_OK;
 }
 
-static int g_group_pref = -1;    // -1 auto, 0 never, >0 group size (env VCY_CDC_GROUP, read once)
-
+// d2 / out2 non-null: the dual-control form (both correlations of a pair from one evaluation of A).
 template <typename T, int TR, int RULES>
-static int launch_partial(const void *e, const void *d, const int32_t *ixs, void *out, const int32_t *order, int64_t G,
+static int launch_partial(const void *e, const void *d, const void *d2, const int32_t *ixs, void *out, void *out2, const int32_t *order, int64_t G,
                           int64_t ld, int64_t cell0, int64_t C_out, int64_t d_row0, int64_t nrndm, double psc, hipStream_t st,
                           FuseArgs<T> fuse = FuseArgs<T>{nullptr, nullptr, nullptr, T(1), T(1)})
 {
     constexpr int N = Vec<T>::N;
-    if (g_group_pref < 0) { const char *ev = getenv("VCY_CDC_GROUP"); g_group_pref = ev ? atoi(ev) : 8; }
-    {   // grouped variant: cells adjacent in the schedule order share neighbour rows out of LDS.  Neighbour lists wider than
-        // one workgroup's LDS budget (8 x 256 pairs) are walked in column TILES of equal width, one launch per tile,
-        // each writing its own columns of `out` (the reference default n_neighbors = C/5, sampled_fraction 0.3 gives
-        // nrndm = 3000: 12 tiles; rows of ixs sorted by neighbour index make the tiles of adjacent cells overlap)
-        constexpr int GC = 8;
-        constexpr int64_t TILE_MAX = 256;
-        if (g_group_pref < 0) { const char *ev = getenv("VCY_CDC_GROUP"); g_group_pref = ev ? atoi(ev) : GC; }
-        const size_t budget_g = (size_t)(g_lds_budget > 155648 ? 155648 : g_lds_budget);
-        int64_t ntiles = (nrndm + TILE_MAX - 1) / TILE_MAX, tile = 0;
-        int npad = 2;
-        size_t lds_g = 0;
-        for (;; ++ntiles) {                                  // fewest equal-width tiles whose sort keys + accumulators fit (f64 needs narrower ones)
-            tile = (nrndm + ntiles - 1) / ntiles;
-            const int64_t maxpairs = GC * tile;
-            for (npad = 2; npad < maxpairs; npad <<= 1) {}
-            lds_g = (size_t)2 * GC * GRP_MAX_NV * 64 * N * sizeof(T) + (size_t)npad * 8 + sizeof(T) * 3 * ((maxpairs + 1) & ~1) +
-                    sizeof(int) * ((maxpairs + 3) & ~1) + (64 + 2 * GC) * sizeof(double) + (GC + 18) * sizeof(int) + 16;
-            if (lds_g <= budget_g || tile <= 16) break;
-        }
-        if (g_group_pref == GC && nrndm >= 8 && C_out >= 4 * GC && nrndm <= 0x7fffffff / 2 && lds_g <= budget_g) {
-            auto kern = k_cdc_partial_grouped<T, TR, RULES, GC>;
-            VCY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
-            // One workgroup per CU is resident (LDS), every group costs the same, so the last round of a launch would leave
-            // most CUs idle for a whole group time (6250 groups on 256 CUs: 24.4 rounds; a 6250-cell shard of an 8-GPU run:
-            // 3.05 rounds -> 4).  The groups beyond the last full round therefore run as a second launch whose neighbour
-            // lists are cut into narrower tiles, as many (group, tile) blocks as there are CUs.
-            const int64_t groups = (C_out + GC - 1) / GC, W = g_cus > 0 ? g_cus : 256;
-            const int64_t full = groups >= 2 * W ? groups / W * W : 0;
-            const int64_t c_main = full * GC, c_tail = C_out - c_main;
-            int64_t tw = tile;
-            if (c_tail > 0) {
-                const int64_t left = groups - full;
-                int64_t split = W / (left * ntiles);                       // how many pieces each base tile can be cut into
-                if (split < 1) split = 1;
-                tw = (tile + split - 1) / split;
-                if (tw < 16) tw = tile < 16 ? tile : 16;
-            }
-            auto nblocks = [&](int64_t ncell, int64_t w) { return ncell > 0 ? ((ncell + GC - 1) / GC + 7) / 8 * 8 * ((nrndm + w - 1) / w) : (int64_t)0; };
-            hipLaunchKernelGGL(kern, dim3((unsigned)(nblocks(c_main, tile) + nblocks(c_tail, tw))), dim3(1024), lds_g, st, (const T *)e, (const T *)d, ixs,
-                               (T *)out, order, (int)G, ld, cell0, d_row0, (int)c_main, (int)tile, (int)c_tail, (int)tw, (int)nrndm, (int)nrndm, npad,
-                               (T)psc, fuse);
-            VCY_LAUNCH_CHECK();
-            return VCY_OK;
-        }
+    DevInfo dev;
+    int rc = device_info(&dev);
+    if (rc) return rc;
+    if (env_int("VCY_CDC_GROUP", GRP_GC) == GRP_GC) {            // VCY_CDC_GROUP=0: one cell per workgroup (A/B testing)
+        bool done = false;
+        rc = d2 ? launch_grouped<T, TR, RULES, GRP_GC, GRP_NV_DUAL, true>(e, d, d2, ixs, out, out2, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st, fuse, dev, &done)
+                : launch_grouped<T, TR, RULES, GRP_GC, GRP_NV, false>(e, d, nullptr, ixs, out, nullptr, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st, fuse, dev, &done);
+        if (rc || done) return rc;
+    }
+    if (d2) {   // small problems: the one-cell-per-workgroup kernel once per control (never fused: d2 is a materialised matrix)
+        rc = launch_partial<T, TR, RULES>(e, d, nullptr, ixs, out, nullptr, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st, fuse);
+        if (rc) return rc;
+        return launch_partial<T, TR, RULES>(e, d2, nullptr, ixs, out2, nullptr, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st);
     }
     const int quantum = 64 * N;  // one wave-instruction worth of elements
     const size_t fixed = sizeof(T) * 3 * ((nrndm + 1) & ~1) + 32 * sizeof(double);
     // budget: stay under 150 KiB so one workgroup (16 waves) owns a CU; fewest chunks that fit
-    const size_t budget = (size_t)(g_lds_budget > 153600 ? 153600 : g_lds_budget);
+    const size_t budget = (size_t)(dev.lds_optin > 153600 ? 153600 : dev.lds_optin);
     if (fixed + 2 * quantum * sizeof(T) > budget)
         return fail(VCY_ERR_UNSUPPORTED, "%s: nrndm=%lld needs more LDS than the %lld-byte budget", "coldeltacor_partial", (long long)nrndm, (long long)budget);
     const int64_t max_chunk = (int64_t)((budget - fixed) / (2 * sizeof(T))) / quantum * quantum;
@@ -674,7 +742,8 @@ static int launch_partial(const void *e, const void *d, const int32_t *ixs, void
     int64_t gchunk = ((Gq / quantum + nchunks - 1) / nchunks) * quantum;
     const size_t lds = fixed + 2 * gchunk * sizeof(T);
     auto kern = k_cdc_partial<T, TR, RULES>;
-    VCY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+    if (rc) return rc;
     const int threads = (nrndm >= 16) ? 1024 : (nrndm >= 8 ? 512 : 256);
     hipLaunchKernelGGL(kern, dim3((unsigned)((C_out + 7) / 8 * 8)), dim3(threads), lds, st, (const T *)e, (const T *)d, ixs, (T *)out, order,
                        (int)G, ld, cell0, d_row0, (int)C_out, (int)nrndm, (int)gchunk, (T)psc, fuse);
@@ -683,12 +752,12 @@ static int launch_partial(const void *e, const void *d, const int32_t *ixs, void
 }
 
 template <typename T>
-static int dispatch_partial(const void *e, const void *d, const int32_t *ixs, void *out, const int32_t *order, int64_t G,
+static int dispatch_partial(const void *e, const void *d, const void *d2, const int32_t *ixs, void *out, void *out2, const int32_t *order, int64_t G,
                             int64_t ld, int64_t cell0, int64_t C_out, int64_t d_row0, int64_t nrndm, int transform, int rules,
                             double psc, hipStream_t st, FuseArgs<T> fuse = FuseArgs<T>{nullptr, nullptr, nullptr, T(1), T(1)})
 {
 #define VCY_CASE(TR, RU) \
-    if (transform == TR && rules == RU) return launch_partial<T, TR, RU>(e, d, ixs, out, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st, fuse);
+    if (transform == TR && rules == RU) return launch_partial<T, TR, RU>(e, d, d2, ixs, out, out2, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st, fuse);
     VCY_CASE(VCY_LINEAR, VCY_RULES_PARTIAL)
     VCY_CASE(VCY_LINEAR, VCY_RULES_FULL)
     VCY_CASE(VCY_SQRT, VCY_RULES_PARTIAL)
@@ -722,22 +791,41 @@ static int dispatch_full(const void *e, const void *d, void *rm, int64_t C, int6
 
 using namespace vcy;
 
+static int check_partial_args(const char *who, const void *e, const void *d, const int32_t *ixs, const void *out, int64_t C, int64_t G, int64_t ld,
+                              int64_t cell0, int64_t C_out, int64_t d_row0, int64_t nrndm, int dtype)
+{
+    if (!(e && d && ixs && out)) return fail(VCY_ERR_INVALID, "%s: null pointer", who);
+    if (!(C > 0 && G > 0 && nrndm > 0 && C_out > 0 && cell0 >= 0 && cell0 + C_out <= C)) return fail(VCY_ERR_INVALID, "%s: bad shape", who);
+    if (ld < G) return fail(VCY_ERR_INVALID, "%s: ld < G", who);
+    if (!(d_row0 >= 0 && d_row0 <= cell0)) return fail(VCY_ERR_INVALID, "%s: d must cover cells cell0..cell0+C_out-1", who);
+    if (!(dtype == VCY_F32 || dtype == VCY_F64)) return fail(VCY_ERR_INVALID, "%s: bad dtype", who);
+    if (ld % (dtype == VCY_F32 ? 4 : 2) != 0) return fail(VCY_ERR_INVALID, "%s: ld must keep rows 16-byte aligned", who);
+    if (((uintptr_t)e % 16) || ((uintptr_t)d % 16)) return fail(VCY_ERR_INVALID, "%s: e/d must be 16-byte aligned", who);
+    return VCY_OK;
+}
+
 extern "C" int vcy_coldeltacor_partial(const void *e, const void *d, const int32_t *ixs, void *out, const int32_t *order,
                                        int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int64_t d_row0,
                                        int64_t nrndm, int transform, int rules, double psc, int dtype, vcy_stream stream)
 {
-    VCY_REQUIRE(e && d && ixs && out, "coldeltacor_partial: null pointer");
-    VCY_REQUIRE(C > 0 && G > 0 && nrndm > 0 && C_out > 0 && cell0 >= 0 && cell0 + C_out <= C, "coldeltacor_partial: bad shape");
-    VCY_REQUIRE(ld >= G, "coldeltacor_partial: ld < G");
-    VCY_REQUIRE(d_row0 >= 0 && d_row0 <= cell0, "coldeltacor_partial: d must cover cells cell0..cell0+C_out-1");
-    VCY_REQUIRE(dtype == VCY_F32 || dtype == VCY_F64, "coldeltacor_partial: bad dtype");
-    VCY_REQUIRE(ld % (dtype == VCY_F32 ? 4 : 2) == 0, "coldeltacor_partial: ld must keep rows 16-byte aligned");
-    VCY_REQUIRE(((uintptr_t)e % 16 == 0) && ((uintptr_t)d % 16 == 0), "coldeltacor_partial: e/d must be 16-byte aligned");
-    int rc = query_device();
+    int rc = check_partial_args("coldeltacor_partial", e, d, ixs, out, C, G, ld, cell0, C_out, d_row0, nrndm, dtype);
     if (rc) return rc;
     hipStream_t st = as_stream(stream);
-    if (dtype == VCY_F32) return dispatch_partial<float>(e, d, ixs, out, order, G, ld, cell0, C_out, d_row0, nrndm, transform, rules, psc, st);
-    return dispatch_partial<double>(e, d, ixs, out, order, G, ld, cell0, C_out, d_row0, nrndm, transform, rules, psc, st);
+    if (dtype == VCY_F32) return dispatch_partial<float>(e, d, nullptr, ixs, out, nullptr, order, G, ld, cell0, C_out, d_row0, nrndm, transform, rules, psc, st);
+    return dispatch_partial<double>(e, d, nullptr, ixs, out, nullptr, order, G, ld, cell0, C_out, d_row0, nrndm, transform, rules, psc, st);
+}
+
+extern "C" int vcy_coldeltacor_partial_dual(const void *e, const void *d, const void *d_rndm, const int32_t *ixs, void *out, void *out_rndm,
+                                            const int32_t *order, int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int64_t d_row0,
+                                            int64_t nrndm, int transform, int rules, double psc, int dtype, vcy_stream stream)
+{
+    int rc = check_partial_args("coldeltacor_partial_dual", e, d, ixs, out, C, G, ld, cell0, C_out, d_row0, nrndm, dtype);
+    if (rc) return rc;
+    VCY_REQUIRE(d_rndm && out_rndm && out_rndm != out, "coldeltacor_partial_dual: d_rndm / out_rndm missing");
+    VCY_REQUIRE((uintptr_t)d_rndm % 16 == 0, "coldeltacor_partial_dual: d_rndm must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    if (dtype == VCY_F32) return dispatch_partial<float>(e, d, d_rndm, ixs, out, out_rndm, order, G, ld, cell0, C_out, d_row0, nrndm, transform, rules, psc, st);
+    return dispatch_partial<double>(e, d, d_rndm, ixs, out, out_rndm, order, G, ld, cell0, C_out, d_row0, nrndm, transform, rules, psc, st);
 }
 
 extern "C" int vcy_coldeltacor_partial_fused(const void *Sx_sz, const void *Ux_sz, const float *gamma, const float *q, const int32_t *ixs,
@@ -745,20 +833,36 @@ extern "C" int vcy_coldeltacor_partial_fused(const void *Sx_sz, const void *Ux_s
                                             int64_t u_row0, int64_t nrndm, int transform, int rules, double psc, double dt_shift,
                                             double used_dt, int dtype, vcy_stream stream)
 {
-    VCY_REQUIRE(Sx_sz && Ux_sz && gamma && ixs && out, "coldeltacor_partial_fused: null pointer");
-    VCY_REQUIRE(C > 0 && G > 0 && nrndm > 0 && C_out > 0 && cell0 >= 0 && cell0 + C_out <= C && ld >= G, "coldeltacor_partial_fused: bad shape");
-    VCY_REQUIRE(u_row0 >= 0 && u_row0 <= cell0, "coldeltacor_partial_fused: Ux must cover cells cell0..cell0+C_out-1");
-    VCY_REQUIRE(dtype == VCY_F32 || dtype == VCY_F64, "coldeltacor_partial_fused: bad dtype");
-    VCY_REQUIRE(ld % (dtype == VCY_F32 ? 4 : 2) == 0, "coldeltacor_partial_fused: ld must keep rows 16-byte aligned");
-    int rc = query_device();
+    int rc = check_partial_args("coldeltacor_partial_fused", Sx_sz, Ux_sz, ixs, out, C, G, ld, cell0, C_out, u_row0, nrndm, dtype);
     if (rc) return rc;
+    VCY_REQUIRE(gamma, "coldeltacor_partial_fused: null pointer");
     hipStream_t st = as_stream(stream);
     if (dtype == VCY_F32) {
         FuseArgs<float> f{(const float *)Ux_sz, gamma, q, (float)dt_shift, (float)used_dt};
-        return dispatch_partial<float>(Sx_sz, Ux_sz, ixs, out, order, G, ld, cell0, C_out, u_row0, nrndm, transform, rules, psc, st, f);
+        return dispatch_partial<float>(Sx_sz, Ux_sz, nullptr, ixs, out, nullptr, order, G, ld, cell0, C_out, u_row0, nrndm, transform, rules, psc, st, f);
     }
     FuseArgs<double> f{(const double *)Ux_sz, gamma, q, dt_shift, used_dt};
-    return dispatch_partial<double>(Sx_sz, Ux_sz, ixs, out, order, G, ld, cell0, C_out, u_row0, nrndm, transform, rules, psc, st, f);
+    return dispatch_partial<double>(Sx_sz, Ux_sz, nullptr, ixs, out, nullptr, order, G, ld, cell0, C_out, u_row0, nrndm, transform, rules, psc, st, f);
+}
+
+// Stage C folded in AND the randomised control in the same pass: d[c] is evaluated from Ux, gamma, q while it is staged
+// (as in vcy_coldeltacor_partial_fused), d_rndm is the materialised transform of the permuted delta_S.
+extern "C" int vcy_coldeltacor_partial_fused_dual(const void *Sx_sz, const void *Ux_sz, const float *gamma, const float *q, const void *d_rndm,
+                                                 const int32_t *ixs, void *out, void *out_rndm, const int32_t *order, int64_t C, int64_t G, int64_t ld,
+                                                 int64_t cell0, int64_t C_out, int64_t u_row0, int64_t nrndm, int transform, int rules, double psc,
+                                                 double dt_shift, double used_dt, int dtype, vcy_stream stream)
+{
+    int rc = check_partial_args("coldeltacor_partial_fused_dual", Sx_sz, Ux_sz, ixs, out, C, G, ld, cell0, C_out, u_row0, nrndm, dtype);
+    if (rc) return rc;
+    VCY_REQUIRE(gamma && d_rndm && out_rndm && out_rndm != out, "coldeltacor_partial_fused_dual: null pointer");
+    VCY_REQUIRE((uintptr_t)d_rndm % 16 == 0, "coldeltacor_partial_fused_dual: d_rndm must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    if (dtype == VCY_F32) {
+        FuseArgs<float> f{(const float *)Ux_sz, gamma, q, (float)dt_shift, (float)used_dt};
+        return dispatch_partial<float>(Sx_sz, Ux_sz, d_rndm, ixs, out, out_rndm, order, G, ld, cell0, C_out, u_row0, nrndm, transform, rules, psc, st, f);
+    }
+    FuseArgs<double> f{(const double *)Ux_sz, gamma, q, dt_shift, used_dt};
+    return dispatch_partial<double>(Sx_sz, Ux_sz, d_rndm, ixs, out, out_rndm, order, G, ld, cell0, C_out, u_row0, nrndm, transform, rules, psc, st, f);
 }
 
 extern "C" int vcy_coldeltacor_full(const void *e, const void *d, void *rm, int64_t C, int64_t G, int64_t ld, int64_t cell0,

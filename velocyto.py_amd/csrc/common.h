@@ -74,6 +74,55 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v)
     v += dpp_val<0x143, 0xC>(v);   // row_bcast31 -> rows 2, 3
     return lane63(v);
 }
+// ---- four wave totals for the price of one: transposing reduction on the gfx950 lane-swap instructions.
+// v_permlane32_swap exchanges lanes 32..63 of its first operand with lanes 0..31 of its second, so after swap(a, c) the
+// sum a + c holds, per lane column, the two-half partial of a in lanes 0..31 and that of c in lanes 32..63: one swap and
+// one add halve two values at once.  v_permlane16_swap does the same with 16-lane rows.  Two levels leave row r of the
+// result holding the 16 column partials of the r-th argument; four DPP adds inside the row finish it.  10 VALU
+// instructions for four totals (3 swaps, 3 adds, 4 DPP adds) against 4 x (6 DPP adds + 2 moves + readlane) for four
+// wave_sum calls.  Returns: every lane of row r (lanes 16r..16r+15) holds the wave total of argument r.
+// Must be called with all 64 lanes active.
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lane_swap32(float &a, float &b)
+{
+    const v2u_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r.x); b = __uint_as_float(r.y);
+}
+__device__ __forceinline__ void lane_swap16(float &a, float &b)
+{
+    const v2u_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r.x); b = __uint_as_float(r.y);
+}
+__device__ __forceinline__ void lane_swap32(double &a, double &b)
+{
+    const unsigned long long ba = (unsigned long long)__double_as_longlong(a), bb = (unsigned long long)__double_as_longlong(b);
+    const v2u_t lo = __builtin_amdgcn_permlane32_swap((unsigned)ba, (unsigned)bb, false, false);
+    const v2u_t hi = __builtin_amdgcn_permlane32_swap((unsigned)(ba >> 32), (unsigned)(bb >> 32), false, false);
+    a = __longlong_as_double((long long)(((unsigned long long)hi.x << 32) | lo.x));
+    b = __longlong_as_double((long long)(((unsigned long long)hi.y << 32) | lo.y));
+}
+__device__ __forceinline__ void lane_swap16(double &a, double &b)
+{
+    const unsigned long long ba = (unsigned long long)__double_as_longlong(a), bb = (unsigned long long)__double_as_longlong(b);
+    const v2u_t lo = __builtin_amdgcn_permlane16_swap((unsigned)ba, (unsigned)bb, false, false);
+    const v2u_t hi = __builtin_amdgcn_permlane16_swap((unsigned)(ba >> 32), (unsigned)(bb >> 32), false, false);
+    a = __longlong_as_double((long long)(((unsigned long long)hi.x << 32) | lo.x));
+    b = __longlong_as_double((long long)(((unsigned long long)hi.y << 32) | lo.y));
+}
+template <typename T> __device__ __forceinline__ T wave_sum_rows(T a, T b, T c, T d)
+{
+    lane_swap32(a, c);                 // a + c: lanes 0..31 <- a over both halves, lanes 32..63 <- c
+    lane_swap32(b, d);
+    T ac = a + c, bd = b + d;
+    lane_swap16(ac, bd);               // ac + bd: row 0 <- a, row 1 <- b, row 2 <- c, row 3 <- d (16 column partials each)
+    T v = ac + bd;
+    v += dpp_val<0xB1, 0xF>(v);        // quad_perm [1,0,3,2]
+    v += dpp_val<0x4E, 0xF>(v);        // quad_perm [2,3,0,1]
+    v += dpp_val<0x141, 0xF>(v);       // row_half_mirror
+    v += dpp_val<0x140, 0xF>(v);       // row_mirror: every lane of the row holds the row total
+    return v;
+}
+
 template <typename T> __device__ __forceinline__ T wave_max(T v)
 {
 #pragma unroll
@@ -98,5 +147,12 @@ template <typename T> __device__ __forceinline__ T block_sum(T v, T *scratch)
 }
 
 inline hipStream_t as_stream(vcy_stream s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- process-wide facts, each computed once under a lock and then only read (layout.hip): nothing a call can observe
+// changes between calls, so the entry points stay re-entrant from any number of host threads and devices.
+struct DevInfo { int cus; int lds_optin; };                      // CU count, largest dynamic LDS a workgroup may ask for
+int device_info(DevInfo *out);                                   // properties of the CURRENT device (cached per device id)
+int ensure_dynamic_lds(const void *kernel, size_t bytes);        // hipFuncAttributeMaxDynamicSharedMemorySize, raised once per (device, kernel)
+int env_int(const char *name, int dflt);                         // integer environment switch, read once per name
 
 }  // namespace vcy

@@ -410,13 +410,12 @@ static int knn_search_impl(const float *xt, const double *x64, const float *qt, 
     VCY_REQUIRE(lds <= 150 * 1024, "knn_search: feature dimension too large for LDS");
     int nb = 1;                                                   // bits for a thread's slice position: jc = tid + 256 * pos
     while (((int64_t)1 << nb) < (C + 255) / 256 + KNN_NC) ++nb;
-    static int rows_pref = -1;                                    // VCY_KNN_ROWS=1 forces the row-materialising kernel (A/B testing)
-    if (rows_pref < 0) { const char *ev = getenv("VCY_KNN_ROWS"); rows_pref = ev ? atoi(ev) : 0; }
+    const int rows_pref = env_int("VCY_KNN_ROWS", 0);             // VCY_KNN_ROWS=1 forces the row-materialising kernel (A/B testing)
     // the threshold comes from 2 words per thread: with Ksel near 512 it is loose and most threads overflow
     const bool rows = large || ksel > 128 || nb > 10 || rows_pref == 1;
 #define VCY_KNN_LAUNCH(L, R)                                                                                                       \
     do {                                                                                                                           \
-        VCY_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_knn_search<L, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        { const int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(k_knn_search<L, R>), lds); if (rc_) return rc_; }    \
         hipLaunchKernelGGL((k_knn_search<L, R>), dim3(blocks), dim3(256), lds, as_stream(stream), xt, x64, qt, q64, ldq, idx, dist, (float *)workspace, \
                            ws_sort, (int)C, (int)P, ldx, q0, (int)Q, (int)k, (int)ksel, nsort, include_self, nb);                \
     } while (0)

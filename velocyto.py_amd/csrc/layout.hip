@@ -4,9 +4,63 @@
 // kernels gather columns at stride C.  On the device a cell's gene vector is one contiguous row;
 // this file holds the tiled transpose (+ dtype change) that converts at the API boundary.
 #include "common.h"
+#include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include <utility>
 
 namespace vcy {
 thread_local char g_err[512] = "";
+
+// Write-once caches behind one mutex (see common.h).  They hold facts about the machine and the environment, never
+// anything derived from a caller's data, and an entry is immutable once inserted.
+static std::mutex g_once_mutex;
+static std::map<int, DevInfo> g_devinfo;
+static std::map<std::pair<int, const void *>, size_t> g_dyn_lds;
+static std::map<std::string, int> g_env;
+
+int device_info(DevInfo *out)
+{
+    int dev = 0;
+    VCY_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_once_mutex);
+    auto it = g_devinfo.find(dev);
+    if (it == g_devinfo.end()) {
+        hipDeviceProp_t p;
+        VCY_CHECK_HIP(hipGetDeviceProperties(&p, dev));
+        DevInfo d{p.multiProcessorCount, (int)p.sharedMemPerBlock};   // 64 KiB default; opt-in up to 160 KiB on gfx950
+        int opt = 0;
+        if (hipDeviceGetAttribute(&opt, hipDeviceAttributeSharedMemPerBlockOptin, dev) == hipSuccess && opt > d.lds_optin) d.lds_optin = opt;
+        it = g_devinfo.emplace(dev, d).first;
+    }
+    *out = it->second;
+    return VCY_OK;
+}
+
+int ensure_dynamic_lds(const void *kernel, size_t bytes)
+{
+    int dev = 0;
+    VCY_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_once_mutex);
+    size_t &have = g_dyn_lds[std::make_pair(dev, kernel)];
+    if (bytes > have) {
+        VCY_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        have = bytes;
+    }
+    return VCY_OK;
+}
+
+int env_int(const char *name, int dflt)
+{
+    std::lock_guard<std::mutex> lock(g_once_mutex);
+    auto it = g_env.find(name);
+    if (it == g_env.end()) {
+        const char *ev = getenv(name);
+        it = g_env.emplace(name, ev ? atoi(ev) : dflt).first;
+    }
+    return it->second;
+}
 
 // 64 x 64 tile through LDS (+1 padding): reads coalesced along src columns, writes coalesced
 // along dst columns.  dst padding columns [rows, ld_dst) are zero-filled by the row's last tile.
@@ -46,17 +100,16 @@ extern "C" int vcy_abi_version(void) { return 1; }
 
 extern "C" int vcy_device_info(int *cu_count, int *lds_bytes_per_block, int64_t *hbm_bytes)
 {
-    int dev = 0;
-    VCY_CHECK_HIP(hipGetDevice(&dev));
-    hipDeviceProp_t p;
-    VCY_CHECK_HIP(hipGetDeviceProperties(&p, dev));
-    if (cu_count) *cu_count = p.multiProcessorCount;
-    if (lds_bytes_per_block) {
-        int v = (int)p.sharedMemPerBlock, opt = 0;
-        if (hipDeviceGetAttribute(&opt, hipDeviceAttributeSharedMemPerBlockOptin, dev) == hipSuccess && opt > v) v = opt;
-        *lds_bytes_per_block = v;
+    DevInfo d;
+    int rc = device_info(&d);
+    if (rc) return rc;
+    if (cu_count) *cu_count = d.cus;
+    if (lds_bytes_per_block) *lds_bytes_per_block = d.lds_optin;
+    if (hbm_bytes) {
+        size_t free_b = 0, total_b = 0;
+        VCY_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
+        *hbm_bytes = (int64_t)total_b;
     }
-    if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
     return VCY_OK;
 }
 

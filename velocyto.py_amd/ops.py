@@ -302,6 +302,74 @@ def coldeltacor_partial_fused(Sx: CellMatrix, Ux: CellMatrix, gamma: torch.Tenso
     return out if perm is None else user_out.scatter_(1, perm[0], perm[1])
 
 
+def _sched(order, dev, C_out):
+    """(order tensor or None, number of scheduled cells)."""
+    if order is None:
+        return None, C_out
+    order = order.to(device=dev, dtype=torch.int32).contiguous()
+    assert int(order.numel()) <= C_out
+    return order, int(order.numel())
+
+
+def coldeltacor_partial_dual(e: CellMatrix, d: CellMatrix, d_rndm: CellMatrix, ixs, transform: int, rules: int = RULES_PARTIAL,
+                             psc: float = 0.0, cell0: int = 0, order: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                             out_rndm: Optional[torch.Tensor] = None, d_row0: int = 0, validate: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(corr, corr_rndm): the real and the randomised-control correlations of a neighbour list in one pass
+    (vcy_coldeltacor_partial_dual; analysis.py:1539-1542, 1578-1601)."""
+    assert e.ld == d.ld == d_rndm.ld and e.dtype == d.dtype == d_rndm.dtype and e.G == d.G == d_rndm.G and d.C == d_rndm.C
+    ix = _as_i32(ixs, e.t.device)
+    C_out, nrndm = ix.shape
+    assert d_row0 <= cell0 and cell0 + C_out <= d_row0 + d.C
+    if validate and ix.numel() and (int(ix.min()) < 0 or int(ix.max()) >= e.C):
+        raise ValueError("neighbour index out of range")
+    out = torch.empty((C_out, nrndm), dtype=e.dtype, device=e.t.device) if out is None else out
+    out_rndm = torch.empty((C_out, nrndm), dtype=e.dtype, device=e.t.device) if out_rndm is None else out_rndm
+    order, n_sched = _sched(order, e.t.device, C_out)
+    if n_sched == 0:
+        return out, out_rndm
+    ix, perm, _ = _sorted_rows(ix, out)
+    perm2 = None if perm is None else out_rndm.gather(1, perm[0])
+    _lib.check(_lib.lib().vcy_coldeltacor_partial_dual(e.t.data_ptr(), d.t.data_ptr(), d_rndm.t.data_ptr(), ix.data_ptr(),
+                                                       (out if perm is None else perm[1]).data_ptr(), (out_rndm if perm is None else perm2).data_ptr(),
+                                                       _p(order), e.C, e.G, e.ld, cell0, n_sched, d_row0, nrndm, transform, rules, float(psc),
+                                                       e.code, _stream()), "coldeltacor_partial_dual")
+    if perm is not None:
+        out.scatter_(1, perm[0], perm[1])
+        out_rndm.scatter_(1, perm[0], perm2)
+    return out, out_rndm
+
+
+def coldeltacor_partial_fused_dual(Sx: CellMatrix, Ux: CellMatrix, gamma: torch.Tensor, q: Optional[torch.Tensor], d_rndm: CellMatrix, ixs,
+                                   transform: int, rules: int = RULES_PARTIAL, psc: float = 0.0, dt_shift: float = 1.0, used_dt: float = 1.0,
+                                   cell0: int = 0, u_row0: int = 0, order: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                                   out_rndm: Optional[torch.Tensor] = None, validate: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Stage C + D + the randomised control in one launch (vcy_coldeltacor_partial_fused_dual)."""
+    assert Sx.ld == Ux.ld == d_rndm.ld and Sx.dtype == Ux.dtype == d_rndm.dtype and Sx.G == Ux.G == d_rndm.G and Ux.C == d_rndm.C
+    dev = Sx.t.device
+    ix = _as_i32(ixs, dev)
+    C_out, nrndm = ix.shape
+    assert u_row0 <= cell0 and cell0 + C_out <= u_row0 + Ux.C
+    if validate and ix.numel() and (int(ix.min()) < 0 or int(ix.max()) >= Sx.C):
+        raise ValueError("neighbour index out of range")
+    out = torch.empty((C_out, nrndm), dtype=Sx.dtype, device=dev) if out is None else out
+    out_rndm = torch.empty((C_out, nrndm), dtype=Sx.dtype, device=dev) if out_rndm is None else out_rndm
+    gamma = gamma.to(device=dev, dtype=torch.float32).contiguous()
+    q = None if q is None else q.to(device=dev, dtype=torch.float32).contiguous()
+    order, n_sched = _sched(order, dev, C_out)
+    if n_sched == 0:
+        return out, out_rndm
+    ix, perm, _ = _sorted_rows(ix, out)
+    perm2 = None if perm is None else out_rndm.gather(1, perm[0])
+    _lib.check(_lib.lib().vcy_coldeltacor_partial_fused_dual(Sx.t.data_ptr(), Ux.t.data_ptr(), gamma.data_ptr(), _p(q), d_rndm.t.data_ptr(), ix.data_ptr(),
+                                                             (out if perm is None else perm[1]).data_ptr(), (out_rndm if perm is None else perm2).data_ptr(),
+                                                             _p(order), Sx.C, Sx.G, Sx.ld, cell0, n_sched, u_row0, nrndm, transform, rules, float(psc),
+                                                             float(dt_shift), float(used_dt), Sx.code, _stream()), "coldeltacor_partial_fused_dual")
+    if perm is not None:
+        out.scatter_(1, perm[0], perm[1])
+        out_rndm.scatter_(1, perm[0], perm2)
+    return out, out_rndm
+
+
 def coldeltacor_full(e: CellMatrix, d: CellMatrix, transform: int, psc: float = 0.0, cell0: int = 0,
                      C_out: Optional[int] = None, rm: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
     """Dense correlation rows rm[c, i] for c in [cell0, cell0+C_out), all i."""
