@@ -7,18 +7,25 @@ sampled_fraction=0.5) => nrndm = 250.  One timed "step" = one pass of the path o
 dataset, inputs (count layers + size factors, pcs, sampled embedding neighbours) already resident in HBM:
 
   A  knn_imputation : exact kNN search in pcs + connectivity weights + pooling of S_sz and U_sz (gathered from the
-                      resident uint16 count layers and per-cell size factors: S_sz = factor * counts)
+                      resident count layers and per-cell size factors: S_sz = factor * counts)
   B  fit_slope      : per-gene gamma = max(0, <Sx,Ux>/<Sx,Sx>)
   C  velocity chain : predict_U -> velocity -> delta_S -> signed-sqrt dmat (one fused pass; by default folded into D's staging)
   D  colDeltaCorSqrtpartial on the sampled embedding neighbours (the dominant kernel)
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): cells are sharded, total work
-fixed ("strong" scaling): ranks all-reduce the fit moments, all-gather the Sx shards (every rank
-needs all of `e`) and all-gather the compact correlation rows.
+`--workload cfg5` runs the atlas-scale form of the same path (BASELINE.json configs[4]): CSR count layers at ~8 % density,
+streamed over Hilbert-ordered cell blocks with sharded `e` (velocyto_amd/atlas.py).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_cdc_partial), from HIP-event
-timing of that launch; `cpu_baseline` times the REFERENCE's own compiled kernel (oracle/_ref) plus the
-oracle port for stages A-C on a bounded closed sub-problem on the host cores.
+N > 1 (one rank per GPU over RCCL; launched by torch.distributed.run, or self-launched with torch.multiprocessing when
+WORLD_SIZE is not set): cells are sharded, total work fixed ("strong" scaling): ranks all-reduce the fit moments, exchange
+the halo rows of Sx their neighbour lists reference and all-gather the compact correlation rows.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_cdc_partial_grouped): it is VALU-issue-bound, so
+`achieved` is its VALU wave-instruction rate (instructions per launch from the rocprofv3 SQ_INSTS_VALU pass named in
+`roofline.counters_from`, scaled by the exact pair-chunk count of this run; time from HIP events of this run) against the
+issue peak of the chip; the HBM-side figures ride along (`hbm_frac_measured`, `vs_noreuse_model`).  `stages` holds the
+per-stage rooflines, `extra` the reference-precision (f64), uint16-layer and randomised-control lines of the same workload.
+`cpu_baseline` times the oracle restatement (oracle/libvelocyto_oracle.so + oracle.py) on a bounded closed sub-problem
+on the host cores.
 """
 import argparse
 import json
@@ -35,10 +42,15 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-HBM_PEAK = 8.0e12   # B/s, MI355X spec (MI355X_MICROARCH.md)
-# profiles/r01k_bench_50kx30k_pmc.csv, k_cdc_partial_grouped<float,SQRT,PARTIAL,8> (velocity chain folded in) at the default
-# workload on 1 GPU: 2 * FETCH_SIZE (37 961 180 KiB; gfx950 half-count correction) + WRITE_SIZE (50 023 KiB), in bytes per launch
-PMC_TRAFFIC_DEFAULT = 2 * 38573338.3125 * 1024 + 50023.84375 * 1024
+HBM_PEAK = 8.0e12                 # B/s, MI355X spec (MI355X_MICROARCH.md)
+# VALU issue peak: 256 CUs x 4 SIMD-32, one wave64 instruction per 2 clocks per SIMD at 2.4 GHz (MI355X_MICROARCH.md
+# "Per-instruction cycle constants": v_fma_f32 2 cyc; tools/ubench/valu_issue.hip measures 2.25 for the plain 2-operand ops)
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
+# Issue cost of the instruction mix the transform + three moment updates NEED per element, at the rates measured by
+# tools/ubench/valu_issue.hip (profiles/r02_valu_issue.txt; clocks per wave64 instruction per SIMD): packed sub 4.27/2,
+# |t|*2^54 clamp 2.5, fma with the psc SGPR 4.16, v_sqrt_f32 8.1, v_bfi_b32 4.2, packed add 4.27/2, two packed fma 4.27
+MIX_CLK_PER_ELEMENT = 4.27 / 2 + 2.53 + 4.16 + 8.12 + 4.2 + 4.27 / 2 + 4.27
+COUNTERS_FILE = os.path.join(ROOT, "profiles", "r02_cdc_counters.json")     # written by tools/summarize_profiles.py from the rocprofv3 passes
 
 
 def parse():
@@ -55,8 +67,17 @@ def parse():
     ap.add_argument("--cpu-cells", type=int, default=1024, help="cells of the closed CPU-baseline sub-problem")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
-                    help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass; the default workload "
-                         "uses the figure recorded in profiles/r01k_bench_50kx30k_pmc.csv, other workloads report null")
+                    help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass of THIS command; without it "
+                         "the figure recorded for the default workload in profiles/r02_cdc_counters.json is reported (named in "
+                         "roofline.counters_from), null for any other workload")
+    ap.add_argument("--workload", choices=["cfg3", "cfg5"], default="cfg3",
+                    help="cfg3: dense count layers, everything resident (the headline); cfg5: CSR layers, block-streamed (atlas.py)")
+    ap.add_argument("--density", type=float, default=0.08, help="cfg5: fraction of non-zero counts per cell")
+    ap.add_argument("--block-cells", type=int, default=0, help="cfg5: cells per streamed block (0 = chosen from free HBM)")
+    ap.add_argument("--counts", choices=["auto", "u16"], default="auto",
+                    help="storage of the resident count layers: auto = uint8 when no count exceeds 255, else uint16; u16 forces uint16")
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32", help="arithmetic / storage type of the path (f64 = the reference's)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the f64 / uint16 / randomised-control lines")
     ap.add_argument("--slab", type=int, default=0, help="gene slab of the pooling kernel (0 = library default)")
     ap.add_argument("--no-fuse", dest="fuse", action="store_false",
                     help="materialise dmat with k_velocity_chain instead of folding the velocity chain into stage D")
@@ -151,18 +172,24 @@ def sample_neighbors_device(embedding, n_neighbors, sampled_fraction, dev, seed=
 
 
 class Pipeline:
-    def __init__(self, args, dev, rank, world):
+    """One rank's view of the path.  `dtype`: torch.float32 (production) or torch.float64 (the reference's arithmetic);
+    `data`: the synthetic dataset (cS, cU, fS, fU, pcs) shared by the pipelines of one process."""
+
+    def __init__(self, args, dev, rank, world, dtype=torch.float32, data=None, counts="auto"):
         from velocyto_amd import ops, distributed
         self.ops, self.D = ops, distributed
-        self.a, self.dev, self.rank, self.world = args, dev, rank, world
+        self.a, self.dev, self.rank, self.world, self.dtype = args, dev, rank, world, dtype
         C, G = args.cells, args.genes
-        # resident inputs: the loom's uint16 count layers + per-cell size factors (S_sz = fS * S is never materialised)
-        self.cS, self.cU, self.fS, self.fU, self.pcs = synth_counts(C, G, args.pca_dims, dev)
+        # resident inputs: the loom's count layers + per-cell size factors (S_sz = fS * S is never materialised)
+        self.cS, self.cU, self.fS, self.fU, self.pcs = data if data is not None else synth_counts(C, G, args.pca_dims, dev)
+        if counts == "u16":                      # real looms are uint16 on disk (constants.py:11); a few heavy genes exceed 255
+            widen = lambda m: m if m.t.dtype == torch.int16 else ops.CountMatrix(m.t.to(torch.int16), m.G)
+            self.cS, self.cU = widen(self.cS), widen(self.cU)
         if world > 1:
             dist.broadcast(self.pcs, 0)          # every rank must relabel / shard by the same embedding, bit for bit
         self.collect = world > 1 or distributed.FORCE
         if self.collect:
-            # cell-sharded run: relabel the cells in Morton order of the embedding so that a rank's contiguous block
+            # cell-sharded run: relabel the cells along a space-filling curve of the embedding so that a rank's contiguous block
             # of cells is spatially coherent and most sampled neighbours are rank-local (dataset preprocessing, untimed)
             perm = (ops.hilbert_order(self.pcs[:, :2].contiguous()) if args.curve == "hilbert" else ops.morton_order(self.pcs[:, :2].contiguous(), 2)).long()
             self.perm = perm
@@ -182,30 +209,39 @@ class Pipeline:
         self.pool_order = ((ops.hilbert_order(self.space[self.c0:self.c1]) if args.curve == "hilbert" else ops.morton_order(self.space[self.c0:self.c1], 3))
                            if args.order == "embedding" else None)
         # persistent outputs
-        self.Ux_loc = ops.CellMatrix.empty(nloc, G, torch.float32)
-        if self.collect:
-            # the rank's own rows of e = Sx_sz live inside the full-height buffer the exchange fills: pooling writes them in place
-            self.Sx_full = ops.CellMatrix(torch.zeros((C, ops.padded_ld(G)), dtype=torch.float32, device=dev), G)
-            self.Sx_loc = self.Sx_full.rows(self.c0, self.c1)
-        else:
-            self.Sx_loc = ops.CellMatrix.empty(nloc, G, torch.float32)
-            self.Sx_full = self.Sx_loc
+        self.Ux_loc = ops.CellMatrix.empty(nloc, G, dtype)
         self.plan = None
+        self.sched = None
+        self.neigh_k = self.neigh_loc          # neighbour lists in the row numbering of the buffer stage D reads (`e_rows`)
         if self.collect and args.exchange == "halo":
+            # SHARDED e: a rank holds its own rows of e = Sx_sz followed by the halo rows its neighbour lists reference
+            # (compact buffer of n_loc + n_halo rows; the lists are renumbered once per graph)
             need = torch.zeros(C, dtype=torch.bool, device=dev)
             need[self.neigh_loc.reshape(-1).long()] = True
             need[self.c0:self.c1] = True
             self.plan = distributed.HaloPlan(need, C)
-        # interior cells (all sampled neighbours rank-local) need no remote row: their stage D runs while the halo moves
-        self.sched = None
-        if self.plan is not None and args.overlap:
-            base = self.order.long() if self.order is not None else torch.arange(nloc, device=dev)
-            inter = ((self.neigh_loc >= self.c0) & (self.neigh_loc < self.c1)).all(1)
-            self.sched = (base[inter[base]].to(torch.int32).contiguous(), base[~inter[base]].to(torch.int32).contiguous())
-        self.corr_loc = torch.empty((nloc, self.nrndm), dtype=torch.float32, device=dev)
-        self.corr = torch.empty((C, self.nrndm), dtype=torch.float32, device=dev) if self.collect else self.corr_loc
-        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(10)]
-        self.stage_ms = np.zeros(5)
+            self.e_rows = ops.CellMatrix(torch.zeros((nloc + self.plan.n_recv, ops.padded_ld(G)), dtype=dtype, device=dev), G)
+            self.Sx_loc = self.e_rows.rows(0, nloc)
+            self.neigh_k = self.plan.localize(self.neigh_loc)
+            if args.overlap:
+                # interior cells (all sampled neighbours rank-local) need no remote row: their stage D runs while the halo moves
+                base = self.order.long() if self.order is not None else torch.arange(nloc, device=dev)
+                inter = ((self.neigh_loc >= self.c0) & (self.neigh_loc < self.c1)).all(1)
+                self.sched = (base[inter[base]].to(torch.int32).contiguous(), base[~inter[base]].to(torch.int32).contiguous())
+            self.e_cell0 = 0
+        elif self.collect:
+            # all-gather exchange: the full-height buffer, own rows written in place by the pooling
+            self.e_rows = ops.CellMatrix(torch.zeros((C, ops.padded_ld(G)), dtype=dtype, device=dev), G)
+            self.Sx_loc = self.e_rows.rows(self.c0, self.c1)
+            self.e_cell0 = self.c0
+        else:
+            self.Sx_loc = ops.CellMatrix.empty(nloc, G, dtype)
+            self.e_rows = self.Sx_loc
+            self.e_cell0 = 0
+        self.corr_loc = torch.empty((nloc, self.nrndm), dtype=dtype, device=dev)
+        self.corr = torch.empty((C, self.nrndm), dtype=dtype, device=dev) if self.collect else self.corr_loc
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(12)]
+        self.stage_ms = np.zeros(7)
         self.d_ms = []
 
     def step(self, timed=False):
@@ -217,13 +253,15 @@ class Pipeline:
         ev[0].record()
         # ---- A: kNN graph (analysis.py:1005) -> connectivity weights (:1006-1010) -> pooling (:1012-1013)
         idx, dist_ = ops.knn_search(self.space, k, include_self=False, q0=c0, Q=nloc)
-        conn = (dist_ > 0).to(torch.float32)                                   # (knn > 0): zero-distance neighbours drop out
-        wrow = torch.cat([torch.ones((nloc, 1), device=self.dev), conn], 1)     # diag = 1
+        ev[9].record()
+        conn = (dist_ > 0).to(self.dtype)                                      # (knn > 0): zero-distance neighbours drop out
+        wrow = torch.cat([torch.ones((nloc, 1), device=self.dev, dtype=self.dtype), conn], 1)     # diag = 1
         wrow = wrow / wrow.sum(1, keepdim=True)
         indices = torch.cat([torch.arange(c0, c1, device=self.dev, dtype=torch.int32)[:, None], idx], 1).contiguous()
         indptr = torch.arange(0, (nloc + 1) * (k + 1), k + 1, device=self.dev, dtype=torch.int64)
         wrow = wrow.contiguous()
-        ops.knn_pool_counts(self.cS, self.cU, self.fS, self.fU, indptr, indices, wrow, dtype=torch.float32, cell0=c0, C_out=nloc,
+        ev[10].record()
+        ops.knn_pool_counts(self.cS, self.cU, self.fS, self.fU, indptr, indices, wrow, dtype=self.dtype, cell0=c0, C_out=nloc,
                             out=self.Sx_loc, out2=self.Ux_loc, validate=False, order=self.pool_order, slab_genes=self.a.slab)
         ev[1].record()
         # ---- B: fit_slope (estimation.py:267-279); sharded: all-reduce of the per-gene moments
@@ -240,24 +278,24 @@ class Pipeline:
         # ---- D: colDeltaCorSqrtpartial; sharded: every rank needs the rows of e = Sx_sz its neighbour lists reference
         def stage_d(order):
             if a.fuse:
-                ops.coldeltacor_partial_fused(self.Sx_full, self.Ux_loc, gamma, None, self.neigh_loc, ops.SQRT, ops.RULES_PARTIAL, 1e-10,
-                                              cell0=c0, u_row0=c0, order=order, out=self.corr_loc, validate=False)
+                ops.coldeltacor_partial_fused(self.e_rows, self.Ux_loc, gamma, None, self.neigh_k, ops.SQRT, ops.RULES_PARTIAL, 1e-10,
+                                              cell0=self.e_cell0, u_row0=self.e_cell0, order=order, out=self.corr_loc, validate=False)
             else:
-                ops.coldeltacor_partial(self.Sx_full, dmat, self.neigh_loc, ops.SQRT, ops.RULES_PARTIAL, 1e-10, cell0=c0,
-                                        d_row0=c0, order=order, out=self.corr_loc, validate=False)
+                ops.coldeltacor_partial(self.e_rows, dmat, self.neigh_k, ops.SQRT, ops.RULES_PARTIAL, 1e-10, cell0=self.e_cell0,
+                                        d_row0=self.e_cell0, order=order, out=self.corr_loc, validate=False)
         if self.sched is not None:
-            handle = self.plan.begin(self.Sx_loc.t, self.Sx_full.t)    # halo rows packed, all_to_all_single started (async on RCCL)
+            handle = self.plan.begin(self.Sx_loc.t, recv_out=self.e_rows.t[nloc:])    # halo rows packed, all_to_all_single started (async on RCCL)
             ev[4].record()
             stage_d(self.sched[0])                                      # interior cells: overlaps with the transfer
             ev[7].record()
-            self.plan.end(handle, self.Sx_full.t)                       # stream waits for the transfer, rows scattered in place
+            self.plan.end(handle, self.e_rows.t, row0=nloc)             # stream waits for the transfer, rows land behind the rank's own
             ev[8].record()
             stage_d(self.sched[1])                                      # cells with at least one remote neighbour
         else:
             if self.plan is not None:
-                self.plan.exchange(self.Sx_loc.t, self.Sx_full.t)      # halo rows only (all_to_all_single)
+                self.plan.end(self.plan.begin(self.Sx_loc.t, recv_out=self.e_rows.t[nloc:]), self.e_rows.t, row0=nloc)      # halo rows only
             elif self.collect:
-                self.D.all_gather_rows(self.Sx_loc.t, C, out=self.Sx_full.t)
+                self.D.all_gather_rows(self.Sx_loc.t, C, out=self.e_rows.t)
             ev[4].record()
             ev[7].record()
             ev[8].record()
@@ -270,15 +308,50 @@ class Pipeline:
             torch.cuda.synchronize()
             t_d = ev[4].elapsed_time(ev[7]) + ev[8].elapsed_time(ev[5])          # both parts of stage D (one part when not overlapped)
             self.stage_ms += np.array([ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3]),
-                                       ev[3].elapsed_time(ev[4]) + ev[7].elapsed_time(ev[8]) + ev[5].elapsed_time(ev[6]), t_d])
+                                       ev[3].elapsed_time(ev[4]) + ev[7].elapsed_time(ev[8]) + ev[5].elapsed_time(ev[6]), t_d,
+                                       ev[0].elapsed_time(ev[9]), ev[10].elapsed_time(ev[1])])
             self.d_ms.append(t_d)
         self.last_gamma = gamma
         return gamma
 
+    def time_dual(self, reps=3):
+        """Stage D with the randomised control of estimate_transition_prob (analysis.py:1539-1542): one dual-control launch
+        against one single launch, same inputs.  The control matrix here is a stand-in with the right shape and statistics
+        (rows of a materialised dmat shuffled over cells with random signs); its values do not change the cost."""
+        ops = self.ops
+        gamma = self.last_gamma
+        dm = ops.velocity_chain(self.Sx_loc, self.Ux_loc, gamma, None, want=("dmat",), transform=ops.SQRT, psc=1e-10)["dmat"]
+        gen = torch.Generator(device=self.dev).manual_seed(7)
+        prm = torch.randperm(dm.C, generator=gen, device=self.dev)
+        sgn = (torch.randint(0, 2, (1, dm.ld), generator=gen, device=self.dev) * 2 - 1).to(self.dtype)
+        d_r = ops.CellMatrix((dm.t.index_select(0, prm) * sgn).contiguous(), dm.G)
+        del dm
+        out_r = torch.empty_like(self.corr_loc)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        def run(dual):
+            best = 1e30
+            for _ in range(reps):
+                e0.record()
+                if dual:
+                    ops.coldeltacor_partial_fused_dual(self.e_rows, self.Ux_loc, gamma, None, d_r, self.neigh_k, ops.SQRT, ops.RULES_PARTIAL, 1e-10,
+                                                       cell0=self.e_cell0, u_row0=self.e_cell0, order=self.order, out=self.corr_loc, out_rndm=out_r, validate=False)
+                else:
+                    ops.coldeltacor_partial_fused(self.e_rows, self.Ux_loc, gamma, None, self.neigh_k, ops.SQRT, ops.RULES_PARTIAL, 1e-10,
+                                                  cell0=self.e_cell0, u_row0=self.e_cell0, order=self.order, out=self.corr_loc, validate=False)
+                e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1))
+            return best
+        single, dual = run(False), run(True)
+        return {"D_single_ms": single, "D_dual_ms": dual, "dual_over_single": dual / single,
+                "note": "estimate_transition_prob(calculate_randomized=True): real + randomised-control correlations from one "
+                        "vcy_coldeltacor_partial_fused_dual launch; two launches would cost 2.0 x"}
+
 
 def cpu_baseline(pipe, args):
-    """Reference kernels (oracle/_ref: velocyto/speedboosted.pyx built with its own flags) for stage D and the
-    oracle port for A-C, on a closed sub-problem of `cpu_cells` cells (all genes, same k / nrndm)."""
+    """The oracle restatement (oracle/velocyto_oracle.c with OpenMP + oracle/oracle.py; pinned against the reference's own
+    outputs in tests/test_oracle_golden.py) for all four stages on a closed sub-problem of `cpu_cells` cells (all genes, same
+    k / nrndm).  Nothing built from the reference runs on the GPU box."""
     import oracle
     Cs = min(args.cpu_cells, args.cells)
     G = args.genes
@@ -300,36 +373,29 @@ def cpu_baseline(pipe, args):
     _, _, dS, _ = oracle.velocity_chain(Sx, Ux, gam, None)
     dmat = oracle.delta_transform(Sx, Sx + dS, "sqrt", 1e-10)
     tC = time.perf_counter() - t0
-    kind = "port"
-    ref_so = [f for f in os.listdir(os.path.join(ROOT, "oracle", "_ref"))] if os.path.isdir(os.path.join(ROOT, "oracle", "_ref")) else []
     t0 = time.perf_counter()
-    if any(f.startswith("speedboosted") and f.endswith(".so") for f in ref_so):
-        import importlib.machinery
-        import importlib.util
-        so = os.path.join(ROOT, "oracle", "_ref", [f for f in ref_so if f.endswith(".so")][0])
-        loader = importlib.machinery.ExtensionFileLoader("speedboosted", so)
-        mod = importlib.util.module_from_spec(importlib.util.spec_from_loader("speedboosted", loader))
-        loader.exec_module(mod)
-        out = np.zeros((Cs, Cs))
-        mod._colDeltaCorSqrtpartial(np.ascontiguousarray(Sx), np.ascontiguousarray(dmat), out, ixs, cores, 1e-10)
-        kind = "reference"
-    else:
-        oracle.coldeltacor_partial_compact(Sx, dmat, ixs, "sqrt", 1e-10, threads=cores)
+    oracle.coldeltacor_partial_compact(Sx, dmat, ixs, "sqrt", 1e-10, threads=cores)
     tD = time.perf_counter() - t0
     total = tA + tB + tC + tD
-    return {"value": Cs / total, "unit": "cells/s", "cores": cores, "kind": kind,
-            "sample": f"closed sub-problem of {Cs} cells x {G} genes, k={min(args.k, Cs - 1)}, nrndm={nr}: stage D by the "
-                      f"reference's own compiled kernel ({tD:.2f} s), stages A-C by the oracle port ({tA:.2f}+{tB:.2f}+{tC:.2f} s); "
-                      "per-cell cost of D is size-independent, the O(C^2) kNN is cheaper at this size (favours the CPU)",
+    return {"value": Cs / total, "unit": "cells/s", "cores": cores, "kind": "port",
+            "sample": f"closed sub-problem of {Cs} cells x {G} genes, k={min(args.k, Cs - 1)}, nrndm={nr}, all four stages by the oracle "
+                      f"restatement (C + OpenMP on {cores} threads for pooling and stage D, NumPy/SciPy for the rest): A {tA:.2f} s, B {tB:.2f} s, "
+                      f"C {tC:.2f} s, D {tD:.2f} s; the per-cell cost of D does not depend on the number of cells, the O(C^2) kNN is cheaper at this "
+                      "size (favours the CPU)",
             "stage_s": {"A": tA, "B": tB, "C": tC, "D": tD}}
 
 
-def main():
-    a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+def load_counters():
+    """Per-launch counters of the dominant kernel from the rocprofv3 --pmc passes committed under profiles/ (file named in
+    the bench line).  Returns {} when the file is missing."""
+    try:
+        with open(COUNTERS_FILE) as f:
+            return json.load(f)
+    except Exception:
+        return {}
+
+
+def run(a, rank, local_rank, world):
     if os.environ.get("VCY_SINGLE_DEVICE", "0") == "1":     # multi-process test on a one-GPU box: every rank on device 0, gloo
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -337,18 +403,24 @@ def main():
     if world > 1 or os.environ.get("VCY_FORCE_COLLECTIVES", "0") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         backend = os.environ.get("VCY_DIST_BACKEND", "nccl")   # "nccl" = RCCL over xGMI; "gloo" only for the one-GPU logic test
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     import velocyto_amd  # noqa: F401
     from velocyto_amd import _lib
     _lib.lib()   # fail loudly if the HIP library is missing
+    if a.workload == "cfg5":
+        from velocyto_amd import atlas
+        res = atlas.bench_main(a, dev, rank, world)
+        finish(res, rank)
+        return
 
-    pipe = Pipeline(a, dev, rank, world)
+    dtype = torch.float64 if a.dtype == "f64" else torch.float32
+    pipe = Pipeline(a, dev, rank, world, dtype=dtype, counts=a.counts)
     for _ in range(a.warmup):
         pipe.step()
 
@@ -369,25 +441,65 @@ def main():
     ms_per_step = dt / a.steps * 1e3
 
     if rank == 0 and a.dump:
-        # in a sharded run the cells were relabelled (Morton order of the embedding): report in the original labels
+        # in a sharded run the cells were relabelled (curve order of the embedding): report in the original labels
         perm = getattr(pipe, "perm", None)
         corr, neigh = pipe.corr, pipe.neigh
         np.savez(a.dump, gamma=pipe.last_gamma.cpu().numpy(), corr=corr.cpu().numpy(), neigh=neigh.cpu().numpy(),
                  perm=(perm.cpu().numpy() if perm is not None else np.arange(a.cells)))
+    res = None
     if rank == 0:
         C, G, nr = a.cells, a.genes, pipe.nrndm
         nloc = pipe.c1 - pipe.c0
+        s = 8 if a.dtype == "f64" else 4
         d_ms = float(np.mean(pipe.d_ms))
-        alg_bytes = nloc * ((nr + 2) * G * 4 + nr * (4 + 4))          # (nrndm+2)*G*s + nrndm*(idx+out) per cell
-        achieved = alg_bytes / (d_ms * 1e-3)
         stage = pipe.stage_ms / a.steps
-        default_wl = (C, G, nr, a.k, world, a.order, a.fuse, a.curve) == (50000, 30000, 250, 30, 1, "embedding", True, "hilbert")
-        traffic = a.traffic_bytes if a.traffic_bytes is not None else (PMC_TRAFFIC_DEFAULT if default_wl else None)
+        # ---- dominant kernel.  Work of one launch: pair-genes, and pair-chunks of 1536 (f32) / 768 (f64) genes
+        pair_genes = float(nloc) * nr * G
+        chunk = 6 * 64 * (16 // s)
+        pair_chunks = float(nloc) * nr * ((G + chunk - 1) // chunk)
+        alg_bytes = nloc * ((nr + 2) * G * s + nr * (4 + s))            # (nrndm+2)*G*s + nrndm*(idx+out) per cell, no reuse credited
+        cnt = load_counters() if a.dtype == "f32" else {}
+        instr = cnt.get("valu_insts_per_pair_chunk", None)
+        default_wl = (C, G, nr, a.k, world, a.order, a.fuse, a.curve, a.dtype, a.counts) == (50000, 30000, 250, 30, 1, "embedding", True, "hilbert", "f32", "auto")
+        traffic = a.traffic_bytes if a.traffic_bytes is not None else (cnt.get("hbm_bytes_per_launch") if default_wl else None)
+        roof = {"bound": "valu", "kernel": f"k_cdc_partial_grouped<{'float' if s == 4 else 'double'}, SQRT, PARTIAL, 8 cells, 6 vectors> (velocity chain folded in)",
+                "unit": "Ginstr/s", "peak": VALU_ISSUE_PEAK / 1e9, "avg_launch_ms": d_ms,
+                "peak_is": "VALU issue: 1024 SIMD-32 x 2.4 GHz / 2 clocks per wave64 instruction (MI355X_MICROARCH.md); f32 plain ops measure 2.25 clocks"}
+        if instr is not None:
+            achieved = instr * pair_chunks / (d_ms * 1e-3)
+            roof.update({"achieved": achieved / 1e9, "frac": achieved / VALU_ISSUE_PEAK,
+                         "valu_insts_per_launch": instr * pair_chunks, "counters_from": os.path.relpath(COUNTERS_FILE, ROOT)})
+            mix_floor_ms = pair_genes * MIX_CLK_PER_ELEMENT / 64.0 / (1024 * 2.4e9) * 1e3
+            roof.update({"mix_floor_ms": mix_floor_ms, "frac_of_mix_floor": mix_floor_ms / d_ms})
+        else:
+            roof.update({"achieved": None, "frac": None, "counters_from": None})
+        roof.update({"traffic": traffic, "hbm_frac_measured": (traffic / (d_ms * 1e-3) / HBM_PEAK) if traffic else None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "vs_noreuse_model": alg_bytes / (d_ms * 1e-3) / HBM_PEAK,
+                     "note": "VALU-issue-bound: `achieved` = SQ_INSTS_VALU of this kernel (rocprofv3 pass in counters_from, per pair-chunk, scaled "
+                             "by this run's exact pair-chunk count) / HIP-event launch time; `frac` is against the issue peak of one plain "
+                             "instruction per 2 clocks per SIMD.  The mix the arithmetic needs is slower than that (v_sqrt_f32 8 clocks, packed "
+                             "ops / v_bfi / SGPR-operand VOP3 4): `mix_floor_ms` is the issue time of that mix alone at the measured rates "
+                             "(tools/ubench/valu_issue.hip), `frac_of_mix_floor` = mix_floor_ms / launch time.  HBM is not the limit: "
+                             "`traffic` (2*FETCH_SIZE + WRITE_SIZE of the PMC passes) is `hbm_frac_measured` of 8 TB/s; `vs_noreuse_model` "
+                             "is SURVEY 8(d)'s no-reuse byte model over launch time over 8 TB/s (above 1: neighbour rows are shared by the "
+                             "8 cells of a group out of LDS and by adjacent groups out of L2)."})
+        cbytes = 1 if pipe.cS.t.dtype == torch.uint8 else 2
+        pool_bytes = nloc * 2 * (G * cbytes + G * s)
+        stages = {
+            "A_knn_search": {"ms": stage[5], "bound": "valu", "note": f"exact kNN of {nloc} queries among {C} points in {a.pca_dims} dims; "
+                             f"{2.0 * nloc * C * a.pca_dims / (stage[5] * 1e-3) / 1e12:.2f} Tflop/s of distance FMAs (f32 vector peak 157)"},
+            "A_pooling": {"ms": stage[6], "bound": "hbm", "algorithmic_bytes": pool_bytes, "achieved_GBs": pool_bytes / (stage[6] * 1e-3) / 1e9,
+                          "frac": pool_bytes / (stage[6] * 1e-3) / HBM_PEAK,
+                          "note": f"both layers: counts ({cbytes} B) read once + pooled matrix ({s} B) written once per cell and gene"},
+            "B_fit_slope": {"ms": stage[1], "bound": "hbm", "algorithmic_bytes": nloc * 2 * G * s, "achieved_GBs": nloc * 2 * G * s / (stage[1] * 1e-3) / 1e9,
+                            "frac": nloc * 2 * G * s / (stage[1] * 1e-3) / HBM_PEAK},
+        }
         res = {
             "metric": "cells/sec through knn_imputation->fit_slope->colDeltaCor, 50k cells x 30k genes",
             "value": C / (ms_per_step * 1e-3), "unit": "cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": a.dtype, "data": "synthetic",
+            "rccl_ranks": dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0,
             "config": {"workload": f"synthetic {C} cells x {G} genes (BASELINE.json configs[2]): knn_imputation(k={a.k}, "
                                    f"{a.pca_dims} PCs) -> fit_slope -> velocity chain -> colDeltaCorSqrtpartial(nrndm={nr}, "
                                    f"n_neighbors={a.n_neighbors}, sampled_fraction={a.sampled_fraction}, psc=1e-10)",
@@ -395,26 +507,66 @@ def main():
                        "inputs": f"spliced/unspliced count layers ({'uint8, no count above 255' if pipe.cS.t.dtype == torch.uint8 else 'uint16'}) + per-cell size factors "
                                  "(S_sz = factor*counts), pcs, sampled neighbours",
                        "parallelism": "single GPU" if world == 1 else f"cells sharded over {world} GPUs in embedding ({a.curve} curve) order; RCCL "
-                                      "all-reduce of fit moments, " + (f"halo exchange of Sx rows (all_to_all, {pipe.plan.n_recv} of {C} rows "
-                                      "received by rank 0" + (f"; overlapped with stage D of the {int(pipe.sched[0].numel())} interior cells of {nloc})"
+                                      "all-reduce of fit moments, " + (f"halo exchange of Sx rows into a compact own+halo buffer (all_to_all, {pipe.plan.n_recv} "
+                                      f"of {C} rows received by rank 0" + (f"; overlapped with stage D of the {int(pipe.sched[0].numel())} interior cells of {nloc})"
                                                               if pipe.sched is not None else ")") if pipe.plan is not None else "all-gather of Sx shards") +
                                       ", all-gather of correlation rows",
                        "stage_ms": {"A_knn_imputation": stage[0], "B_fit_slope": stage[1], "C_velocity_chain": stage[2],
                                     "D_exchange": stage[3], "D_coldeltacor": stage[4]},
                        "velocity_chain": "folded into the staging of d[c] in the stage-D kernel" if a.fuse else "k_velocity_chain (dmat materialised)",
                        "cell_order_D": a.order + (f" ({a.curve} curve)" if a.order == "embedding" else "")},
-            "roofline": {"bound": "hbm", "kernel": "k_cdc_partial_grouped<float, SQRT, PARTIAL, 8>", "achieved": achieved / 1e9,
-                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": d_ms,
-                         "note": "achieved = ALGORITHMIC bytes (no reuse credited: (nrndm+2)*G*4 + nrndm*8 per cell) / HIP-event "
-                                 "launch time. The grouped kernel reads a neighbour row once per 8-cell group (3.5x reuse out of "
-                                 "LDS) and adjacent groups share rows in the per-XCD L2, so frac > 1 means it beats the no-reuse HBM "
-                                 "roofline; `traffic` is the PMC-measured L2-miss traffic of the same launch (profiles/r01k_*). The "
-                                 "kernel is VALU-bound: 9.0 VALU instr per pair-gene (v_sqrt_f32 takes two issue slots), VALU pipes "
-                                 "95 % busy (4 x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)."},
+            "roofline": roof, "stages": stages,
         }
+        if world == 1 and not a.no_extra and a.dtype == "f32" and a.counts == "auto":
+            res["extra"] = extra_lines(a, dev, pipe)
         if not a.no_cpu_baseline and world == 1:     # reported on rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(pipe, a)
+    finish(res, rank)
+
+
+def extra_lines(a, dev, pipe):
+    """Same workload, one GPU: (1) stage D with the randomised control, (2) uint16 count layers, (3) the reference's own
+    arithmetic (f64 storage and accumulation) incl. the largest f32-vs-f64 difference over ALL correlations and gammas."""
+    out = {"randomised_control": pipe.time_dual()}
+    data = (pipe.cS, pipe.cU, pipe.fS, pipe.fU, pipe.pcs)
+    corr32, gamma32 = pipe.corr_loc.clone(), pipe.last_gamma.clone()
+    pipe.step()                                       # (time_dual overwrote corr_loc with the same values; keep it simple)
+    corr32 = pipe.corr_loc.clone()
+
+    def short(p, steps):
+        p.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            p.step(timed=True)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+    if pipe.cS.t.dtype == torch.uint8:
+        p16 = Pipeline(a, dev, 0, 1, dtype=torch.float32, data=data, counts="u16")
+        ms = short(p16, 2)
+        st = p16.stage_ms / 2
+        out["uint16_layers"] = {"ms_per_step": ms, "cells_per_s": a.cells / (ms * 1e-3), "A_pooling_ms": st[6],
+                                "note": "the loom's on-disk type (constants.py:11); taken when any count of a layer exceeds 255",
+                                "same_results_as_uint8": bool(torch.equal(p16.corr_loc, corr32))}
+        del p16
+    pipe.Sx_loc = pipe.e_rows = pipe.Ux_loc = None     # make room: the f64 pipeline holds 2 x 12 GB at 50k x 30k
+    torch.cuda.empty_cache()
+    p64 = Pipeline(a, dev, 0, 1, dtype=torch.float64, data=data)
+    ms = short(p64, 1)
+    st = p64.stage_ms
+    ok = torch.isfinite(p64.corr_loc) & torch.isfinite(corr32)
+    dcorr = float((p64.corr_loc[ok] - corr32[ok].double()).abs().max())
+    g64, g32 = p64.last_gamma.double(), gamma32.double()
+    dgam = float(((g64 - g32).abs() / g64.abs().clamp(min=1e-30))[g64 > 0].max())
+    out["f64"] = {"dtype": "f64", "ms_per_step": ms, "cells_per_s": a.cells / (ms * 1e-3),
+                  "stage_ms": {"A_knn_imputation": st[0], "B_fit_slope": st[1], "D_coldeltacor": st[4]},
+                  "f32_vs_f64": {"max_abs_dcorr_all_pairs": dcorr, "pairs_compared": int(ok.sum()), "nan_pattern_equal": bool(torch.equal(torch.isnan(p64.corr_loc), torch.isnan(corr32))),
+                                 "max_rel_dgamma": dgam},
+                  "note": "the reference's arithmetic (speedboosted.pyx:13-538 is fp64 throughout): f64 storage of Sx/Ux, f64 moments, same kernels"}
+    return out
+
+
+def finish(res, rank):
     def flush_c_stdio():                             # RCCL writes its banner through C stdio, which is block-buffered on a pipe:
         sys.stdout.flush()                           # push it out now, so that nothing can land after the JSON line at exit
         try:
@@ -429,6 +581,26 @@ def main():
     if rank == 0:                                    # the ONE JSON line, last thing on stdout
         flush_c_stdio()
         print(json.dumps(res), flush=True)
+
+
+def _spawned(local_rank, a):
+    os.environ.update({"RANK": str(local_rank), "LOCAL_RANK": str(local_rank), "WORLD_SIZE": str(a.gpus)})
+    run(a, local_rank, local_rank, a.gpus)
+
+
+def main():
+    a = parse()
+    if "WORLD_SIZE" in os.environ:                   # launched by torch.distributed.run (the driver's way)
+        world, rank, local_rank = int(os.environ["WORLD_SIZE"]), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+        assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+        run(a, rank, local_rank, world)
+    elif a.gpus > 1:                                 # self-launch: one process per GPU
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        import torch.multiprocessing as mp
+        mp.spawn(_spawned, args=(a,), nprocs=a.gpus, join=True)
+    else:
+        run(a, 0, 0, 1)
 
 
 if __name__ == "__main__":

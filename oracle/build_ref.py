@@ -9,9 +9,11 @@ and compiles it with the reference's own flags.  The resulting extension module
 
     oracle/_ref/speedboosted.cpython-310-x86_64-linux-gnu.so
 
-travels to the GPU box with the snapshot (it is NOT in .gpurunignore) and is used
-  * to validate the C restatement in oracle/velocyto_oracle.c (tests/golden/make_golden.py),
-  * as the ``cpu_baseline.kind == "reference"`` leg of bench.py.
+stays in the build container (oracle/_ref/ is listed in .gitignore AND .gpurunignore: nothing built from the
+reference travels to the GPU box) and is used only
+  * to validate the C restatement in oracle/velocyto_oracle.c and to generate tests/golden/*.npz
+    (tests/golden/make_golden.py).
+bench.py's ``cpu_baseline`` times the pinned restatement (libvelocyto_oracle.so, kind "port"), not this module.
 
 Runs only where /root/reference exists (this container).  Needs Cython (3.2.9 here),
 gcc and numpy headers - all present in the image; nothing is stubbed.

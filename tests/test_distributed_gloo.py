@@ -68,6 +68,21 @@ def _worker(rank, world, port, C, G, nr, q):
         assert np.array_equal(full2.numpy()[need.numpy()], 2.0 * Sx.T[need.numpy()])
         corr_h = oracle.coldeltacor_partial_compact(np.nan_to_num(full2.numpy().T / 2.0), dmat, ixs, "sqrt", 1e-10, c0=c0, c1=c1)[c0:c1]
         assert np.array_equal(np.nan_to_num(corr_h, nan=9.0), np.nan_to_num(corr_loc, nan=9.0))
+        # SHARDED e: own rows + halo rows in a compact buffer, neighbour lists renumbered (no full-height copy of e anywhere)
+        n_loc = c1 - c0
+        compact = torch.full((n_loc + plan.n_recv, G), float("nan"), dtype=torch.float64)
+        compact[:n_loc] = Sx_loc
+        h = plan.begin(Sx_loc, recv_out=compact[n_loc:])
+        plan.end(h, compact, row0=n_loc)
+        loc = plan.localize(torch.as_tensor(ixs[c0:c1]))
+        assert int(loc.min()) >= 0 and int(loc.max()) < compact.shape[0] and not bool(torch.isnan(compact).any())
+        assert torch.equal(compact[loc.long()], torch.as_tensor(Sx.T)[torch.as_tensor(ixs[c0:c1])]), "renumbered lists must address the same rows"
+        # stage D on the compact buffer: cells 0..n_loc-1 of a (n_loc + n_halo)-cell problem, d holds the own rows only
+        d_pad = np.zeros((G, compact.shape[0]))
+        d_pad[:, :n_loc] = dmat[:, c0:c1]
+        corr_c = oracle.coldeltacor_partial_compact(compact.numpy().T.copy(), d_pad, np.vstack([loc.numpy(), np.zeros((plan.n_recv, nr), dtype=np.int32)]),
+                                                    "sqrt", 1e-10, c0=0, c1=n_loc)[:n_loc]
+        assert np.array_equal(np.nan_to_num(corr_c, nan=9.0), np.nan_to_num(corr_loc, nan=9.0)), "sharded e changed the correlations"
         if rank == 0:
             q.put((gamma, corr.numpy(), Sx_full))
     finally:

@@ -1,9 +1,13 @@
 """The cell-sharded pipeline of bench.py with MORE THAN ONE RANK on a one-GPU box: every rank runs on cuda:0 and the
 collectives go through gloo (host-staged; `VCY_SINGLE_DEVICE=1 VCY_DIST_BACKEND=gloo`), so that everything except the
 RCCL transport itself is the code the 2/4/8-GPU runs execute: Morton relabelling, shard bounds, kNN queries of a shard
-against all cells, pooling of a shard, all-reduce of the fit moments, halo plan / all-gather of Sx rows, stage D with
-cell0 / u_row0 offsets on a full-height buffer - split into the interior cells (run while the halo moves) and the cells
-with remote neighbours -, all-gather of the correlation rows.
+against all cells, pooling of a shard, all-reduce of the fit moments, halo plan with SHARDED e (a compact own + halo
+buffer and renumbered neighbour lists; `--exchange allgather` keeps the full-height buffer with cell0 / u_row0 offsets),
+stage D split into the interior cells (run while the halo moves) and the cells with remote neighbours, all-gather of the
+correlation rows.
+
+`test_rccl_collectives_on_one_gpu` runs the same code on the REAL transport: backend "nccl" (= RCCL) at world size 1 with
+the collectives forced, launched through bench.py's own self-launcher, and must reproduce the plain one-rank run.
 
 The sharded results must equal the one-rank run of the same (relabelled) problem: neighbour samples and labels
 identical, gamma to fp64-summation-order tolerance, correlations to 2e-6.
@@ -22,8 +26,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ARGS = ["--no-cpu-baseline", "--cells", "4100", "--genes", "1536", "--n-neighbors", "100", "--k", "12", "--steps", "1", "--warmup", "1"]
 
 
-def run(world, dump, extra=(), port=29611):
-    env = dict(os.environ, VCY_SINGLE_DEVICE="1", VCY_DIST_BACKEND="gloo", VCY_FORCE_COLLECTIVES="1", MASTER_PORT=str(port))
+def run(world, dump, extra=(), port=29611, backend="gloo", force="1"):
+    env = dict(os.environ, VCY_SINGLE_DEVICE="1", VCY_DIST_BACKEND=backend, VCY_FORCE_COLLECTIVES=force, MASTER_PORT=str(port),
+               MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
     if world == 1:
         cmd = [sys.executable, "bench.py", "--gpus", "1", *ARGS, "--dump", dump, *extra]
     else:
@@ -33,18 +40,37 @@ def run(world, dump, extra=(), port=29611):
     assert r.returncode == 0, r.stderr[-3000:]
     last = [l for l in r.stdout.strip().splitlines() if l.strip()][-1]
     assert last.startswith("{") and '"n_gpus": %d' % world in last, last[:200]      # the JSON line is the last thing on stdout
-    return dict(np.load(dump))
+    return dict(np.load(dump)), last
 
 
 @pytest.mark.parametrize("world,extra", [(2, ()), (3, ("--exchange", "allgather")), (3, ()), (2, ("--no-overlap",)), (2, ("--no-fuse",))])
 def test_sharded_pipeline_equals_one_rank(tmp_path, world, extra):
     from velocyto_amd import ops
     ops.require_gpu()
-    one = run(1, str(tmp_path / "one.npz"), extra, port=29611 + world)
-    many = run(world, str(tmp_path / "many.npz"), extra, port=29631 + world + len(extra))
+    one, _ = run(1, str(tmp_path / "one.npz"), extra, port=29611 + world)
+    many, _ = run(world, str(tmp_path / "many.npz"), extra, port=29631 + world + len(extra))
     assert np.array_equal(one["perm"], many["perm"]) and np.array_equal(one["neigh"], many["neigh"])
     np.testing.assert_allclose(many["gamma"], one["gamma"], rtol=2e-6, atol=1e-9)
     fin = np.isfinite(one["corr"])
     assert np.array_equal(np.isfinite(many["corr"]), fin)
     np.testing.assert_allclose(many["corr"][fin], one["corr"][fin], atol=2e-6)
     assert one["corr"].shape == (4100, 50) and fin.mean() > 0.99
+
+
+def test_rccl_collectives_on_one_gpu(tmp_path):
+    """init_process_group("nccl"), all_reduce, all_gather_into_tensor, all_to_all_single (halo) and barrier on RCCL - the
+    transport the multi-GPU runs use - at world size 1 with the collectives forced, against the same relabelled problem
+    run over gloo (which the tests above tie to the 2- and 3-rank runs)."""
+    import json
+    from velocyto_amd import ops
+    ops.require_gpu()
+    ref, line0 = run(1, str(tmp_path / "gloo.npz"), port=29701)
+    rccl, line1 = run(1, str(tmp_path / "rccl.npz"), port=29702, backend="nccl")
+    agat, line2 = run(1, str(tmp_path / "agat.npz"), ("--exchange", "allgather"), port=29703, backend="nccl")
+    assert json.loads(line0)["rccl_ranks"] == 0 and json.loads(line1)["rccl_ranks"] == 1 and json.loads(line2)["rccl_ranks"] == 1
+    for got in (rccl, agat):
+        assert np.array_equal(got["perm"], ref["perm"]) and np.array_equal(got["neigh"], ref["neigh"])
+        np.testing.assert_array_equal(got["gamma"], ref["gamma"])
+        fin = np.isfinite(ref["corr"])
+        assert np.array_equal(np.isfinite(got["corr"]), fin)
+        np.testing.assert_array_equal(got["corr"][fin], ref["corr"][fin])

@@ -517,11 +517,16 @@ class VelocytoLoom(PreprocessMixin):
             self._neigh = neigh
             sched = ops.hilbert_order(embedding) if embedding.shape[1] >= 2 else None      # scheduling only: same numbers in any order
             self.__dict__["_embed_order"] = sched
-            self._corr = ops.coldeltacor_partial(e, dmat, neigh, kern, ops.RULES_PARTIAL, psc, validate=False, order=sched)
+            if calculate_randomized:
+                # the reference's two colDeltaCor*partial calls (:1578-1601) share e and the neighbour lists, hence every
+                # A = f(e_i - e_c): one dual-control pass instead of two launches (vcy_coldeltacor_partial_dual)
+                self._corr, self._corr_random = ops.coldeltacor_partial_dual(e, dmat, dmat_r, neigh, kern, ops.RULES_PARTIAL, psc,
+                                                                             validate=False, order=sched)
+            else:
+                self._corr = ops.coldeltacor_partial(e, dmat, neigh, kern, ops.RULES_PARTIAL, psc, validate=False, order=sched)
             if ops.corr_fixup(self._corr, neigh, zero_self=True, fix_nan=True, nan_to=1.0):                      # :1604-1607
                 logging.warning("Nans encountered in corrcoef and corrected to 1s. If not identical cells were present it is probably a small isolated cluster converging after imputation.")
             if calculate_randomized:
-                self._corr_random = ops.coldeltacor_partial(e, dmat_r, neigh, kern, ops.RULES_PARTIAL, psc, validate=False, order=sched)
                 if ops.corr_fixup(self._corr_random, neigh, zero_self=True, fix_nan=True, nan_to=1.0):
                     logging.warning("Nans encountered in corrcoef_random and corrected to 1s. If not identical cells were present it is probably a small isolated cluster converging after imputation.")
             else:

@@ -145,31 +145,57 @@ class HaloPlan:
         cat = lambda xs: torch.cat(xs) if xs else torch.empty(0, dtype=torch.int64, device=dev)
         self.send_idx, self.recv_idx = cat(send_idx), cat(recv_idx)
         self.n_send, self.n_recv = int(self.send_idx.numel()), int(self.recv_idx.numel())
-        self._send = self._recv = None
+        self._send = self._recv = self._cur = None
+
+    def localize(self, ixs: torch.Tensor) -> torch.Tensor:
+        """Global row numbers -> row numbers of the COMPACT buffer a rank keeps when `e` is sharded: its own rows first
+        (global c0..c1-1 -> 0..n_loc-1), then the received halo rows in the order they arrive (ascending global number ->
+        n_loc, n_loc+1, ...).  Every index must be an own row or a row named in this rank's `need` mask."""
+        n_loc = self.c1 - self.c0
+        g = ixs.long()
+        own = (g >= self.c0) & (g < self.c1)
+        pos = torch.searchsorted(self.recv_idx, g.reshape(-1)).reshape(g.shape) if self.n_recv else torch.zeros_like(g)
+        if self.n_recv:
+            hit = self.recv_idx[pos.clamp(max=self.n_recv - 1)] == g
+            assert bool((own | hit).all()), "localize: an index is neither an own row nor a halo row of this plan"
+        else:
+            assert bool(own.all()), "localize: an index is not an own row and the plan has no halo"
+        return torch.where(own, g - self.c0, n_loc + pos).to(torch.int32).contiguous()
 
     def exchange(self, local: torch.Tensor, out_full: torch.Tensor) -> torch.Tensor:
         """local: (c1-c0, ld) rows this rank owns; out_full: (n_total, ld).  Afterwards out_full holds the
-        rank's own rows and every remote row its mask asked for."""
+        rank's own rows and every remote row its mask asked for (full-height, replicated-size buffer)."""
         return self.end(self.begin(local, out_full), out_full)
 
-    def begin(self, local: torch.Tensor, out_full: torch.Tensor):
-        """First half of exchange(): own rows in place, rows to send packed, the all-to-all STARTED (RCCL: asynchronous on
-        its own stream, so kernels launched next - work that needs no remote row - overlap with the transfer).
-        Returns the handle end() takes."""
-        assert local.shape[0] == self.c1 - self.c0 and out_full.shape[0] == self.n and local.shape[1:] == out_full.shape[1:]
-        if local.data_ptr() != out_full[self.c0:self.c1].data_ptr():      # callers may keep their rows inside out_full already
-            out_full[self.c0:self.c1].copy_(local)
+    def begin(self, local: torch.Tensor, out_full: Optional[torch.Tensor] = None, recv_out: Optional[torch.Tensor] = None):
+        """First half of the exchange: rows to send packed, the all-to-all STARTED (RCCL: asynchronous on its own stream,
+        so kernels launched next - work that needs no remote row - overlap with the transfer).  With `out_full` the rank's
+        own rows are put in place in the full-height buffer; with `recv_out` (n_recv rows, e.g. the tail of the compact
+        own+halo buffer) the received rows land there directly.  Returns the handle end() takes."""
+        assert local.shape[0] == self.c1 - self.c0
+        if out_full is not None:
+            assert out_full.shape[0] == self.n and local.shape[1:] == out_full.shape[1:]
+            if local.data_ptr() != out_full[self.c0:self.c1].data_ptr():      # callers may keep their rows inside out_full already
+                out_full[self.c0:self.c1].copy_(local)
         if not active():
             return None                      # (forced collectives at world size 1 run the empty all-to-all: API smoke test)
         tail = tuple(local.shape[1:])
         if self._send is None or self._send.dtype != local.dtype or tuple(self._send.shape[1:]) != tail:
             self._send = torch.empty((self.n_send,) + tail, dtype=local.dtype, device=local.device)
-            self._recv = torch.empty((self.n_recv,) + tail, dtype=local.dtype, device=local.device)
+            self._recv = None
+        if recv_out is not None:
+            assert recv_out.shape[0] == self.n_recv and tuple(recv_out.shape[1:]) == tail and recv_out.is_contiguous()
+            recv = recv_out
+        else:
+            if self._recv is None or self._recv.dtype != local.dtype or tuple(self._recv.shape[1:]) != tail:
+                self._recv = torch.empty((self.n_recv,) + tail, dtype=local.dtype, device=local.device)
+            recv = self._recv
+        self._cur = recv
         torch.index_select(local, 0, self.send_idx, out=self._send)
         if _host_staged(local, self.group):
             # gloo (one-GPU logic tests): point-to-point exchange of host copies, completed here
             send_h = self._send.cpu()
-            recv_h = torch.empty(self._recv.shape, dtype=self._recv.dtype)
+            recv_h = torch.empty(recv.shape, dtype=recv.dtype)
             outs = list(recv_h.split(self.recv_splits)) if self.n_recv else [recv_h[:0] for _ in range(self.ws)]
             ins = list(send_h.split(self.send_splits)) if self.n_send else [send_h[:0] for _ in range(self.ws)]
             reqs = []
@@ -182,17 +208,22 @@ class HaloPlan:
                     reqs.append(dist.irecv(outs[peer], peer, group=self.group))
             for r in reqs:
                 r.wait()
-            self._recv.copy_(recv_h)
+            recv.copy_(recv_h)
             return "done"
-        return dist.all_to_all_single(self._recv, self._send, output_split_sizes=self.recv_splits, input_split_sizes=self.send_splits,
+        return dist.all_to_all_single(recv, self._send, output_split_sizes=self.recv_splits, input_split_sizes=self.send_splits,
                                       group=self.group, async_op=True)
 
-    def end(self, handle, out_full: torch.Tensor) -> torch.Tensor:
-        """Second half of exchange(): wait for the transfer (the current stream waits, not the host) and scatter the
-        received rows to their global positions."""
+    def end(self, handle, out: Optional[torch.Tensor] = None, row0: Optional[int] = None) -> Optional[torch.Tensor]:
+        """Second half of the exchange: wait for the transfer (the current stream waits, not the host).  row0 None: scatter
+        the received rows to their global positions in the full-height `out`; row0 given: the rows belong at out[row0:
+        row0 + n_recv] (compact own+halo buffer) - nothing to do when begin() received straight into that slice."""
         if handle is None:
-            return out_full
+            return out
         if handle != "done":
             handle.wait()
-        out_full.index_copy_(0, self.recv_idx, self._recv)
-        return out_full
+        recv = self._cur
+        if row0 is None:
+            out.index_copy_(0, self.recv_idx, recv)
+        elif out is not None and recv.data_ptr() != out[row0:row0 + self.n_recv].data_ptr():
+            out[row0:row0 + self.n_recv].copy_(recv)
+        return out
