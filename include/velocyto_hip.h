@@ -158,6 +158,20 @@ int vcy_knn_pool_counts(const void *countsS, const void *countsU, const double *
                         int64_t C, int64_t G, int64_t ld16, int64_t ld_out, int64_t cell0, int64_t C_out, int maximum,
                         int64_t slab_genes, int count_dtype, int dtype, vcy_stream stream);
 
+/* Atlas-scale pooling: the same product (neighbors.py:416-423 applied to S_sz = factor * S, analysis.py:546-549,
+ * 1011-1019) gathered from a SPARSE count layer in CSR form - indptr (C + 1) int64, indices (nnz) int32 gene numbers
+ * ascending inside a row, data (nnz) uint16 / uint8 counts (count_dtype) - for datasets whose layers do not fit dense
+ * (BASELINE.json configs[4]; the reference loads every layer dense, analysis.py:59-61).  out (C_out, ld_out) dense rows of
+ * `dtype`; g_indptr / g_indices / w: the kNN graph rows of the C_out output cells (entries name CSR rows);
+ * scale (C) per-row size factors; maximum: np.maximum with the cell's own scaled counts (row cell0 + c).  Results are
+ * bit-identical to vcy_knn_pool_counts on the densified layer.  slabptr: the table vcy_csr_slab_ptr fills,
+ * C x (ceil(G / vcy_csr_slab_genes()) + 1) int32 = offsets inside each row of the first non-zero of every gene slab.  */
+int64_t vcy_csr_slab_genes(void);
+int vcy_csr_slab_ptr(const int64_t *indptr, const int32_t *indices, int32_t *slabptr, int64_t C, int64_t G, vcy_stream stream);
+int vcy_knn_pool_csr(const int64_t *indptr, const int32_t *indices, const void *data, const int32_t *slabptr, const double *scale,
+                     void *out, const int64_t *g_indptr, const int32_t *g_indices, const void *w, const int32_t *order, int64_t C,
+                     int64_t G, int64_t ld_out, int64_t cell0, int64_t C_out, int maximum, int count_dtype, int dtype, vcy_stream stream);
+
 /* Exact Euclidean kNN in a low-dimensional space (what sklearn NearestNeighbors provides to
  * neighbors.knn_distance_matrix :363-376, BalancedKNN.fit/kneighbors :239-243,282 and
  * analysis.py:1547-1549).  xt: (P, ldx) TRANSPOSED coordinates (feature-major) of all C

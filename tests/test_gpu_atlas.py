@@ -1,0 +1,175 @@
+"""Atlas-scale form of the path (BASELINE.json configs[4]): CSR count layers, pooling from sparse rows, block-streamed
+stage D with sharded e.  Every kernel call goes through the C ABI on cuda:0.
+
+Bars: the CSR pooling is BIT-IDENTICAL to the dense pooling of the densified layer (same arithmetic in the same order);
+the streamed path in one block is bit-identical to the resident dense path, in several blocks equal up to the fp64
+summation order of the fit moments (correlations 2e-6); spot checks against the CPU oracle at the f32 tolerances of
+test_gpu_ops.py.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import velocyto_amd
+    from velocyto_amd import ops as _ops
+    _ops.require_gpu()
+    return _ops
+
+
+def _random_counts(rng, C, G, density, big=False):
+    a = rng.poisson(1.5, (C, G)) * (rng.random((C, G)) < density)
+    if big:
+        a[rng.integers(0, C, 5), rng.integers(0, G, 5)] = rng.integers(300, 60000, 5)      # forces uint16 storage
+    a[min(3, C - 1)] = 0                                                                    # an empty row
+    return a.astype(np.int64)
+
+
+def test_csr_counts_container(ops):
+    import scipy.sparse as sp
+    rng = np.random.default_rng(0)
+    for big in (False, True):
+        a = _random_counts(rng, 70, 4500, 0.08, big)
+        dense = ops.CountMatrix.from_genes_major(a.T.copy())
+        csr = ops.CsrCounts.from_dense(dense)
+        assert csr.C == 70 and csr.G == 4500 and csr.nnz == int((a != 0).sum())
+        assert (csr.data.dtype == torch.int16) == big
+        ref = sp.csr_matrix(a)
+        assert np.array_equal(csr.indptr.cpu().numpy(), ref.indptr) and np.array_equal(csr.indices.cpu().numpy(), ref.indices)
+        assert np.array_equal(csr.to_dense().as_int32().cpu().numpy(), a)
+        assert np.array_equal(csr.row_sums().cpu().numpy(), a.sum(1))
+        c2 = ops.CsrCounts.from_scipy(ref)
+        assert torch.equal(c2.indptr, csr.indptr) and torch.equal(c2.indices, csr.indices) and torch.equal(c2.data, csr.data)
+        sel = torch.tensor([5, 3, 69, 5, 0])
+        sub = csr.rows(sel)
+        assert np.array_equal(sub.to_dense().as_int32().cpu().numpy(), a[sel.numpy()])
+        # slab table: lower bounds of every 2048-gene boundary inside each row
+        sp_t = csr.slabptr.cpu().numpy()
+        for r in (0, 3, 17):
+            row = ref.indices[ref.indptr[r]:ref.indptr[r + 1]]
+            assert np.array_equal(sp_t[r], np.searchsorted(row, np.arange(sp_t.shape[1]) * 2048))
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("big", [False, True])
+@pytest.mark.parametrize("G", [700, 2048, 5001])
+def test_knn_pool_csr_bit_identical_to_dense(ops, dtype, big, G):
+    rng = np.random.default_rng(G + big)
+    C, k = 150, 9
+    a = _random_counts(rng, C, G, 0.1, big)
+    dense = ops.CountMatrix.from_genes_major(a.T.copy())
+    csr = ops.CsrCounts.from_dense(dense)
+    scale = torch.as_tensor(rng.gamma(4.0, 0.25, C))
+    # ragged graph: row lengths 0 .. k + 70 (one row longer than a wave), self first where present
+    lens = rng.integers(1, k + 2, C)
+    lens[7], lens[11] = 0, k + 70
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    indices = np.concatenate([rng.choice(C, n, replace=False) for n in lens]).astype(np.int32)
+    w = rng.random(indices.size)
+    for maximum in (False, True):
+        ref = ops.knn_pool_counts(dense, None, scale, None, indptr, indices, w, dtype=dtype, maximum=maximum)
+        got = ops.knn_pool_csr(csr, scale, indptr, indices, w, dtype=dtype, maximum=maximum)
+        assert torch.equal(got.t, ref.t), f"maximum={maximum}: CSR pooling differs from dense pooling"
+    # a block of output cells with a schedule, written into rows of a larger buffer
+    c0, n = 40, 64
+    ip = indptr[c0:c0 + n + 1] - indptr[c0]
+    ix, ww = indices[indptr[c0]:indptr[c0 + n]], w[indptr[c0]:indptr[c0 + n]]
+    buf = ops.CellMatrix.empty(n + 5, G, dtype)
+    buf.t.fill_(-1.0)
+    order = torch.as_tensor(rng.permutation(n).astype(np.int32))
+    ops.knn_pool_csr(csr, scale, ip, ix, ww, dtype=dtype, cell0=c0, C_out=n, out=buf, order=order, maximum=True)
+    assert torch.equal(buf.t[:n], ops.knn_pool_counts(dense, None, scale, None, indptr, indices, w, dtype=dtype, maximum=True).t[c0:c0 + n])
+    assert bool((buf.t[n:] == -1.0).all())
+    # and the product itself in fp64 (neighbors.py:416-423 on S_sz = scale * counts; the oracle's own entry point insists
+    # on rows of w summing to one, which this ragged graph - empty row included - does not)
+    import scipy.sparse as sp
+    W = sp.csr_matrix((w, indices, indptr), shape=(C, C))
+    ref_o = np.asarray(W.dot((a * scale.numpy()[:, None]).astype(np.float64))).T
+    got = ops.knn_pool_csr(csr, scale, indptr, indices, w, dtype=dtype).to_genes_major()
+    np.testing.assert_allclose(got, ref_o, rtol=2e-6 if dtype == "float32" else 1e-12, atol=1e-6 if dtype == "float32" else 1e-12)
+
+
+def _dense_reference(ops, atlas, cS, cU, fS, fU, pcs, emb, k, n_neighbors, frac):
+    """The resident dense path on the same data: knn_pool_counts -> fit_slope -> fused stage D with a full-height e."""
+    C = cS.C
+    idx, dist = ops.knn_search(pcs, k, include_self=False)
+    conn = (dist > 0).float()
+    w = torch.cat([torch.ones((C, 1), device=idx.device), conn], 1)
+    w = (w / w.sum(1, keepdim=True)).contiguous()
+    ind = torch.cat([torch.arange(C, device=idx.device, dtype=torch.int32)[:, None], idx], 1).contiguous()
+    ptr = torch.arange(0, (C + 1) * (k + 1), k + 1, device=idx.device, dtype=torch.int64)
+    Sx, Ux = ops.knn_pool_counts(cS.to_dense(), cU.to_dense(), fS, fU, ptr, ind, w, dtype=torch.float32, validate=False)
+    gamma = ops.fit_slope_from_moments(ops.fit_slope_moments(Ux, Sx))
+    neigh = atlas.sample_neighbors(emb.double(), 0, C, n_neighbors, frac)
+    corr = ops.coldeltacor_partial_fused(Sx, Ux, gamma, None, neigh, ops.SQRT, ops.RULES_PARTIAL, 1e-10, validate=False)
+    return Sx, Ux, gamma, neigh, corr
+
+
+def test_atlas_path_equals_resident_dense_path(ops):
+    from velocyto_amd import atlas
+    dev = ops.require_gpu()
+    C, G, k = 6000, 3000, 12
+    cS, cU, totS, totU, pcs, emb = atlas.synth_atlas(C, G, 12, dev, density=0.08)
+    assert 0.06 < cS.nnz / (C * G) < 0.10
+    fS, fU = atlas.size_factors(totS, totU, C)
+    Sx, Ux, gamma, neigh, corr = _dense_reference(ops, atlas, cS, cU, fS, fU, pcs, emb, k, 100, 0.5)
+    one = atlas.AtlasPath(cS, cU, fS, fU, pcs, emb, k=k, n_neighbors=100, sampled_fraction=0.5, block_cells=0)
+    c1 = one.run().clone()
+    assert torch.equal(one.neigh, neigh)
+    e_buf, Ux_b = one._resident
+    assert torch.equal(e_buf.t[:C], Sx.t) and torch.equal(Ux_b.t, Ux.t), "pooled matrices from CSR differ from the dense path"
+    assert torch.equal(one.gamma, gamma)
+    assert torch.equal(torch.nan_to_num(c1, nan=7.0), torch.nan_to_num(corr, nan=7.0)), "one-block streamed path must be bit-identical"
+    many = atlas.AtlasPath(cS, cU, fS, fU, pcs, emb, k=k, n_neighbors=100, sampled_fraction=0.5, block_cells=1400)
+    assert len(many.blocks()) == 5
+    c5 = many.run()
+    torch.testing.assert_close(many.gamma, gamma, rtol=2e-6, atol=1e-9)
+    fin = torch.isfinite(corr)
+    assert torch.equal(torch.isfinite(c5), fin)
+    assert float((c5[fin] - corr[fin]).abs().max()) <= 2e-6
+    assert many.peak_block_bytes < one.peak_block_bytes / 2        # the point of streaming: O(block) dense memory
+
+
+ARGS = ["--workload", "cfg5", "--no-cpu-baseline", "--cells", "9000", "--genes", "2100", "--n-neighbors", "100", "--k", "12", "--pca-dims", "10",
+        "--steps", "1", "--warmup", "0"]
+
+
+def _run_bench(world, dump, extra=(), port=29801):
+    env = dict(os.environ, VCY_SINGLE_DEVICE="1", VCY_DIST_BACKEND="gloo", VCY_FORCE_COLLECTIVES="1", MASTER_PORT=str(port), MASTER_ADDR="127.0.0.1")
+    for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(key, None)
+    if world == 1:
+        cmd = [sys.executable, "bench.py", "--gpus", "1", *ARGS, "--dump", dump, *extra]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), "bench.py", "--gpus", str(world), *ARGS, "--dump", dump, *extra]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    last = [l for l in r.stdout.strip().splitlines() if l.strip()][-1]
+    assert last.startswith("{") and '"n_gpus": %d' % world in last and '"e_sharded": true' in last, last[:300]
+    return dict(np.load(dump))
+
+
+@pytest.mark.parametrize("world,extra", [(2, ()), (3, ()), (2, ("--block-cells", "1000"))])
+def test_atlas_sharded_ranks_equal_one_rank(tmp_path, world, extra):
+    """2 and 3 ranks on one GPU (gloo transport): count-row halo exchange, pooling of the halo e rows, sharded stage D and the
+    all-gather of the correlation rows reproduce the one-rank run."""
+    from velocyto_amd import ops
+    ops.require_gpu()
+    one = _run_bench(1, str(tmp_path / "one.npz"), port=29801 + world)
+    many = _run_bench(world, str(tmp_path / "many.npz"), extra, port=29821 + world + len(extra))
+    assert np.array_equal(one["neigh"], many["neigh"])
+    np.testing.assert_allclose(many["gamma"], one["gamma"], rtol=2e-6, atol=1e-9)
+    fin = np.isfinite(one["corr"])
+    assert np.array_equal(np.isfinite(many["corr"]), fin)
+    np.testing.assert_allclose(many["corr"][fin], one["corr"][fin], atol=2e-6)

@@ -17,7 +17,7 @@ def build(force: bool = False) -> str:
 
 def __getattr__(name):  # lazy: importing the package must not need torch/GPU
     import importlib
-    if name in ("ops", "estimation", "neighbors", "diffusion", "analysis", "speedboosted", "distributed", "loom_io", "serialization", "preprocess"):
+    if name in ("ops", "estimation", "neighbors", "diffusion", "analysis", "speedboosted", "distributed", "loom_io", "serialization", "preprocess", "atlas"):
         return importlib.import_module(f"velocyto_amd.{name}")
     if name in _ROOT_NAMES:                       # the analysis-side names velocyto/__init__.py:12-15 re-exports at the package root
         return getattr(importlib.import_module(f"velocyto_amd.{_ROOT_NAMES[name]}"), name)

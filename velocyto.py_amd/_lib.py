@@ -43,6 +43,10 @@ SIGNATURES = {
     "vcy_knn_pool2": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_vp]),
     "vcy_knn_pool_counts": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                                     c_int, c_i64, c_int, c_int, c_vp]),
+    "vcy_csr_slab_genes": (c_i64, []),
+    "vcy_csr_slab_ptr": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "vcy_knn_pool_csr": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64,
+                                 c_int, c_int, c_int, c_vp]),
     "vcy_knn_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "vcy_knn_search": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_vp]),
     "vcy_knn_query": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp]),

@@ -64,6 +64,15 @@ __device__ __forceinline__ double lane63(double v)
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
+// value of lane `l` (wave-uniform lane number) broadcast to the whole wave
+__device__ __forceinline__ float readlane_t(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ double readlane_t(double v, int l)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
 template <typename T> __device__ __forceinline__ T wave_sum(T v)
 {
     v += dpp_val<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]

@@ -102,6 +102,36 @@ def all_gather_rows(local: torch.Tensor, n_total: int, out: Optional[torch.Tenso
     return out
 
 
+def all_to_all_uneven(send: torch.Tensor, send_splits: Sequence[int], recv_splits: Sequence[int], group=None) -> torch.Tensor:
+    """One all_to_all_single with uneven splits along dim 0 (RCCL); gloo (CPU tests, one-GPU logic tests) goes through
+    point-to-point transfers of host copies.  Returns the received rows, peers in rank order."""
+    rank, ws = world()
+    tail = tuple(send.shape[1:])
+    recv = torch.empty((int(sum(recv_splits)),) + tail, dtype=send.dtype, device=send.device)
+    if not active():
+        return recv
+    if dist.get_backend(group) != "gloo":
+        dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=list(recv_splits), input_split_sizes=list(send_splits), group=group)
+        return recv
+    send_h = send.cpu().contiguous()
+    recv_h = torch.empty(recv.shape, dtype=recv.dtype)
+    outs, ins = list(recv_h.split(list(recv_splits))), list(send_h.split(list(send_splits)))
+    reqs = []
+    for peer in range(ws):
+        if peer == rank:
+            if ins[peer].numel():
+                outs[peer].copy_(ins[peer])
+            continue
+        if ins[peer].numel():
+            reqs.append(dist.isend(ins[peer].contiguous(), peer, group=group))
+        if outs[peer].numel():
+            reqs.append(dist.irecv(outs[peer], peer, group=group))
+    for r in reqs:
+        r.wait()
+    recv.copy_(recv_h)
+    return recv
+
+
 class HaloPlan:
     """Exchange of exactly the remote rows a rank needs (built once per neighbour graph, reused every pass).
 
@@ -161,6 +191,39 @@ class HaloPlan:
         else:
             assert bool(own.all()), "localize: an index is not an own row and the plan has no halo"
         return torch.where(own, g - self.c0, n_loc + pos).to(torch.int32).contiguous()
+
+    def fetch(self, local: torch.Tensor) -> torch.Tensor:
+        """The halo rows of a small per-row tensor (graph rows, size factors, ...): (n_recv, ...) in arrival order =
+        ascending global row number, the order localize() assumes."""
+        local = local.contiguous()
+        recv = torch.empty((self.n_recv,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        h = self.begin(local, recv_out=recv)
+        self.end(h, recv, row0=0)
+        return recv
+
+    def fetch_ragged(self, lens: torch.Tensor, *flat: torch.Tensor):
+        """Halo rows of RAGGED per-row data (the CSR rows of a count layer): `lens` (n_loc) row lengths, every tensor of
+        `flat` the rows' elements back to back.  Returns (lens of the n_recv halo rows, their elements back to back for each
+        tensor of `flat`), rows in the order of fetch()."""
+        lens = lens.to(torch.int64).contiguous()
+        lens_halo = self.fetch(lens.reshape(-1, 1)).reshape(-1)
+        ptr = torch.zeros(lens.numel() + 1, dtype=torch.int64, device=lens.device)
+        torch.cumsum(lens, 0, out=ptr[1:])
+        send_lens = lens[self.send_idx]
+        # elements each peer gets / sends: row lengths summed over that peer's segment of the row lists
+        seg = lambda v, splits: [int(x.sum()) for x in v.split(list(splits))] if v.numel() else [0] * len(splits)
+        e_send, e_recv = seg(send_lens, self.send_splits), seg(lens_halo, self.recv_splits)
+        total = int(send_lens.sum()) if send_lens.numel() else 0
+        if total:
+            sp = torch.zeros(send_lens.numel() + 1, dtype=torch.int64, device=lens.device)
+            torch.cumsum(send_lens, 0, out=sp[1:])
+            r = torch.repeat_interleave(torch.arange(send_lens.numel(), device=lens.device), send_lens)
+            src = ptr[self.send_idx][r] + (torch.arange(total, device=lens.device) - sp[r])
+        outs = []
+        for f in flat:
+            packed = f[src] if total else f[:0]
+            outs.append(all_to_all_uneven(packed, e_send, e_recv, group=self.group))
+        return (lens_halo, *outs)
 
     def exchange(self, local: torch.Tensor, out_full: torch.Tensor) -> torch.Tensor:
         """local: (c1-c0, ld) rows this rank owns; out_full: (n_total, ld).  Afterwards out_full holds the

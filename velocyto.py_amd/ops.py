@@ -220,6 +220,149 @@ class CountMatrix:
         return out
 
 
+class CsrCounts:
+    """A (C cells, G genes) molecule-count layer on the device in CSR form, cells-major: ``indptr`` (C + 1) int64,
+    ``indices`` (nnz) int32 gene numbers ascending inside a row, ``data`` (nnz) counts as uint8 (no count above 255) or
+    uint16 bits in an int16 tensor.  The atlas-scale storage of a loom layer (BASELINE.json configs[4]: 1M cells x 30k genes
+    at ~8 % density is 2.4e9 non-zeros = 12-14 GB where the dense uint16 layer is 60 GB and the reference's float64 copy,
+    analysis.py:59-61, 240 GB).  ``slabptr`` is the per-row table of gene-slab boundaries the pooling kernel walks
+    (vcy_csr_slab_ptr), built on first use."""
+
+    __slots__ = ("indptr", "indices", "data", "G", "_slabptr")
+
+    def __init__(self, indptr: torch.Tensor, indices: torch.Tensor, data: torch.Tensor, G: int):
+        assert indptr.dtype == torch.int64 and indices.dtype == torch.int32 and data.dtype in (torch.uint8, torch.int16)
+        assert indptr.is_cuda and indices.is_cuda and data.is_cuda and indices.numel() == data.numel()
+        self.indptr, self.indices, self.data, self.G = indptr.contiguous(), indices.contiguous(), data.contiguous(), int(G)
+        self._slabptr = None
+
+    C = property(lambda self: int(self.indptr.numel()) - 1)
+    nnz = property(lambda self: int(self.indices.numel()))
+    code = property(lambda self: U8 if self.data.dtype == torch.uint8 else U16)
+    nbytes = property(lambda self: self.indptr.numel() * 8 + self.indices.numel() * 4 + self.data.numel() * self.data.element_size())
+
+    @property
+    def slabptr(self) -> torch.Tensor:
+        if self._slabptr is None:
+            L = _lib.lib()
+            nslab = (self.G + int(L.vcy_csr_slab_genes()) - 1) // int(L.vcy_csr_slab_genes())
+            sp = torch.empty((max(self.C, 1), nslab + 1), dtype=torch.int32, device=self.indptr.device)
+            if self.C:
+                _lib.check(L.vcy_csr_slab_ptr(self.indptr.data_ptr(), self.indices.data_ptr(), sp.data_ptr(), self.C, self.G, _stream()), "csr_slab_ptr")
+            self._slabptr = sp
+        return self._slabptr
+
+    @classmethod
+    def from_dense(cls, m: "CountMatrix", block: int = 8192) -> "CsrCounts":
+        """The non-zeros of a dense count matrix, row by row (block-wise: the index temporaries stay small)."""
+        dev = m.t.device
+        ptr, idx, dat = [torch.zeros(1, dtype=torch.int64, device=dev)], [], []
+        base = 0
+        for s0 in range(0, m.C, block):
+            blk = m.t[s0:s0 + block, : m.G]
+            nz = blk != 0
+            cnt = nz.sum(1)
+            ptr.append(base + torch.cumsum(cnt, 0))
+            base += int(cnt.sum())
+            rc = torch.nonzero(nz, as_tuple=False)                # row-major: rows ascending, genes ascending inside a row
+            idx.append(rc[:, 1].to(torch.int32))
+            dat.append(blk[nz])
+        cat = lambda xs, dt: torch.cat(xs) if xs else torch.empty(0, dtype=dt, device=dev)
+        return cls(torch.cat(ptr), cat(idx, torch.int32), cat(dat, m.t.dtype), m.G)
+
+    @classmethod
+    def from_scipy(cls, a, G: Optional[int] = None, narrow: bool = True) -> "CsrCounts":
+        """scipy.sparse matrix of shape (C, G) holding integer counts 0..65535 -> device CSR (sorted indices, explicit zeros dropped)."""
+        import scipy.sparse as sp
+        dev = require_gpu()
+        a = sp.csr_matrix(a)
+        a.sum_duplicates()
+        a.eliminate_zeros()
+        a.sort_indices()
+        vals = np.asarray(a.data)
+        if vals.size and (vals.min() < 0 or vals.max() > 65535 or not np.array_equal(vals, np.rint(vals))):
+            raise ValueError("CsrCounts holds integer counts in 0..65535")
+        if narrow and (vals.size == 0 or vals.max() <= 255):
+            dat = torch.from_numpy(vals.astype(np.uint8))
+        else:
+            dat = torch.from_numpy(vals.astype(np.uint16).view(np.int16))
+        return cls(torch.from_numpy(a.indptr.astype(np.int64)).to(dev), torch.from_numpy(a.indices.astype(np.int32)).to(dev), dat.to(dev),
+                   a.shape[1] if G is None else G)
+
+    def rows(self, sel: torch.Tensor) -> "CsrCounts":
+        """The CSR of the rows `sel` (int64 row numbers, any order, repeats allowed): the row gather behind cell blocks and
+        count-row halos."""
+        sel = sel.to(device=self.indptr.device, dtype=torch.int64)
+        start, stop = self.indptr[sel], self.indptr[sel + 1]
+        lens = stop - start
+        ptr = torch.zeros(sel.numel() + 1, dtype=torch.int64, device=sel.device)
+        torch.cumsum(lens, 0, out=ptr[1:])
+        total = int(ptr[-1]) if sel.numel() else 0
+        # position t of the output belongs to output row r = searchsorted(ptr, t, right) - 1 and source start[r] + (t - ptr[r])
+        t = torch.arange(total, dtype=torch.int64, device=sel.device)
+        r = torch.repeat_interleave(torch.arange(sel.numel(), device=sel.device), lens) if total else t
+        src = start[r] + (t - ptr[r]) if total else t
+        return CsrCounts(ptr, self.indices[src], self.data[src], self.G)
+
+    def to_dense(self, narrow: bool = False) -> "CountMatrix":
+        dev = self.indptr.device
+        dt = torch.uint8 if (self.data.dtype == torch.uint8) else torch.int16
+        out = torch.zeros((self.C, padded_ld(self.G)), dtype=dt, device=dev)
+        if self.nnz:
+            r = torch.repeat_interleave(torch.arange(self.C, device=dev), self.indptr[1:] - self.indptr[:-1])
+            out[r, self.indices.long()] = self.data
+        return CountMatrix(out, self.G)
+
+    def row_sums(self) -> torch.Tensor:
+        """Molecules per cell (S.sum(0) of the reference's (G, C) layout; analysis.py:540-546) as float64."""
+        vals = self.data.to(torch.int64) if self.data.dtype == torch.uint8 else (self.data.to(torch.int64) & 0xFFFF)
+        cs = torch.zeros(self.nnz + 1, dtype=torch.int64, device=self.indptr.device)
+        torch.cumsum(vals, 0, out=cs[1:])
+        return (cs[self.indptr[1:]] - cs[self.indptr[:-1]]).double()
+
+
+def knn_pool_csr(counts: CsrCounts, scale, indptr, indices, weights, dtype=None, maximum: bool = False, cell0: int = 0,
+                 C_out: Optional[int] = None, out: Optional[CellMatrix] = None, order: Optional[torch.Tensor] = None,
+                 validate: bool = True) -> CellMatrix:
+    """Pooled matrix gathered from a CSR count layer (vcy_knn_pool_csr): out[c,:] = sum_p w[p] * scale[idx[p]] * counts[idx[p],:],
+    bit-identical to knn_pool_counts on the densified layer."""
+    dev = counts.indptr.device
+    dt = resolve_dtype(dtype)
+    C_out = counts.C - cell0 if C_out is None else C_out
+    ip = (indptr if isinstance(indptr, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(indptr).astype(np.int64))).to(device=dev, dtype=torch.int64).contiguous()
+    ix = _as_i32(indices, dev)
+    w = (weights if isinstance(weights, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(weights))).to(device=dev, dtype=dt).contiguous()
+    sc = (torch.ones(counts.C, dtype=torch.float64, device=dev) if scale is None else
+          (scale if isinstance(scale, torch.Tensor) else torch.as_tensor(np.asarray(scale, dtype=np.float64))).to(device=dev, dtype=torch.float64).contiguous())
+    assert ip.numel() == C_out + 1 and ix.numel() == w.numel() and sc.numel() == counts.C
+    if validate and ix.numel() and (int(ix.min()) < 0 or int(ix.max()) >= counts.C):
+        raise ValueError("neighbour index out of range")
+    out = CellMatrix.empty(C_out, counts.G, dt) if out is None else out
+    assert out.C >= C_out and out.G == counts.G and out.dtype == dt
+    if order is not None:
+        order = order.to(device=dev, dtype=torch.int32).contiguous()
+        assert order.numel() == C_out
+    _lib.check(_lib.lib().vcy_knn_pool_csr(counts.indptr.data_ptr(), counts.indices.data_ptr(), counts.data.data_ptr(), counts.slabptr.data_ptr(),
+                                           sc.data_ptr(), out.t.data_ptr(), ip.data_ptr(), ix.data_ptr(), w.data_ptr(), _p(order), counts.C, counts.G,
+                                           out.ld, cell0, C_out, int(maximum), counts.code, out.code, _stream()), "knn_pool_csr")
+    return out
+
+
+def localize_rows(ixs: torch.Tensor, b0: int, b1: int, outside: torch.Tensor) -> torch.Tensor:
+    """Row numbers of a compact buffer laid out as [rows b0..b1-1 | the rows `outside` (ascending, disjoint from b0..b1-1)]
+    for the global row numbers `ixs`; every index must be in one of the two parts."""
+    g = ixs.long()
+    own = (g >= b0) & (g < b1)
+    if outside.numel():
+        pos = torch.searchsorted(outside, g.reshape(-1)).reshape(g.shape)
+        hit = outside[pos.clamp(max=outside.numel() - 1)] == g
+        assert bool((own | hit).all()), "localize_rows: an index is in neither part of the buffer"
+    else:
+        pos = torch.zeros_like(g)
+        assert bool(own.all()), "localize_rows: an index is outside the block and no outside rows were given"
+    return torch.where(own, g - b0, (b1 - b0) + pos).to(torch.int32).contiguous()
+
+
 def _as_i32(ixs, dev) -> torch.Tensor:
     if isinstance(ixs, torch.Tensor):
         return ixs.to(device=dev, dtype=torch.int32).contiguous()
