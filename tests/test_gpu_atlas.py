@@ -173,3 +173,71 @@ def test_atlas_sharded_ranks_equal_one_rank(tmp_path, world, extra):
     fin = np.isfinite(one["corr"])
     assert np.array_equal(np.isfinite(many["corr"]), fin)
     np.testing.assert_allclose(many["corr"][fin], one["corr"][fin], atol=2e-6)
+
+
+def test_atlas_fullsize_200k_cells_30k_genes(ops, oracle):
+    """BASELINE.json configs[4] at the size ONE GPU walks: 200 000 cells x 30 000 genes, CSR layers at ~8 % density,
+    streamed in four blocks (dense Sx/Ux of the whole dataset would be 48 GB; a block holds ~15 GB).
+      * pooling from CSR == pooling from the densified layers, bit for bit, on cell blocks from both ends of the dataset;
+      * gamma against fp64 column sums of the pooled blocks; correlations of sampled cells against the fp64 oracle on the
+        rows they touch (f32 tolerance 5e-5); size-independent properties of the whole result."""
+    from velocyto_amd import atlas
+    dev = ops.require_gpu()
+    C, G, k = 200_000, 30_000, 30
+    cS, cU, totS, totU, pcs, emb = atlas.synth_atlas(C, G, 30, dev, density=0.08)
+    dens = cS.nnz / (C * G)
+    assert 0.07 < dens < 0.09, dens
+    fS, fU = atlas.size_factors(totS, totU, C)
+    path = atlas.AtlasPath(cS, cU, fS, fU, pcs, emb, k=k, n_neighbors=500, sampled_fraction=0.5, block_cells=50_000)
+    assert path.nrndm == 250 and len(path.blocks()) == 4
+    corr = path.run()
+    # ---- A: CSR pooling against the dense kernel on the densified layer (6 GB of uint8 per layer), three blocks of 4096 cells
+    dS, dU = cS.to_dense(), cU.to_dense()
+    for b0 in (0, 101_000, C - 4096):
+        rows = slice(b0, b0 + 4096)
+        gi, gw = path.g_idx[rows], path.g_w[rows]
+        ptr = torch.arange(0, 4097 * (k + 1), k + 1, device=dev, dtype=torch.int64)
+        ref_S, ref_U = ops.knn_pool_counts(dS, dU, path.fS, path.fU, ptr, gi.reshape(-1), gw.reshape(-1), dtype=torch.float32, C_out=4096, validate=False)
+        got_S = ops.CellMatrix.empty(4096, G, torch.float32)
+        got_U = ops.CellMatrix.empty(4096, G, torch.float32)
+        path._pool(path.cS, path.fS, rows, got_S)
+        path._pool(path.cU, path.fU, rows, got_U)
+        assert torch.equal(got_S.t, ref_S.t) and torch.equal(got_U.t, ref_U.t), f"block at {b0}: CSR pooling differs from dense pooling"
+    del dS, dU, ref_S, ref_U
+    # ---- B: gamma = max(0, <Sx,Ux>/<Sx,Sx>) over ALL cells, re-derived in fp64 from freshly pooled blocks
+    sxx = torch.zeros(G, dtype=torch.float64, device=dev)
+    sxy = torch.zeros(G, dtype=torch.float64, device=dev)
+    for b0 in range(0, C, 20_000):
+        n = min(20_000, C - b0)
+        bS, bU = ops.CellMatrix.empty(n, G, torch.float32), ops.CellMatrix.empty(n, G, torch.float32)
+        path._pool(path.cS, path.fS, slice(b0, b0 + n), bS)
+        path._pool(path.cU, path.fU, slice(b0, b0 + n), bU)
+        sxx += (bS.t[:, :G].double() ** 2).sum(0)
+        sxy += (bS.t[:, :G].double() * bU.t[:, :G].double()).sum(0)
+    ref_g = torch.clamp(sxy / sxx, min=0)
+    okg = sxx > 0
+    torch.testing.assert_close(path.gamma.double()[okg], ref_g[okg], rtol=2e-6, atol=1e-12)
+    # ---- D: properties of the whole result
+    fin = torch.isfinite(corr)
+    assert fin.float().mean().item() > 0.999 and corr[fin].abs().max().item() <= 1 + 1e-5
+    assert bool((path.neigh[:, 1:] > path.neigh[:, :-1]).all()) and int(path.neigh.max()) < C
+    # ---- D: sampled cells against the fp64 oracle (first / last block, block boundaries)
+    g64 = path.gamma.double().cpu().numpy()
+    for c in (17, 49_999, 50_000, 123_456, C - 3):
+        nb = path.neigh[c].long()
+        rows = torch.cat([torch.tensor([c], device=dev), nb])
+        eS = ops.CellMatrix.empty(rows.numel(), G, torch.float32)
+        path._pool(path.cS, path.fS, rows, eS)
+        uC = ops.CellMatrix.empty(1, G, torch.float32)
+        path._pool(path.cU, path.fU, rows[:1], uC)
+        e_sub = eS.t[:, :G].double().cpu().numpy().T
+        s, u = e_sub[:, 0], uC.t[0, :G].double().cpu().numpy()
+        Dv = (s + (u - g64 * s)) - s
+        d_sub = np.zeros_like(e_sub)
+        d_sub[:, 0] = np.sign(Dv) * np.sqrt(np.abs(Dv) + 1e-10)
+        ixs = np.zeros((e_sub.shape[1], nb.numel()), dtype=np.int64)
+        ixs[0] = np.arange(1, nb.numel() + 1)
+        ref = oracle.coldeltacor_partial_compact(e_sub, d_sub, ixs, "sqrt", 1e-10, c0=0, c1=1)[0]
+        got = corr[c].cpu().numpy()
+        okc = np.isfinite(ref)
+        np.testing.assert_allclose(got[okc], ref[okc], atol=5e-5)

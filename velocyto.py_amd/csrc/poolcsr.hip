@@ -6,7 +6,7 @@
 // analysis.py:59-61, which is what caps it).  A cell's row is (gene index int32, count uint8/uint16) pairs, genes ascending.
 //
 // out[c, :] = sum_p (w[p] * scale[j_p]) * counts[j_p, :]  over the k+1 graph entries p of cell c:  a MERGE of k+1 sparse
-// rows into one dense row.  One WAVE owns a (cell, gene slab) unit: the slab (2048 genes, 8 KB of f32) lives in LDS, the
+// rows into one dense row.  One WAVE owns a cell and walks its gene slabs: the slab (2048 genes, 8 KB of f32) lives in LDS, the
 // graph entries are walked in order and every non-zero of the row's slab segment does  slab[g] = fma(ws, x, slab[g]).
 // LDS operations of one wave execute in program order and the non-zeros of one row hit distinct genes, so every gene
 // receives its contributions in graph order with one rounding each - bit for bit the arithmetic of the dense kernel
@@ -41,89 +41,127 @@ __global__ __launch_bounds__(256) void k_csr_slab_ptr(const int64_t *__restrict_
     slabptr[t] = lo;
 }
 
+// One wave = one output cell x a contiguous range of gene slabs.  Per-entry facts (source row, weight x size factor, row
+// start, slab boundary table) are loaded once into lane registers (lane = graph entry) and handed out with v_readlane; slab
+// boundaries of consecutive slabs share an endpoint, so each further slab costs one 4-byte load per entry, issued a slab
+// ahead.  The non-zeros of CSR_ROWS rows are requested together (up to CSR_NZ x 64 of each: 32 loads in flight per lane)
+// and then applied row by row in graph order: one round trip per CSR_ROWS rows instead of one per row.
+constexpr int CSR_ROWS = 4;
+
 template <typename T, typename CT>
 __global__ __launch_bounds__(64 * CSR_WAVES) void k_knn_pool_csr(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                                                                   const CT *__restrict__ data, const int32_t *__restrict__ slabptr,
                                                                   const double *__restrict__ scale, T *__restrict__ out,
                                                                   const int64_t *__restrict__ g_indptr, const int32_t *__restrict__ g_indices,
                                                                   const T *__restrict__ w, const int32_t *__restrict__ order, int G, int64_t ld_out,
-                                                                  int64_t cell0, int C_out, int nslab, int maximum)
+                                                                  int64_t cell0, int C_out, int nslab, int nsplit, int maximum)
 {
     using V = typename Vec<T>::type;
     constexpr int N = Vec<T>::N;
     __shared__ __attribute__((aligned(16))) T lds[CSR_WAVES][CSR_SLAB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     T *slab = lds[wave];
-    // slab-major, XCD-aware schedule as in pool.hip: workgroup b runs on XCD b % 8 (observed; speed only), so XCD x is given a
-    // contiguous range of the (locality-sorted) cell schedule and co-resident units re-read the same CSR rows from one L2
+    // split-major, XCD-aware schedule as in pool.hip: workgroup b runs on XCD b % 8 (observed; speed only), so XCD x is given a
+    // contiguous range of the (locality-sorted) cell schedule and co-resident waves re-read the same CSR rows from one L2
     const int nquads = (C_out + CSR_WAVES - 1) / CSR_WAVES, per = (nquads + 7) / 8, nblk = per * 8;
     const int64_t b = blockIdx.x;
-    const int s = (int)(b / nblk), bi = (int)(b % nblk);
-    const int pos = ((bi & 7) * per + (bi >> 3)) * CSR_WAVES + wave;
-    if ((bi & 7) * per + (bi >> 3) >= nquads || pos >= C_out) return;      // whole waves leave: no barrier below
+    const int split = (int)(b / nblk), bi = (int)(b % nblk);
+    const int quad = (bi & 7) * per + (bi >> 3);
+    const int pos = quad * CSR_WAVES + wave;
+    if (quad >= nquads || pos >= C_out) return;         // whole waves leave: there is no barrier below
     const int cl = order ? order[pos] : pos;
-    const int g0 = s * CSR_SLAB;
-#pragma unroll
-    for (int i = 0; i < CSR_SLAB / N / 64; ++i) {
-        V z;
-        T *zp = reinterpret_cast<T *>(&z);
-#pragma unroll
-        for (int k = 0; k < N; ++k) zp[k] = T(0);
-        reinterpret_cast<V *>(slab)[lane + 64 * i] = z;
-    }
+    const int sper = (nslab + nsplit - 1) / nsplit, s0 = split * sper, s1 = min(nslab, s0 + sper);
     const int64_t p0 = g_indptr[cl], p1 = g_indptr[cl + 1];
-    for (int64_t pb = p0; pb < p1; pb += 64) {
-        // lane l holds graph entry pb + l: source row, weight, and the row's segment [a, e) inside this slab
-        const int cnt = (int)min((int64_t)64, p1 - pb);
-        int64_t a_l = 0;
-        int n_l = 0;
+    const int64_t own = cell0 + cl;
+
+    for (int64_t pb = p0; pb < p1 || pb == p0; pb += 64) {     // batches of 64 graph entries (one batch for any kNN graph)
+        const bool first = pb == p0, last = pb + 64 >= p1;
+        const int cnt = (int)max((int64_t)0, min((int64_t)64, p1 - pb));
+        int64_t base_l = 0;
+        const int32_t *sp_l = slabptr;
         T ws_l = T(0);
+        int lo_l = 0, hi_l = 0;
         if (lane < cnt) {
             const int j = g_indices[pb + lane];
             ws_l = w[pb + lane] * (T)scale[j];
-            const int32_t *sp = slabptr + (int64_t)j * (nslab + 1) + s;
-            const int o0 = sp[0], o1 = sp[1];
-            a_l = indptr[j] + o0;
-            n_l = o1 - o0;
+            base_l = indptr[j];
+            sp_l = slabptr + (int64_t)j * (nslab + 1);
+            if (s0 < s1) { lo_l = sp_l[s0]; hi_l = sp_l[s0 + 1]; }
         }
-        for (int u = 0; u < cnt; ++u) {
-            const int64_t a = ((int64_t)__builtin_amdgcn_readlane((int)(a_l >> 32), u) << 32) | (unsigned)__builtin_amdgcn_readlane((int)a_l, u);
-            const int n = __builtin_amdgcn_readlane(n_l, u);
-            const T ws = readlane_t(ws_l, u);
-            for (int t0 = 0; t0 < n; t0 += 64 * CSR_NZ) {
-                int g[CSR_NZ];
-                CT x[CSR_NZ];
+        for (int s = s0; s < s1; ++s) {
+            const int g0 = s * CSR_SLAB;
+            const int64_t a_l = base_l + lo_l;
+            const int n_l = hi_l - lo_l;
+            lo_l = hi_l;
+            if (lane < cnt && s + 1 < s1) hi_l = sp_l[s + 2];   // next slab's far boundary, a slab ahead
+            if (first) {
 #pragma unroll
-                for (int q = 0; q < CSR_NZ; ++q) {
-                    const int t = t0 + lane + 64 * q;
-                    g[q] = -1;
-                    if (t < n) { g[q] = indices[a + t] - g0; x[q] = data[a + t]; }
+                for (int i = 0; i < CSR_SLAB / N / 64; ++i) {
+                    V z;
+                    T *zp = reinterpret_cast<T *>(&z);
+#pragma unroll
+                    for (int k = 0; k < N; ++k) zp[k] = T(0);
+                    reinterpret_cast<V *>(slab)[lane + 64 * i] = z;
+                }
+            } else {                                             // rows of more than 64 entries: continue from the partial sums
+                const T *orow = out + (int64_t)cl * ld_out + g0;
+                const int nv = (int)min((int64_t)CSR_SLAB, ld_out - g0) / N;
+#pragma unroll
+                for (int i = 0; i < CSR_SLAB / N / 64; ++i) {
+                    const int v = lane + 64 * i;
+                    if (v < nv) reinterpret_cast<V *>(slab)[v] = reinterpret_cast<const V *>(orow)[v];
+                }
+            }
+            for (int u0 = 0; u0 < cnt; u0 += CSR_ROWS) {
+                int g[CSR_ROWS][CSR_NZ];
+                CT x[CSR_ROWS][CSR_NZ];
+                T ws[CSR_ROWS];
+                int64_t a[CSR_ROWS];
+                int n[CSR_ROWS];
+#pragma unroll
+                for (int r = 0; r < CSR_ROWS; ++r) {
+                    const int u = min(u0 + r, cnt - 1);
+                    a[r] = ((int64_t)__builtin_amdgcn_readlane((int)(a_l >> 32), u) << 32) | (unsigned)__builtin_amdgcn_readlane((int)a_l, u);
+                    n[r] = (u0 + r < cnt) ? __builtin_amdgcn_readlane(n_l, u) : 0;
+                    ws[r] = readlane_t(ws_l, u);
+#pragma unroll
+                    for (int q = 0; q < CSR_NZ; ++q) {
+                        const int t = lane + 64 * q;
+                        g[r][q] = -1;
+                        if (t < n[r]) { g[r][q] = indices[a[r] + t] - g0; x[r][q] = data[a[r] + t]; }
+                    }
                 }
 #pragma unroll
-                for (int q = 0; q < CSR_NZ; ++q)
-                    if (g[q] >= 0) slab[g[q]] = fma(ws, (T)x[q], slab[g[q]]);
+                for (int r = 0; r < CSR_ROWS; ++r) {
+#pragma unroll
+                    for (int q = 0; q < CSR_NZ; ++q)
+                        if (g[r][q] >= 0) slab[g[r][q]] = fma(ws[r], (T)x[r][q], slab[g[r][q]]);
+                    for (int t = 64 * CSR_NZ + lane; t < n[r]; t += 64) {       // segments longer than 256 non-zeros (dense rows)
+                        const int gg = indices[a[r] + t] - g0;
+                        slab[gg] = fma(ws[r], (T)data[a[r] + t], slab[gg]);
+                    }
+                }
+            }
+            if (maximum && last) {                       // np.maximum(S_sz, Sx): the cell's own scaled counts (analysis.py:1017-1019)
+                const int32_t *sp = slabptr + own * (nslab + 1) + s;
+                const int64_t ao = indptr[own] + sp[0];
+                const int no = sp[1] - sp[0];
+                const T fs = (T)scale[own];
+                for (int t = lane; t < no; t += 64) {
+                    const int gg = indices[ao + t] - g0;
+                    const T o = fs * (T)data[ao + t];
+                    slab[gg] = slab[gg] > o ? slab[gg] : o;
+                }
+            }
+            // the dense row piece: 16-byte stores; rows are padded to ld_out (zeros beyond G: no non-zero lives there)
+            T *orow = out + (int64_t)cl * ld_out + g0;
+            const int nv = (int)min((int64_t)CSR_SLAB, ld_out - g0) / N;
+#pragma unroll
+            for (int i = 0; i < CSR_SLAB / N / 64; ++i) {
+                const int v = lane + 64 * i;
+                if (v < nv) reinterpret_cast<V *>(orow)[v] = reinterpret_cast<const V *>(slab)[v];
             }
         }
-    }
-    if (maximum) {                                       // np.maximum(S_sz, Sx): the cell's own scaled counts (analysis.py:1017-1019)
-        const int64_t j = cell0 + cl;
-        const int32_t *sp = slabptr + j * (nslab + 1) + s;
-        const int64_t a = indptr[j] + sp[0];
-        const int n = sp[1] - sp[0];
-        const T fs = (T)scale[j];
-        for (int t = lane; t < n; t += 64) {
-            const int g = indices[a + t] - g0;
-            const T o = fs * (T)data[a + t];
-            slab[g] = slab[g] > o ? slab[g] : o;
-        }
-    }
-    // the dense row piece: 16-byte stores; rows are padded to ld_out (zeros beyond G: no non-zero lives there)
-    T *orow = out + (int64_t)cl * ld_out + g0;
-    const int nv = (int)min((int64_t)CSR_SLAB, ld_out - g0) / N;
-#pragma unroll
-    for (int i = 0; i < CSR_SLAB / N / 64; ++i) {
-        const int v = lane + 64 * i;
-        if (v < nv) reinterpret_cast<V *>(orow)[v] = reinterpret_cast<const V *>(slab)[v];
     }
 }
 
@@ -153,12 +191,18 @@ extern "C" int vcy_knn_pool_csr(const int64_t *indptr, const int32_t *indices, c
     VCY_REQUIRE(dtype == VCY_F32 || dtype == VCY_F64, "knn_pool_csr: bad dtype");
     VCY_REQUIRE(ld_out % 16 == 0 && ((uintptr_t)out % 16) == 0, "knn_pool_csr: output rows must be 16-byte aligned with ld_out % 16 == 0");
     const int64_t nslab = (G + CSR_SLAB - 1) / CSR_SLAB;
-    const int64_t nquads = (C_out + CSR_WAVES - 1) / CSR_WAVES, blocks = nslab * ((nquads + 7) / 8 * 8);
+    // a wave walks a contiguous range of slabs of its cell; few output cells (halo rows, small blocks) split the slabs over
+    // more waves so that the launch still fills the 256 CUs x 20 resident waves
+    int64_t nsplit = (4 * 5120 + C_out - 1) / C_out;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > nslab) nsplit = nslab;
+    nsplit = (nslab + ((nslab + nsplit - 1) / nsplit) - 1) / ((nslab + nsplit - 1) / nsplit);      // no empty ranges
+    const int64_t nquads = (C_out + CSR_WAVES - 1) / CSR_WAVES, blocks = nsplit * ((nquads + 7) / 8 * 8);
     VCY_REQUIRE(blocks < (1LL << 31), "knn_pool_csr: grid too large");
     hipStream_t st = as_stream(stream);
 #define VCY_POOLCSR(T, CT)                                                                                                                          \
     hipLaunchKernelGGL((k_knn_pool_csr<T, CT>), dim3((unsigned)blocks), dim3(64 * CSR_WAVES), 0, st, indptr, indices, (const CT *)data, slabptr, scale, \
-                       (T *)out, g_indptr, g_indices, (const T *)w, order, (int)G, ld_out, cell0, (int)C_out, (int)nslab, maximum)
+                       (T *)out, g_indptr, g_indices, (const T *)w, order, (int)G, ld_out, cell0, (int)C_out, (int)nslab, (int)nsplit, maximum)
     if (dtype == VCY_F32) { if (count_dtype == VCY_U16) VCY_POOLCSR(float, uint16_t); else VCY_POOLCSR(float, uint8_t); }
     else { if (count_dtype == VCY_U16) VCY_POOLCSR(double, uint16_t); else VCY_POOLCSR(double, uint8_t); }
 #undef VCY_POOLCSR
