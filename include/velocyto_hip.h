@@ -284,6 +284,14 @@ int vcy_velocity_chain(const void *Sx_sz, const void *Ux_sz, const float *gamma,
                        double used_dt, int assumption, int clip, int transform, double psc, int dtype,
                        vcy_stream stream);
 
+/* One stage of the same chain from its STORED predecessor - calculate_velocity reads self.Upred (analysis.py:1369),
+ * calculate_shift self.velocity (:1399), extrapolate_cell_at_t self.delta_S (:1429-1431) - so that a matrix the user has
+ * edited between two calls propagates as it does in the reference:  out = a * x + b * y  (y may be NULL: out = a * x),
+ * then |out| < zero_below[g] -> 0 (zero_below (G) doubles or NULL: the eps rule, :1377-1379) and max(out, 0) when clip.
+ * Products and sum are rounded separately (numpy's evaluation order).  Cells-major (C, ld) matrices of `dtype`.          */
+int vcy_lincomb(const void *x, const void *y, void *out, double a, double b, const double *zero_below, int clip, int64_t C,
+                int64_t G, int64_t ld, int dtype, vcy_stream stream);
+
 /* The non-default weight constructions of VelocytoLoom.fit_gammas (analysis.py:1182-1192,
  * 1208-1219), materialised densely for vcy_fit_weighted(weight_mode 0).  Per-gene fp64 vectors:
  *   mode 0 "sum"   W = S/pa + U/pb            mode 1 "prod"  W = (S/pa)*(U/pb)

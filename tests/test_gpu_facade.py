@@ -630,3 +630,79 @@ def test_reference_quirks_reproduce_or_fix_as_documented(vcy, golden):
         vlm.estimate_transition_prob(hidim="pcs", embed="ts", ndims=3)
     with pytest.raises(ValueError):
         vlm.estimate_transition_prob(hidim="Sx_sz", embed="ts", ndims=3)
+
+
+def test_checkpoint_restores_masks_and_device_state(vcy, golden, tmp_path):
+    """to_hdf5 / load_velocyto_hdf5 (analysis.py:76-94, 2454-2470; serialization.py:44-115): boolean masks come back as bool
+    (and keep filtering), the state downstream of estimate_transition_prob - kept compact on the device - survives, and a
+    checkpoint in the reference's own form (dense corrcoef + embedding_knn graph) is gathered into that compact form."""
+    from velocyto_amd.analysis import load_velocyto_hdf5
+    from velocyto_amd import loom_io, serialization
+    g = golden("pipeline")
+    vlm = _prep_for_transition(vcy, g, "float64")
+    vlm.cv_mean_selected = np.arange(vlm.S.shape[0]) % 3 != 0                      # a gene mask as score_cv_vs_mean leaves it
+    vlm.estimate_transition_prob(hidim="Sx_sz", embed="ts", transform="sqrt", n_neighbors=40, knn_random=True, sampled_fraction=0.5, threads=1)
+    vlm.calculate_embedding_shift(sigma_corr=0.05)
+    path = str(tmp_path / "ck.hdf5")
+    serialization.dump_hdf5(vlm, path, data_compression=4, chunks=(64, 64), pickle_protocol=4)
+    v2 = serialization.load_hdf5(path, obj_class=vcy.analysis.VelocytoLoom, dtype="float64")
+    assert v2.cv_mean_selected.dtype == np.bool_ and np.array_equal(v2.cv_mean_selected, vlm.cv_mean_selected)
+    np.testing.assert_array_equal(v2.corrcoef, vlm.corrcoef)
+    np.testing.assert_array_equal(v2.corrcoef_random, vlm.corrcoef_random)
+    np.testing.assert_array_equal(v2.transition_prob, vlm.transition_prob)
+    assert (v2.embedding_knn != vlm.embedding_knn).nnz == 0
+    # the restored object continues where the saved one stopped: same chain settings, same downstream results
+    for o in (vlm, v2):
+        o.calculate_embedding_shift(sigma_corr=0.08)
+        o.prepare_markov(sigma_D=2.0, sigma_W=4.0)
+        o.run_markov(n_steps=20)
+        o.extrapolate_cell_at_t(delta_t=0.5)
+    np.testing.assert_array_equal(v2.delta_embedding, vlm.delta_embedding)
+    np.testing.assert_array_equal(v2.diffused, vlm.diffused)
+    np.testing.assert_array_equal(v2.Sx_sz_t, vlm.Sx_sz_t)
+    # a reloaded bool mask filters like a fresh one (an integer mask would fancy-index rows 0 and 1)
+    keep = v2.cv_mean_selected
+    v2.filter_genes(by_cv_vs_mean=True)
+    assert v2.S.shape[0] == int(keep.sum()) and list(v2.ra["Gene"]) == list(np.asarray(vlm.ra["Gene"])[keep])
+    # the reference's own checkpoint form
+    ref = {k: v for k, v in loom_io.hdf5_load(path).items() if not k.endswith("_compact") and not k.endswith("_indices") and k != "&chain_settings"}
+    ref["corrcoef"], ref["transition_prob"] = vlm.corrcoef, vlm.transition_prob
+    path2 = str(tmp_path / "ref_style.hdf5")
+    loom_io.hdf5_dump(path2, ref)
+    v3 = load_velocyto_hdf5(path2, dtype="float64")
+    nz = vlm.embedding_knn.toarray() > 0
+    np.testing.assert_array_equal(v3.corrcoef[nz], vlm.corrcoef[nz])
+    v3.calculate_embedding_shift(sigma_corr=0.08)
+    np.testing.assert_allclose(v3.delta_embedding, vlm.delta_embedding, rtol=1e-12, atol=1e-14)
+
+
+def test_stored_intermediates_feed_the_next_stage(vcy, golden):
+    """The reference's chain reads the stored attributes (calculate_velocity: self.Upred, calculate_shift: self.velocity,
+    extrapolate_cell_at_t: self.delta_S; analysis.py:1369, 1399, 1430): an intermediate assigned by the user must propagate,
+    and the host views of device matrices are read-only so that an in-place edit cannot be lost silently."""
+    g = golden("pipeline")
+    vlm = _prep_for_transition(vcy, g, "float64")
+    base_dS = vlm.delta_S.copy()
+    with pytest.raises(ValueError):
+        vlm.velocity[0, 0] = 0.0                                   # a host copy: refuse, do not ignore
+    vel = vlm.velocity.copy()
+    vel[::2] = 0.0                                                 # mask every other gene
+    vlm.velocity = vel
+    vlm.calculate_shift(assumption="constant_velocity", delta_t=2.0)
+    np.testing.assert_allclose(vlm.delta_S, 2.0 * vel, rtol=1e-15)
+    vlm.extrapolate_cell_at_t(delta_t=1.0)
+    np.testing.assert_allclose(vlm.Sx_sz_t, np.clip(vlm.Sx_sz + 2.0 * vel, 0, None), rtol=1e-15)
+    dS = base_dS.copy()
+    dS[1::2] = 0.0
+    vlm.delta_S = dS
+    vlm.extrapolate_cell_at_t(delta_t=1.5, clip=False)
+    np.testing.assert_allclose(vlm.Sx_sz_t, vlm.Sx_sz + 1.5 * dS, rtol=1e-15)
+    up = vlm.Upred.copy() * 1.1
+    vlm.Upred = up
+    vlm.calculate_velocity()
+    np.testing.assert_allclose(vlm.velocity, vlm.Ux_sz - up, rtol=1e-14, atol=1e-15)
+    # recomputing an upstream stage puts the chain back on the fused kernel path
+    vlm.predict_U()
+    vlm.calculate_velocity()
+    vlm.calculate_shift(assumption="constant_velocity")
+    np.testing.assert_allclose(vlm.delta_S, base_dS, rtol=1e-13, atol=1e-15)

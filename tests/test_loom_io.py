@@ -69,7 +69,7 @@ def test_hdf5_flat_dump_load(loom_io, tmp_path):
     assert set(back) == set(d)
     np.testing.assert_array_equal(back["Sx"], d["Sx"])
     assert back["gammas"].dtype == np.float32 and back["ix"].dtype == np.int64
-    np.testing.assert_array_equal(back["flag"], [1, 0, 1])
+    assert back["flag"].dtype == np.bool_ and back["flag"].tolist() == [True, False, True]      # 8-bit enum, as h5py stores bools
     assert back["scalar"].shape == (1,) and back["scalar"][0] == 3.5
     assert pickle.loads(zlib.decompress(back["&ca"].tobytes())) == {"CellID": list(range(9))}
 
@@ -92,3 +92,80 @@ def test_velocytoloom_checkpoint_roundtrip(loom_io, tmp_path):
     v2.predict_U(); v2.calculate_velocity()                      # the restored object keeps working on the device
     vlm.predict_U(); vlm.calculate_velocity()
     np.testing.assert_array_equal(v2.velocity, vlm.velocity)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Files this repository's writer did NOT produce: tests/golden/loompy_v2.loom / loompy_v3.loom, written by the C program
+# tests/golden/make_loom_fixture.c straight on libhdf5 in loompy's layout (chunked (64, 64) gzip-2 /matrix and layers with
+# unlimited maxshape, uint16 / uint32 layers, fixed-length ASCII (v2) or variable-length UTF-8 (v3) string attributes,
+# LOOM_SPEC_VERSION as a root attribute (v2) or under /attrs (v3)).  The expected numbers are the program's closed formulas.
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NG, NC = 23, 17
+
+
+def _expected():
+    g, c = np.meshgrid(np.arange(NG), np.arange(NC), indexing="ij")
+    S = ((g * 7 + c * 3) % 11) * ((g + c) % 3 != 0) + 40000 * ((g == 5) & (c == 4)) + 300 * ((g == 20) & (c == 16))
+    U = ((g * 5 + c * 2) % 7) * ((g * c) % 4 != 1)
+    A = ((g + 2 * c) % 5 == 0).astype(np.int64)
+    return S, U, A
+
+
+@pytest.mark.parametrize("version", ["v2", "v3"])
+def test_read_loompy_layout(loom_io, version):
+    path = os.path.join(GOLDEN, f"loompy_{version}.loom")
+    layers, ca, ra = loom_io.read_loom(path)
+    S, U, A = _expected()
+    want = np.uint16 if version == "v2" else np.uint32
+    for name, ref in (("spliced", S), ("unspliced", U), ("ambiguous", A)):
+        assert layers[name].dtype == want and layers[name].shape == (NG, NC)
+        np.testing.assert_array_equal(layers[name], ref)
+    assert int(layers["spliced"].max()) == 40000                                  # beyond uint8: the uint16 device path
+    genes = [("G\u00e8ne_2" if (version == "v3" and g == 2) else f"Gene_{g * g}") for g in range(NG)]
+    assert [str(x) for x in ra["Gene"]] == genes
+    assert [str(x) for x in ra["Accession"]] == [f"ENSMUSG{1000 + 37 * g:011d}" for g in range(NG)]
+    assert [str(x) for x in ra["Chromosome"]] == [str(1 + g % 19) for g in range(NG)]
+    assert [str(x) for x in ra["Strand"]] == ["-" if g % 2 else "+" for g in range(NG)]
+    np.testing.assert_array_equal(ra["Start"], 100000 * np.arange(NG) + 17)
+    np.testing.assert_array_equal(ra["End"], ra["Start"] + 1500 + 13 * np.arange(NG))
+    assert ra["Start"].dtype == np.int64
+    assert [str(x) for x in ca["CellID"]] == [f"sample1:{'ABCD'[c % 4]}ACGT{c * 31:04d}x" for c in range(NC)]
+    np.testing.assert_array_equal(ca["Clusters"], np.arange(NC) % 3)
+    x, y = 0.5 * np.arange(NC) - 3.25, 1.0 / (1 + np.arange(NC))
+    if version == "v2":
+        np.testing.assert_array_equal(ca["_X"], x)
+        np.testing.assert_array_equal(ca["_Y"], y)
+    else:
+        assert ca["TSNE"].shape == (NC, 2)
+        np.testing.assert_array_equal(ca["TSNE"], np.stack([x, y], 1))
+    fa = loom_io.read_file_attrs(path)
+    assert fa["LOOM_SPEC_VERSION"] == ("2.0.1" if version == "v2" else "3.0.0") and "CreationDate" in fa
+    assert loom_io.layer_shape(path, "unspliced") == (NG, NC)
+    np.testing.assert_array_equal(loom_io.read_layer_block(path, "spliced", 3, 11), S[:, 3:11])      # hyperslab across the gzip chunks
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("version", ["v2", "v3"])
+def test_loompy_layout_to_device(loom_io, version):
+    """The same files through the facade constructor (analysis.py:56-67) and straight into the CSR form of the atlas path."""
+    import velocyto_amd
+    from velocyto_amd import ops
+    path = os.path.join(GOLDEN, f"loompy_{version}.loom")
+    S, U, A = _expected()
+    vlm = velocyto_amd.analysis.VelocytoLoom(path, dtype="float64")
+    assert np.array_equal(vlm.S, S) and np.array_equal(vlm.U, U) and np.array_equal(vlm.A, A)
+    np.testing.assert_array_equal(vlm.initial_cell_size, S.sum(0))
+    assert vlm._counts["S"].t.dtype == torch_int16()                # 40 000 does not fit a byte: uint16 bits on the device
+    for layer, ref in (("spliced", S), ("unspliced", U)):
+        for blk in (5, 64):                                         # blocks smaller and larger than the file
+            csr = loom_io.read_layer_csr(path, layer, cell_block=blk)
+            assert csr.C == NC and csr.G == NG and csr.nnz == int((ref != 0).sum())
+            np.testing.assert_array_equal(csr.to_dense().as_int32().cpu().numpy(), ref.T)
+    part = loom_io.read_layer_csr(path, "spliced", cell_block=4, c0=6, c1=15)     # a rank's shard of the cells
+    np.testing.assert_array_equal(part.to_dense().as_int32().cpu().numpy(), S.T[6:15])
+    np.testing.assert_array_equal(part.row_sums().cpu().numpy(), S.sum(0)[6:15])
+
+
+def torch_int16():
+    import torch
+    return torch.int16

@@ -81,6 +81,7 @@ SIGNATURES = {
     "vcy_diffuse_step_csc": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),
     "vcy_fit_weighted": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_dbl, c_dbl,
                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]),
+    "vcy_lincomb": (c_int, [c_vp, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_vp]),
     "vcy_velocity_chain": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64,
                                    c_dbl, c_dbl, c_dbl, c_int, c_int, c_int, c_dbl, c_int, c_vp]),
 }

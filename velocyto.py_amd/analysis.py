@@ -89,7 +89,9 @@ class VelocytoLoom(PreprocessMixin):
             if name in d:
                 h = object.__getattribute__(self, "_host")
                 if name not in h:
-                    h[name] = d[name].to_genes_major(order="F")      # same values/strides the reference ends up with
+                    a = d[name].to_genes_major(order="F")            # same values/strides the reference ends up with
+                    a.setflags(write=False)                          # a host COPY of device data: an in-place edit would be lost, so
+                    h[name] = a                                      # it fails loudly - assign the whole attribute to change it
                 return h[name]
         elif name in _LAZY_DENSE:
             return self._densify(name)
@@ -290,7 +292,14 @@ class VelocytoLoom(PreprocessMixin):
         # schedule the pooling along the Hilbert curve of the two leading coordinates of the search space (results do not
         # depend on it; neighbouring cells gather overlapping rows while they are still in L2)
         self.__dict__["_pool_order"] = ops.hilbert_order(np.ascontiguousarray(space[:, :2])) if np.shape(space)[1] >= 2 else None
-        self._pool(self.knn_smoothing_w, maximum, "S_sz" if size_norm else "S", "U_sz" if size_norm else "U")
+        self._pool(self.knn_smoothing_w, maximum and size_norm, "S_sz" if size_norm else "S", "U_sz" if size_norm else "U")
+        if maximum and not size_norm:
+            # the reference takes the maximum with the SIZE-NORMALISED layers whatever was pooled (analysis.py:1017-1019:
+            # np.maximum(self.S_sz, self.Sx)); reproduced as is
+            for pooled, raw in (("Sx", "S_sz"), ("Ux", "U_sz")):
+                m = CellMatrix(torch.maximum(self.dev(pooled).t, self.dev(raw).t), self.dev(pooled).G)
+                self._set_dev(pooled, m)
+                self._set_dev(pooled + "_sz", m.clone())
 
     def knn_imputation_precomputed(self, knn_smoothing_w: sparse.spmatrix, maximum: bool = False) -> None:
         """analysis.py:1025-1053."""
@@ -428,27 +437,31 @@ class VelocytoLoom(PreprocessMixin):
         if self.which_S_for_pred not in ("Sx_sz", "Sx"):
             raise NotImplementedError(f"Not implemented with which_S = {self.which_S_for_pred}")
         self._vel_eps = eps
-        self._set_dev("velocity", self._chain(("velocity",))["velocity"])
+        # velocity = Ux_sz - self.Upred with the STORED Upred (analysis.py:1369-1379): an Upred edited by the user propagates
+        Ud, up = self.dev("Ux_sz" if self.which_S_for_pred == "Sx_sz" else "Ux"), self.dev("Upred")
+        thr = ops.gene_quantiles(up, [100])[0] * float(eps) if eps else None           # Upred.max(1) * eps   (:1378)
+        self._set_dev("velocity", ops.lincomb(Ud, up, 1.0, -1.0, zero_below=thr))
 
     def calculate_shift(self, assumption: str = "constant_velocity", delta_t: float = 1) -> None:
         """analysis.py:1381-1408."""
         if assumption not in ("constant_velocity", "constant_unspliced"):
             raise NotImplementedError(f"Assumption {assumption} is not implemented")
         self._assumption, self._shift_dt = (0 if assumption == "constant_velocity" else 1), float(delta_t)
-        self._set_dev("delta_S", self._chain(("delta_S",))["delta_S"])
+        if assumption == "constant_velocity":
+            self._set_dev("delta_S", ops.lincomb(self.dev("velocity"), None, float(delta_t)))     # delta_t * self.velocity (:1399)
+        else:
+            self._set_dev("delta_S", self._chain(("delta_S",))["delta_S"])          # closed form from Sx_sz, Ux_sz, gammas, q (:1400-1406)
 
     def extrapolate_cell_at_t(self, delta_t: float = 1, clip: bool = True) -> None:
         """analysis.py:1410-1439."""
         self._extrap_dt, self._clip = float(delta_t), bool(clip)
         if clip:
             self.used_delta_t = delta_t
-        out = self._chain(("Sx_sz_t",))["Sx_sz_t"]
-        if self.which_S_for_pred == "Sx_sz":
-            self._set_dev("Sx_sz_t", out)
-        elif self.which_S_for_pred == "Sx":
-            self._set_dev("Sx_t", out)
-        else:
+        if self.which_S_for_pred not in ("Sx_sz", "Sx"):
             raise NotImplementedError("not implemented for other situations other than Sx or Sx_sz")
+        # Sx_sz + delta_t * self.delta_S on the STORED delta_S, clipped at 0 (:1429-1431)
+        out = ops.lincomb(self.dev(self.which_S_for_pred), self.dev("delta_S"), 1.0, float(delta_t), clip=clip)
+        self._set_dev("Sx_sz_t" if self.which_S_for_pred == "Sx_sz" else "Sx_t", out)
 
     # ------------------------------------------------------------------ stage D
     def estimate_transition_prob(self, hidim: str = "Sx_sz", embed: str = "ts", transform: str = "sqrt", ndims: int = None,
@@ -694,6 +707,7 @@ class VelocytoLoom(PreprocessMixin):
         from .loom_io import hdf5_dump
         from .serialization import _obj2uint
         exclude = set(kwargs.get("exclude", ()) or ())
+        noarray_compression, protocol = int(kwargs.get("noarray_compression", 9)), int(kwargs.get("pickle_protocol", 2))
         out = {}
         for name in self._dev:
             if name not in exclude:
@@ -701,14 +715,22 @@ class VelocytoLoom(PreprocessMixin):
         items = dict(self.__dict__)
         if "_neigh" in items and "embedding_knn" not in exclude:
             items["embedding_knn"] = self.embedding_knn               # assembled on demand; a plain attribute in the reference
+        # what the reference persists as the dense (cells, cells) corrcoef / transition_prob (20 GB each at 50k cells) is kept
+        # in its compact neighbour-list form, under public names, together with the settings of the velocity chain
+        for key, pub in _COMPACT_STATE.items():
+            if key in items and pub not in exclude:
+                out[pub] = items[key].cpu().numpy()
+        chain = {k: items[k] for k in _CHAIN_SETTINGS if k in items}
+        if chain:
+            items["chain_settings"] = chain
         for name, val in items.items():
             if name.startswith("_") or name in exclude or isinstance(val, torch.Tensor):
                 continue                                              # device-side caches are rebuilt on demand
             if isinstance(val, np.ndarray) and val.dtype.kind in "fiub":
                 out[name] = val
             else:
-                out["&" + name] = _obj2uint(val, compression=9, protocol=2)
-        hdf5_dump(filename, out)
+                out["&" + name] = _obj2uint(val, compression=noarray_compression, protocol=protocol)
+        hdf5_dump(filename, out, compression=int(kwargs.get("data_compression", 0)), chunks=tuple(kwargs.get("chunks", (2048, 2048))))
 
 
     def reload_raw(self, substitute: bool = False) -> None:
@@ -794,16 +816,53 @@ def gaussian_kernel(X: np.ndarray, mu: float = 0, sigma: float = 1) -> np.ndarra
     return np.exp(-(X - mu)**2 / (2 * sigma**2)) / np.sqrt(2 * np.pi * sigma**2)
 
 
-def load_velocyto_hdf5(filename: str, dtype=None) -> VelocytoLoom:
+_COMPACT_STATE = {"_neigh": "embedding_knn_indices", "_corr": "corrcoef_compact", "_corr_random": "corrcoef_random_compact",
+                  "_tp": "transition_prob_compact", "_tp_random": "transition_prob_random_compact", "_tp_ixs": "transition_prob_indices"}
+_CHAIN_SETTINGS = ("_which_gamma", "_which_offset", "_vel_eps", "_assumption", "_shift_dt", "_extrap_dt", "_clip")
+
+
+def _restore_device_state(vlm: "VelocytoLoom") -> None:
+    """After a checkpoint has been read: rebuild the device-side state the methods downstream of estimate_transition_prob
+    use.  Checkpoints of this package carry it in compact form; a checkpoint written by the reference carries the dense
+    corrcoef / transition_prob and the embedding_knn graph, which are gathered back into neighbour lists here."""
+    st = vlm.__dict__
+    dev = ops.require_gpu()
+    dt = vlm._dtype
+    for k, v in (st.pop("chain_settings", None) or {}).items():
+        st[k] = v
+    for key, pub in _COMPACT_STATE.items():
+        if pub in st:
+            a = st.pop(pub)
+            st[key] = torch.as_tensor(a).to(dev).to(torch.int32 if key in ("_neigh", "_tp_ixs") else dt).contiguous()
+    if "_neigh" not in st and "embedding_knn" in st and sparse.issparse(st["embedding_knn"]):
+        knn = sparse.csr_matrix(st["embedding_knn"])
+        knn.sort_indices()
+        lens = np.diff(knn.indptr)
+        if lens.size and (lens == lens[0]).all():
+            neigh = knn.indices.reshape(knn.shape[0], int(lens[0])).astype(np.int32)
+            st["_neigh"] = torch.as_tensor(neigh).to(dev)
+            rows = np.arange(knn.shape[0])[:, None]
+            for dense, key in (("corrcoef", "_corr"), ("corrcoef_random", "_corr_random"), ("transition_prob", "_tp"), ("transition_prob_random", "_tp_random")):
+                if dense in st and isinstance(st[dense], np.ndarray) and st[dense].shape == knn.shape:
+                    st[key] = torch.as_tensor(np.ascontiguousarray(st.pop(dense)[rows, neigh])).to(dev).to(dt)
+            if "_tp" in st:
+                st["_tp_ixs"] = st["_neigh"]
+    st.pop("embedding_knn", None)                                     # assembled from _neigh when read
+
+
+def load_velocyto_hdf5(filename: str, dtype=None, obj_class: type = None) -> VelocytoLoom:
     """analysis.py:2454-2470 + serialization.load_hdf5 (serialization.py:95-115): rebuild a VelocytoLoom from a
     checkpoint written by `to_hdf5` (or by the reference's dump_hdf5: same layout)."""
     import pickle
     import zlib
     from .loom_io import hdf5_load
-    vlm = VelocytoLoom(None, dtype=dtype)
+    if obj_class is not None and not (isinstance(obj_class, type) and issubclass(obj_class, VelocytoLoom)):
+        raise TypeError("obj_class must be VelocytoLoom or a subclass of it")
+    vlm = (obj_class or VelocytoLoom)(None, dtype=dtype)
     for name, arr in hdf5_load(filename).items():
         if name.startswith("&"):
             setattr(vlm, name[1:], pickle.loads(zlib.decompress(np.asarray(arr, dtype=np.uint8).tobytes())))
         else:
             setattr(vlm, name, arr)
+    _restore_device_state(vlm)
     return vlm

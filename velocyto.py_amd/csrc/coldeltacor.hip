@@ -75,6 +75,36 @@ template <typename T, int TR, int RULES> __device__ __forceinline__ T xform_shif
     const T k = xform<T, TR, RULES>(T(0), psc);
     return (k - k == T(0)) ? k : T(0);             // psc = 0 gives -inf: every agreeing gene is NaN in the reference as well
 }
+// f32 forms the logarithm as v_log_f32 (log2) times log10(2); the shift is taken in the log2 domain, BEFORE that scaling,
+// so that an agreeing gene contributes an exact zero whatever the compiler contracts: (l - l0) * c, never fma(l, c, -K)
+// (which leaves the rounding residue of l * c on every agreeing gene and turns a zero-variance self pair into noise).
+template <> __device__ __forceinline__ float xform_shift<float, VCY_LOG10, VCY_RULES_PARTIAL>(float psc)
+{
+    const float l0 = __builtin_amdgcn_logf(psc);                // f(0) = +log10(psc): t >= 0 takes the positive branch
+    return (l0 - l0 == 0.f) ? l0 : 0.f;
+}
+template <> __device__ __forceinline__ float xform_shift<float, VCY_LOG10, VCY_RULES_FULL>(float psc)
+{
+    const float l0 = -__builtin_amdgcn_logf(psc);               // f(0) = -log10(psc): t > 0 fails at t == 0
+    return (l0 - l0 == 0.f) ? l0 : 0.f;
+}
+
+// A[g] - K: the transformed difference as it enters the moments
+template <typename T, int TR, int RULES> __device__ __forceinline__ T xform_s(T t, T psc, T K)
+{
+    const T a = xform<T, TR, RULES>(t, psc);
+    return TR == VCY_LOG10 ? a - K : a;
+}
+template <> __device__ __forceinline__ float xform_s<float, VCY_LOG10, VCY_RULES_PARTIAL>(float t, float psc, float K)
+{
+    const float l = __builtin_amdgcn_logf(fabsf(t) + psc);
+    return (((t >= 0.f) ? l : -l) - K) * 0.30102999566398120f;
+}
+template <> __device__ __forceinline__ float xform_s<float, VCY_LOG10, VCY_RULES_FULL>(float t, float psc, float K)
+{
+    const float l = __builtin_amdgcn_logf(fabsf(t) + psc);
+    return (((t > 0.f) ? l : -l) - K) * 0.30102999566398120f;
+}
 
 template <typename T> __device__ __forceinline__ T pearson_from_moments(double sA, double sAA, double sAb, double sb, double sbb, double n)
 {
@@ -191,8 +221,7 @@ __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, c
                     const T *bp = reinterpret_cast<const T *>(&dcv);
 #pragma unroll
                     for (int k = 0; k < N; ++k) {
-                        T a = xform<T, TR, RULES>(xp[k] - ep[k], psc);
-                        if (TR == VCY_LOG10) a -= K;
+                        T a = xform_s<T, TR, RULES>(xp[k] - ep[k], psc, K);
                         sA[k] += a;
                         sAA[k] = fma(a, a, sAA[k]);
                         sAb[k] = fma(a, bp[k], sAb[k]);
@@ -208,8 +237,7 @@ __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, c
                 const T *bp = reinterpret_cast<const T *>(&dcv);
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
-                    T a = xform<T, TR, RULES>(xp[k] - ep[k], psc);
-                    if (TR == VCY_LOG10) a -= K;
+                    T a = xform_s<T, TR, RULES>(xp[k] - ep[k], psc, K);
                     sA[k] += a;
                     sAA[k] = fma(a, a, sAA[k]);
                     sAb[k] = fma(a, bp[k], sAb[k]);
@@ -218,8 +246,7 @@ __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, c
             {
                 const int g = nvec * N + lane;
                 if (g < gl) {
-                    T a = xform<T, TR, RULES>(row[g] - ec[g], psc);
-                    if (TR == VCY_LOG10) a -= K;
+                    T a = xform_s<T, TR, RULES>(row[g] - ec[g], psc, K);
                     sA[0] += a;
                     sAA[0] = fma(a, a, sAA[0]);
                     sAb[0] = fma(a, dc[g], sAb[0]);
@@ -460,8 +487,7 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
                         const T *bp2 = reinterpret_cast<const T *>(&dcv2[u]);
 #pragma unroll
                         for (int k = 0; k < N; ++k) {
-                            T a = xform<T, TR, RULES>(xp[k] - ep[k], psc);
-                            if (TR == VCY_LOG10) a -= K;
+                            T a = xform_s<T, TR, RULES>(xp[k] - ep[k], psc, K);
                             sA[k] += a;
                             sAA[k] = fma(a, a, sAA[k]);
                             sAb[k] = fma(a, bp[k], sAb[k]);
@@ -485,8 +511,7 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
                         const int valid = (ragged && v == nvec - 1) ? (gl - v * N) : N;
 #pragma unroll
                         for (int k = 0; k < N; ++k) {
-                            T a = xform<T, TR, RULES>(xp[k] - ep[k], psc);
-                            if (TR == VCY_LOG10) a -= K;
+                            T a = xform_s<T, TR, RULES>(xp[k] - ep[k], psc, K);
                             if (k >= valid) a = T(0);
                             sA[k] += a;
                             sAA[k] = fma(a, a, sAA[k]);
@@ -617,8 +642,7 @@ __global__ __launch_bounds__(256) void k_cdc_full(const T *__restrict__ e, const
             const T x = ei[il][g];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                T a = xform<T, TR, VCY_RULES_FULL>(x - ecs[cg * 4 + k][g], psc);
-                if (TR == VCY_LOG10) a -= K;
+                T a = xform_s<T, TR, VCY_RULES_FULL>(x - ecs[cg * 4 + k][g], psc, K);
                 sA[k] += a;
                 sAA[k] = fma(a, a, sAA[k]);
                 sAb[k] = fma(a, dcs[cg * 4 + k][g], sAb[k]);

@@ -113,9 +113,59 @@ template <typename T> __global__ __launch_bounds__(256) void k_velocity_chain(Ve
     }
     for (; c < c1; ++c) one(c, reinterpret_cast<const V *>(Sx + c * a.ld)[v], reinterpret_cast<const V *>(Ux + c * a.ld)[v]);
 }
+// One stage of the chain from its STORED predecessor, the way the reference's methods read self.Upred / self.velocity /
+// self.delta_S (analysis.py:1369, 1399, 1429-1431) - so that an intermediate the user has edited propagates:
+//     out = a * x + b * y      (two roundings of the products, then the sum: numpy's evaluation order, no FMA contraction)
+//     |out| < zero_below[g] -> 0   (the eps rule of calculate_velocity, :1377-1379)        clip: max(out, 0)  (:1431)
+template <typename T>
+__global__ __launch_bounds__(256) void k_lincomb(const T *__restrict__ x, const T *__restrict__ y, T *__restrict__ out, T a, T b,
+                                                  const double *__restrict__ zero_below, int clip, int64_t C, int G, int64_t ld)
+{
+#pragma clang fp contract(off)
+    using V = typename Vec<T>::type;
+    constexpr int N = Vec<T>::N;
+    const int64_t nvec = ld / N, total = C * nvec;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = t / nvec;
+        const int v = (int)(t - c * nvec);
+        const V xv = reinterpret_cast<const V *>(x + c * ld)[v];
+        V yv = xv, ov;
+        if (y) yv = reinterpret_cast<const V *>(y + c * ld)[v];
+        const T *xp = reinterpret_cast<const T *>(&xv), *yp = reinterpret_cast<const T *>(&yv);
+        T *op = reinterpret_cast<T *>(&ov);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int g = v * N + k;
+            T r = T(0);
+            if (g < G) {
+                const T p = a * xp[k];
+                r = y ? p + b * yp[k] : p;
+                if (zero_below && fabs((double)r) < zero_below[g]) r = T(0);
+                if (clip) r = r < T(0) ? T(0) : r;
+            }
+            op[k] = r;
+        }
+        reinterpret_cast<V *>(out + c * ld)[v] = ov;
+    }
+}
 }  // namespace vcy
 
 using namespace vcy;
+
+extern "C" int vcy_lincomb(const void *x, const void *y, void *out, double a, double b, const double *zero_below, int clip, int64_t C,
+                           int64_t G, int64_t ld, int dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(x && out && C > 0 && G > 0 && ld >= G, "lincomb: bad arguments");
+    VCY_REQUIRE(dtype == VCY_F32 || dtype == VCY_F64, "lincomb: bad dtype");
+    VCY_REQUIRE(ld % (dtype == VCY_F32 ? 4 : 2) == 0, "lincomb: ld must keep rows 16-byte aligned");
+    const int64_t total = C * (ld / (dtype == VCY_F32 ? 4 : 2));
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipStream_t st = as_stream(stream);
+    if (dtype == VCY_F32) hipLaunchKernelGGL(k_lincomb<float>, dim3(blocks), dim3(256), 0, st, (const float *)x, (const float *)y, (float *)out, (float)a, (float)b, zero_below, clip, C, (int)G, ld);
+    else hipLaunchKernelGGL(k_lincomb<double>, dim3(blocks), dim3(256), 0, st, (const double *)x, (const double *)y, (double *)out, a, b, zero_below, clip, C, (int)G, ld);
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}
 
 extern "C" int vcy_velocity_chain(const void *Sx_sz, const void *Ux_sz, const float *gamma, const float *q, const double *eps_thr,
                                   void *Upred, void *velocity, void *delta_S, void *Sx_sz_t, void *dmat, int64_t C, int64_t G,

@@ -26,7 +26,8 @@ hid_t = ctypes.c_int64
 hsize_t = ctypes.c_uint64
 H5F_ACC_RDONLY, H5F_ACC_TRUNC = 0, 2
 H5P_DEFAULT, H5S_ALL = 0, 0
-H5T_INTEGER, H5T_FLOAT, H5T_STRING = 0, 1, 3
+H5T_INTEGER, H5T_FLOAT, H5T_STRING, H5T_ENUM = 0, 1, 3, 8
+H5S_SELECT_SET = 0
 H5_INDEX_NAME, H5_ITER_INC = 0, 0
 H5T_VARIABLE = ctypes.c_size_t(-1).value
 
@@ -62,7 +63,16 @@ def _lib():
                 ("H5Lexists", ctypes.c_int, [hid_t, ctypes.c_char_p, hid_t]),
                 ("H5Gget_num_objs", ctypes.c_int, [hid_t, ctypes.POINTER(hsize_t)]),
                 ("H5Lget_name_by_idx", ctypes.c_ssize_t, [hid_t, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, hsize_t, ctypes.c_char_p, ctypes.c_size_t, hid_t]),
-                ("H5Dvlen_reclaim", ctypes.c_int, [hid_t, hid_t, hid_t, ctypes.c_void_p])):
+                ("H5Dvlen_reclaim", ctypes.c_int, [hid_t, hid_t, hid_t, ctypes.c_void_p]),
+                ("H5Pcreate", hid_t, [hid_t]), ("H5Pset_chunk", ctypes.c_int, [hid_t, ctypes.c_int, ctypes.POINTER(hsize_t)]),
+                ("H5Pset_deflate", ctypes.c_int, [hid_t, ctypes.c_uint]), ("H5Pclose", ctypes.c_int, [hid_t]),
+                ("H5Sselect_hyperslab", ctypes.c_int, [hid_t, ctypes.c_int, ctypes.POINTER(hsize_t), ctypes.POINTER(hsize_t), ctypes.POINTER(hsize_t), ctypes.POINTER(hsize_t)]),
+                ("H5Tenum_create", hid_t, [hid_t]), ("H5Tenum_insert", ctypes.c_int, [hid_t, ctypes.c_char_p, ctypes.c_void_p]),
+                ("H5Tget_nmembers", ctypes.c_int, [hid_t]),
+                ("H5Aget_num_attrs", ctypes.c_int, [hid_t]),
+                ("H5Aopen_by_idx", hid_t, [hid_t, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, hsize_t, hid_t, hid_t]),
+                ("H5Aget_name", ctypes.c_ssize_t, [hid_t, ctypes.c_size_t, ctypes.c_char_p]), ("H5Aget_type", hid_t, [hid_t]),
+                ("H5Aget_space", hid_t, [hid_t]), ("H5Aread", ctypes.c_int, [hid_t, hid_t, ctypes.c_void_p]), ("H5Aclose", ctypes.c_int, [hid_t])):
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
         L._native = {k: hid_t.in_dll(L, f"H5T_NATIVE_{k}_g").value for k in
@@ -110,6 +120,14 @@ def _read_dataset(L, parent: int, name: str) -> np.ndarray:
             L.H5Tclose(tp)
             L.H5Sclose(sp)
             return out
+        elif cls == H5T_ENUM and size == 1:
+            # h5py stores numpy bool arrays as an 8-bit enum {FALSE = 0, TRUE = 1} (what the reference's dump_hdf5 writes for
+            # boolean attributes such as cv_mean_selected; serialization.py:44-92): read the bytes through the file's own type
+            raw = np.empty(shape, dtype=np.int8)
+            _check(L.H5Dread(d, tp, H5S_ALL, H5S_ALL, H5P_DEFAULT, raw.ctypes.data), f"read {name}")
+            L.H5Tclose(tp)
+            L.H5Sclose(sp)
+            return raw.astype(np.bool_)
         else:
             raise IOError(f"dataset {name}: unsupported HDF5 type class {cls}")
         out = np.empty(shape, dtype=dt)
@@ -166,6 +184,127 @@ def read_loom(path: str) -> Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray], 
         L.H5Fclose(f)
 
 
+def read_file_attrs(path: str) -> Dict[str, object]:
+    """File-level attributes of a .loom file: the datasets under /attrs (LOOM_SPEC_VERSION >= 3.0.0) and the HDF5 attributes
+    of the root group (loompy 2 wrote LOOM_SPEC_VERSION, CreationDate, ... there).  Values as str / numpy scalars or arrays."""
+    L = _lib()
+    f = _check(L.H5Fopen(path.encode(), H5F_ACC_RDONLY, H5P_DEFAULT), f"open {path}")
+    out: Dict[str, object] = {}
+    try:
+        root = _check(L.H5Gopen2(f, b"/", H5P_DEFAULT), "open root group")
+        n = L.H5Aget_num_attrs(root)
+        for i in range(max(n, 0)):
+            a = _check(L.H5Aopen_by_idx(root, b".", H5_INDEX_NAME, H5_ITER_INC, i, H5P_DEFAULT, H5P_DEFAULT), "open attribute")
+            ln = L.H5Aget_name(a, 0, None)
+            nb = ctypes.create_string_buffer(ln + 1)
+            L.H5Aget_name(a, ln + 1, nb)
+            tp = L.H5Aget_type(a)
+            cls, size = L.H5Tget_class(tp), L.H5Tget_size(tp)
+            if cls == H5T_STRING:
+                if L.H5Tis_variable_str(tp) > 0:
+                    buf = ctypes.c_char_p()
+                    L.H5Aread(a, tp, ctypes.byref(buf))
+                    out[nb.value.decode()] = (buf.value or b"").decode("utf-8", "replace")
+                else:
+                    raw = ctypes.create_string_buffer(size + 1)
+                    L.H5Aread(a, tp, raw)
+                    out[nb.value.decode()] = raw.value.decode("utf-8", "replace")
+            elif cls in (H5T_INTEGER, H5T_FLOAT):
+                dt = np.dtype(np.float32 if size == 4 else np.float64) if cls == H5T_FLOAT else np.dtype(("u" if L.H5Tget_sign(tp) == 0 else "i") + str(size))
+                v = np.empty((), dtype=dt)
+                L.H5Aread(a, L._native[_NP2H5[dt]], v.ctypes.data)
+                out[nb.value.decode()] = v[()]
+            L.H5Tclose(tp)
+            L.H5Aclose(a)
+        L.H5Gclose(root)
+        g, names = _group_members(L, f, "attrs")
+        if g is not None:
+            for k in names:
+                v = _read_dataset(L, g, k)
+                out[k] = v[()] if getattr(v, "shape", None) == () else v
+            L.H5Gclose(g)
+        return out
+    finally:
+        L.H5Fclose(f)
+
+
+def layer_shape(path: str, layer: str = "spliced") -> Tuple[int, int]:
+    """(genes, cells) of /layers/<layer> without reading it."""
+    L = _lib()
+    f = _check(L.H5Fopen(path.encode(), H5F_ACC_RDONLY, H5P_DEFAULT), f"open {path}")
+    try:
+        d = _check(L.H5Dopen2(f, f"layers/{layer}".encode(), H5P_DEFAULT), f"open layer {layer}")
+        sp = L.H5Dget_space(d)
+        dims = (hsize_t * 2)()
+        L.H5Sget_simple_extent_dims(sp, dims, None)
+        L.H5Sclose(sp)
+        L.H5Dclose(d)
+        return int(dims[0]), int(dims[1])
+    finally:
+        L.H5Fclose(f)
+
+
+def read_layer_block(path: str, layer: str, c0: int, c1: int) -> np.ndarray:
+    """The columns (cells) c0..c1-1 of /layers/<layer>, all genes, as stored: one hyperslab read (chunked / gzip-compressed
+    layers are decoded by the HDF5 library)."""
+    L = _lib()
+    f = _check(L.H5Fopen(path.encode(), H5F_ACC_RDONLY, H5P_DEFAULT), f"open {path}")
+    try:
+        d = _check(L.H5Dopen2(f, f"layers/{layer}".encode(), H5P_DEFAULT), f"open layer {layer}")
+        sp, tp = L.H5Dget_space(d), L.H5Dget_type(d)
+        dims = (hsize_t * 2)()
+        L.H5Sget_simple_extent_dims(sp, dims, None)
+        G, C = int(dims[0]), int(dims[1])
+        if not (0 <= c0 < c1 <= C):
+            raise IndexError(f"cells {c0}:{c1} outside 0:{C}")
+        cls, size = L.H5Tget_class(tp), L.H5Tget_size(tp)
+        dt = (np.dtype(np.float32 if size == 4 else np.float64) if cls == H5T_FLOAT else np.dtype(("u" if L.H5Tget_sign(tp) == 0 else "i") + str(size)))
+        start, count = (hsize_t * 2)(0, c0), (hsize_t * 2)(G, c1 - c0)
+        _check(L.H5Sselect_hyperslab(sp, H5S_SELECT_SET, start, None, count, None), "select hyperslab")
+        msp = L.H5Screate_simple(2, count, None)
+        out = np.empty((G, c1 - c0), dtype=dt)
+        _check(L.H5Dread(d, L._native[_NP2H5[dt]], msp, sp, H5P_DEFAULT, out.ctypes.data), f"read layer {layer}")
+        L.H5Sclose(msp); L.H5Sclose(sp); L.H5Tclose(tp); L.H5Dclose(d)
+        return out
+    finally:
+        L.H5Fclose(f)
+
+
+def read_layer_csr(path: str, layer: str, cell_block: int = 8192, c0: int = 0, c1: Optional[int] = None):
+    """A count layer of a .loom file straight into the device CSR form of the atlas path (ops.CsrCounts, cells-major): the
+    file is read in blocks of `cell_block` cells (hyperslabs of the genes x cells dataset), each block is transposed and
+    compacted on the device, so neither the host nor the device ever holds the dense layer (analysis.py:59-61 loads it
+    whole as float64).  c0:c1 restricts to a range of cells (a rank's shard)."""
+    import torch
+    from . import ops
+    dev = ops.require_gpu()
+    G, C = layer_shape(path, layer)
+    c1 = C if c1 is None else c1
+    ptr, idx, dat = [torch.zeros(1, dtype=torch.int64, device=dev)], [], []
+    base, wide = 0, False
+    for s in range(c0, c1, cell_block):
+        e = min(c1, s + cell_block)
+        blk = read_layer_block(path, layer, s, e)
+        if blk.dtype.kind == "f":
+            if not np.array_equal(blk, np.rint(blk)):
+                raise ValueError(f"layer {layer} holds non-integer values: not a count layer")
+        if blk.size and (blk.min() < 0 or blk.max() > 65535):
+            raise ValueError(f"layer {layer}: counts outside 0..65535 cannot be held as uint16")
+        t = torch.from_numpy(np.ascontiguousarray(blk.astype(np.int32))).to(dev).t().contiguous()          # (cells, genes)
+        nz = t != 0
+        cnt = nz.sum(1)
+        ptr.append(base + torch.cumsum(cnt, 0))
+        base += int(cnt.sum())
+        idx.append(torch.nonzero(nz, as_tuple=False)[:, 1].to(torch.int32))
+        vals = t[nz]
+        wide = wide or bool(vals.numel() and int(vals.max()) > 255)
+        dat.append(vals)
+    cat = lambda xs, dt: torch.cat(xs) if xs else torch.empty(0, dtype=dt, device=dev)
+    vals = cat(dat, torch.int32)
+    data = vals.to(torch.int16) if wide else vals.to(torch.uint8)                                     # int16 holds the uint16 bit pattern
+    return ops.CsrCounts(torch.cat(ptr), cat(idx, torch.int32), data, G)
+
+
 def write_loom(path: str, layers: Dict[str, np.ndarray], col_attrs: Optional[Dict[str, np.ndarray]] = None,
                row_attrs: Optional[Dict[str, np.ndarray]] = None, matrix: Optional[np.ndarray] = None) -> None:
     """Write the layout velocyto's counting pipeline produces (commands/_run.py:283-297): /matrix float32,
@@ -208,7 +347,9 @@ def write_loom(path: str, layers: Dict[str, np.ndarray], col_attrs: Optional[Dic
 # ----------------------------------------------------------------------------------------------------------
 # Flat HDF5 dump / load of a dict of arrays: the container format of velocyto/serialization.py:44-115
 # (every ndarray attribute -> a dataset under its name; anything else -> pickle + zlib -> uint8 dataset "&name").
-def hdf5_dump(path: str, arrays: Dict[str, np.ndarray]) -> None:
+def hdf5_dump(path: str, arrays: Dict[str, np.ndarray], compression: int = 0, chunks: Tuple[int, int] = (2048, 2048)) -> None:
+    """compression > 0: 2-d numeric datasets are written chunked (`chunks`, clipped to the shape) with gzip at that level,
+    like serialization.dump_hdf5's data_compression / chunks (serialization.py:44-92)."""
     L = _lib()
     f = _check(L.H5Fcreate(path.encode(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT), f"create {path}")
     try:
@@ -216,26 +357,42 @@ def hdf5_dump(path: str, arrays: Dict[str, np.ndarray]) -> None:
             arr = np.asarray(arr)
             if arr.dtype.kind in ("U", "O"):
                 arr = np.char.encode(arr.astype(str), "utf-8")
-            if arr.dtype == np.bool_:
-                arr = arr.astype(np.uint8)
+            is_bool = arr.dtype == np.bool_
+            if is_bool:
+                arr = arr.astype(np.int8)
             arr = np.ascontiguousarray(arr)
             nd = max(arr.ndim, 1)
             shape = arr.shape if arr.ndim else (1,)
             dims = (hsize_t * nd)(*shape)
             sp = L.H5Screate_simple(nd, dims, None)
-            if arr.dtype.kind == "S":
+            if is_bool:
+                # the 8-bit enum h5py uses for numpy bools, so that masks come back as bool arrays (and checkpoints stay
+                # interchangeable with files written through h5py by the reference)
+                tp = _check(L.H5Tenum_create(L._native["INT8"]), "H5Tenum_create")
+                for label, val in ((b"FALSE", 0), (b"TRUE", 1)):
+                    v = ctypes.c_int8(val)
+                    _check(L.H5Tenum_insert(tp, label, ctypes.byref(v)), "H5Tenum_insert")
+            elif arr.dtype.kind == "S":
                 tp = L.H5Tcopy(L._c_s1)
                 L.H5Tset_size(tp, max(arr.dtype.itemsize, 1))
             elif arr.dtype in _NP2H5:
                 tp = L._native[_NP2H5[arr.dtype]]
             else:
                 raise TypeError(f"{name}: dtype {arr.dtype} cannot be stored")
-            d = _check(L.H5Dcreate2(f, name.encode(), tp, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT), f"create {name}")
+            dcpl = H5P_DEFAULT
+            if compression > 0 and arr.ndim == 2 and arr.size and arr.dtype.kind != "S":
+                dcpl = _check(L.H5Pcreate(hid_t.in_dll(L, "H5P_CLS_DATASET_CREATE_ID_g").value), "H5Pcreate")
+                ch = (hsize_t * 2)(min(int(chunks[0]), arr.shape[0]), min(int(chunks[1]), arr.shape[1]))
+                _check(L.H5Pset_chunk(dcpl, 2, ch), "H5Pset_chunk")
+                _check(L.H5Pset_deflate(dcpl, min(int(compression), 9)), "H5Pset_deflate")
+            d = _check(L.H5Dcreate2(f, name.encode(), tp, sp, H5P_DEFAULT, dcpl, H5P_DEFAULT), f"create {name}")
+            if dcpl != H5P_DEFAULT:
+                L.H5Pclose(dcpl)
             if arr.size:
                 _check(L.H5Dwrite(d, tp, H5S_ALL, H5S_ALL, H5P_DEFAULT, arr.ctypes.data), f"write {name}")
             L.H5Dclose(d)
             L.H5Sclose(sp)
-            if arr.dtype.kind == "S":
+            if arr.dtype.kind == "S" or is_bool:
                 L.H5Tclose(tp)
     finally:
         L.H5Fclose(f)

@@ -942,6 +942,18 @@ def velocity_chain(Sx_sz: CellMatrix, Ux_sz: CellMatrix, gamma: torch.Tensor, q:
     return {n: m for n, m in outs.items() if m is not None}
 
 
+def lincomb(x: CellMatrix, y: Optional[CellMatrix], a: float, b: float = 0.0, zero_below: Optional[torch.Tensor] = None,
+            clip: bool = False) -> CellMatrix:
+    """a * x + b * y (y may be None), |.| < zero_below[g] -> 0, optionally clipped at 0 (vcy_lincomb): one stage of the
+    velocity chain from its stored predecessor."""
+    assert y is None or (y.t.shape == x.t.shape and y.dtype == x.dtype)
+    out = CellMatrix(torch.empty_like(x.t), x.G)
+    zb = None if zero_below is None else zero_below.to(device=x.t.device, dtype=torch.float64).contiguous()
+    _lib.check(_lib.lib().vcy_lincomb(x.t.data_ptr(), None if y is None else y.t.data_ptr(), out.t.data_ptr(), float(a), float(b), _p(zb),
+                                      int(clip), x.C, x.G, x.ld, x.code, _stream()), "lincomb")
+    return out
+
+
 # --------------------------------------------------------------------------- pre-step + E/F helpers
 def row_sums(M: CellMatrix) -> torch.Tensor:
     """cell sizes: M.sum over genes per cell (S.sum(0) in the reference layout) -> (C,) fp64."""

@@ -24,12 +24,14 @@ def _uint2obj(uint: np.ndarray) -> object:
 
 def dump_hdf5(obj: Any, filename: str, data_compression: int = 7, chunks=(2048, 2048), noarray_compression: int = 9, pickle_protocol: int = 2,
               exclude_attributes=None) -> None:
-    """serialization.py:44-97 for a VelocytoLoom of this package (compression arguments are accepted; libhdf5 is driven with
-    its defaults; `exclude_attributes` is an extension)."""
-    obj.to_hdf5(filename, exclude=set(exclude_attributes or ()))
+    """serialization.py:44-97 for a VelocytoLoom of this package: 2-d datasets chunked + gzip (`data_compression`, `chunks`),
+    everything that is not an array pickled with `pickle_protocol` and zlib level `noarray_compression`
+    (`exclude_attributes` is an extension)."""
+    obj.to_hdf5(filename, exclude=set(exclude_attributes or ()), data_compression=data_compression, chunks=chunks,
+                noarray_compression=noarray_compression, pickle_protocol=pickle_protocol)
 
 
 def load_hdf5(filename: str, obj_class: type = None, dtype=None):
-    """serialization.py:100-115."""
+    """serialization.py:100-115: `obj_class` (VelocytoLoom or a subclass) is the class that is instantiated."""
     from .analysis import load_velocyto_hdf5
-    return load_velocyto_hdf5(filename, dtype=dtype)
+    return load_velocyto_hdf5(filename, dtype=dtype, obj_class=obj_class)
