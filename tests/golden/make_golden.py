@@ -446,10 +446,45 @@ def golden_preprocess(ana):
     save("preprocess", **{k: np.asarray(v) for k, v in out.items()})
 
 
+CFG1_SEED, CFG1_G, CFG1_C, CFG1_P, CFG1_K = 20180813, 2000, 3000, 20, 30
+
+
+def cfg1_inputs():
+    """BASELINE.json configs[0] stand-in (DentateGyrus.loom is not available offline): 3000 cells x 2000 genes
+    of seeded synthetic counts and a 20-d search space derived from the same latent time.  Pure NumPy from a PCG64 seed, so
+    tests/test_gpu_fullsize.py regenerates the identical arrays on the GPU box; only the reference's OUTPUTS are stored."""
+    rng = np.random.default_rng(CFG1_SEED)
+    S, U, t = synth_counts(rng, CFG1_G, CFG1_C)
+    pcs = np.concatenate([np.stack([8.0 * t, 3.0 * np.sin(3.0 * t)], 1), rng.normal(0, 0.25, (CFG1_C, CFG1_P - 2))], 1) + rng.normal(0, 0.05, (CFG1_C, CFG1_P))
+    return S, U, pcs
+
+
+def golden_cfg1(ana):
+    """fit_gammas() with its defaults (maxmin_diag weights, weighted offset fit by L-BFGS-B; analysis.py:1120-1260,
+    estimation.py:212-241, 337-366) at cfg1 size.  Stored: gammas, q, R2 (float32) + checksums of the pooled matrices."""
+    S, U, pcs = cfg1_inputs()
+    vlm = make_vlm(ana, S, U)
+    vlm.normalize("both", size=True, log=True)
+    vlm.pcs = pcs
+    vlm.knn_imputation(k=CFG1_K, n_pca_dims=CFG1_P, n_jobs=4)
+    vlm.fit_gammas()
+    save("cfg1", gammas=vlm.gammas, q=vlm.q, R2=vlm.R2, seed=np.asarray(CFG1_SEED), shape=np.asarray([CFG1_G, CFG1_C, CFG1_P, CFG1_K]),
+         Sx_sum=np.asarray(vlm.Sx_sz.sum()), Ux_sum=np.asarray(vlm.Ux_sz.sum()), Sx_row17=np.ascontiguousarray(vlm.Sx_sz[17]),
+         knn_row0=np.sort(vlm.knn[0].indices))
+
+
 if __name__ == "__main__":
     est, nb, dif, ana = load_reference()
-    golden_coldeltacor(est)
-    golden_fits(est)
-    golden_neighbors(nb)
-    golden_pipeline(ana, dif)
-    golden_preprocess(ana)
+    which = set(sys.argv[1:])
+    if not which or "coldeltacor" in which:
+        golden_coldeltacor(est)
+    if not which or "fits" in which:
+        golden_fits(est)
+    if not which or "neighbors" in which:
+        golden_neighbors(nb)
+    if not which or "pipeline" in which:
+        golden_pipeline(ana, dif)
+    if not which or "preprocess" in which:
+        golden_preprocess(ana)
+    if not which or "cfg1" in which:
+        golden_cfg1(ana)

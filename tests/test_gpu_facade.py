@@ -5,7 +5,8 @@ reference's own run (tests/golden/pipeline.npz, fits.npz, neighbors.npz, coldelt
 f64 storage reproduces the reference to rounding; f32 storage (production) to the stated f32
 tolerances.  The weighted-offset gamma fit is compared (a) exactly against the oracle's closed-form
 solution of the same box-constrained problem and (b) loosely against the reference's L-BFGS-B
-stopping point (rtol 1e-4 with <= 5 % outliers, worst 2e-2: SURVEY.md section 7).
+stopping point (rtol 1e-4 with at most one outlier among the 90 genes here, <= 1 % of 2000 genes at cfg1 size in
+test_gpu_fullsize.py; worst 2e-2: SURVEY.md section 7).
 """
 import numpy as np
 import pytest
@@ -91,7 +92,8 @@ def test_facade_fit_gammas(vcy, golden, oracle, dtype):
     close(vlm.gammas, g["gammas_plain"], gt, 0)
     assert np.all(vlm.q == 0)
 
-    def loose(got, ref, frac=0.05, worst=2e-2):
+    def loose(got, ref, frac=1.5 / 90, worst=2e-2):          # at most ONE gene of this 90-gene fixture (the <= 1 % bar of SURVEY section 7
+                                                             # is enforced on 2000 genes in test_gpu_fullsize.py::test_cfg1_*)
         rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)
         assert np.mean(rel > 1e-4) <= frac and rel.max() < worst, (np.mean(rel > 1e-4), rel.max())
 
