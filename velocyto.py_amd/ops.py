@@ -668,7 +668,7 @@ def knn_search(space, k: int, include_self: bool = False, q0: int = 0, Q: Option
     """Exact Euclidean kNN of rows q0..q0+Q of `space` (C, P) among all C rows.
     Returns (idx int32 (Q,k), dist float64 (Q,k)), nearest first, ties by index."""
     dev = require_gpu()
-    x64 = (torch.from_numpy(np.ascontiguousarray(space, dtype=np.float64)) if not isinstance(space, torch.Tensor) else space.double()).to(dev).contiguous()
+    x64 = (torch.from_numpy(np.array(space, dtype=np.float64, order="C")) if not isinstance(space, torch.Tensor) else space.double()).to(dev).contiguous()
     C, P = x64.shape
     Q = C - q0 if Q is None else Q
     ldx = (C + 63) // 64 * 64
@@ -689,7 +689,7 @@ def knn_search(space, k: int, include_self: bool = False, q0: int = 0, Q: Option
 def knn_query(points, queries, k: int, query_block: int = 8192) -> Tuple[torch.Tensor, torch.Tensor]:
     """k nearest of `points` (C, P) for every row of `queries` (Q, P): (idx int32 (Q,k), dist float64 (Q,k))."""
     dev = require_gpu()
-    to64 = lambda a: (torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)) if not isinstance(a, torch.Tensor) else a.double()).to(dev).contiguous()
+    to64 = lambda a: (torch.from_numpy(np.array(a, dtype=np.float64, order="C")) if not isinstance(a, torch.Tensor) else a.double()).to(dev).contiguous()
     x64, q64 = to64(points), to64(queries)
     C, P = x64.shape
     Q = q64.shape[0]
