@@ -688,3 +688,21 @@ def test_coldeltacor_partial_fused_dual(ops, dtype):
     f1, f2 = ops.coldeltacor_partial_fused_dual(Sx, Ux, gam, q, D2, ixs, ops.SQRT, ops.RULES_PARTIAL, 1e-10)
     eq = lambda a, b: torch.equal(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b, nan=7.0))    # (self pairs are NaN in both)
     assert eq(r1, f1) and eq(r2, f2)                             # same kernel, d[c] staged from dmat or evaluated on the fly
+
+
+def test_knn_search_segmented_equals_one_launch(ops, monkeypatch):
+    """Point sets beyond one launch's candidate range are searched in segments and merged (ops._knn_search_segmented):
+    same neighbours, same order (ties by index), same fp64 distances as the one-launch search."""
+    rng = np.random.default_rng(3)
+    C, P, k = 3000, 7, 12
+    X = rng.normal(size=(C, P))
+    X[100] = X[7]; X[2000] = X[7]; X[2999] = X[1500]          # exact duplicates across segments: distance ties at 0
+    X[:, 3] = np.round(X[:, 3], 1)                               # and many exact ties at positive distances
+    ref_i, ref_d = ops.knn_search(X, k, include_self=False)
+    ref_is, ref_ds = ops.knn_search(X, k, include_self=True, q0=500, Q=700)
+    for seg in (1024, 999, 2990):                                # the last one leaves a segment shorter than k + 1
+        monkeypatch.setattr(ops, "KNN_SEGMENT", seg)
+        i, d = ops.knn_search(X, k, include_self=False)
+        assert torch.equal(i, ref_i) and torch.equal(d, ref_d), seg
+        i, d = ops.knn_search(X, k, include_self=True, q0=500, Q=700)
+        assert torch.equal(i, ref_is) and torch.equal(d, ref_ds), seg

@@ -137,6 +137,7 @@ class AtlasPath:
         self.gamma = None
         self.stage_ms = np.zeros(4)
         self._resident = None
+        self._plan = None
         self.peak_block_bytes = 0
 
     # ------------------------------------------------------------------ pooling of arbitrary E rows
@@ -159,11 +160,34 @@ class AtlasPath:
     def blocks(self) -> List[Tuple[int, int]]:
         return [(b, min(self.nloc, b + self.block_cells)) for b in range(0, self.nloc, self.block_cells)]
 
+    def _plan_blocks(self) -> None:
+        """Per block, once per graph: the e rows it reads outside itself (E-row numbers, ascending global number) and its
+        neighbour lists in the numbering of its buffer [block | outside]; and the two buffers every block reuses."""
+        self._plan = []
+        single = len(self.blocks()) == 1
+        max_rows, max_nb = 0, 0
+        for (b0, b1) in self.blocks():
+            nb_ix = self.neigh[b0:b1]
+            if single:
+                erows_out = torch.arange(self.nloc, self.nloc + self.n_e_halo, device=self.dev)
+                ixs = ops.localize_rows(nb_ix, self.c0, self.c1, self.e_out)
+            else:
+                g = torch.unique(nb_ix.reshape(-1).long())                           # ascending global numbers
+                outside = g[(g < self.c0 + b0) | (g >= self.c0 + b1)]
+                erows_out = self._e_rows_of(outside)
+                ixs = ops.localize_rows(nb_ix, self.c0 + b0, self.c0 + b1, outside)
+            self._plan.append((b0, b1, erows_out, ixs))
+            max_rows, max_nb = max(max_rows, (b1 - b0) + int(erows_out.numel())), max(max_nb, b1 - b0)
+        self._ebuf = ops.CellMatrix.empty(max_rows, self.G, self.dtype)
+        self._ubuf = ops.CellMatrix.empty(max_nb, self.G, self.dtype)
+        self.peak_block_bytes = (self._ebuf.t.numel() + self._ubuf.t.numel()) * self._ebuf.t.element_size()
+
     # ------------------------------------------------------------------ one pass of the path
     def run(self, timed: bool = False) -> torch.Tensor:
         dev, G = self.dev, self.G
-        blocks = self.blocks()
-        single = len(blocks) == 1
+        if self._plan is None:
+            self._plan_blocks()
+        single = len(self._plan) == 1
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         tA = tB = tD = tK = 0.0
         # ---- A, first half: the exact kNN search of the own cells among all cells (analysis.py:1005).  The graph of a dataset
@@ -177,22 +201,15 @@ class AtlasPath:
             tK = ev[0].elapsed_time(ev[1])
         # ---- pass 1: A (pooling of the own cells) + B (fit_slope moments, estimation.py:267-279), block by block
         mom = torch.zeros((3, G), dtype=torch.float64, device=dev)
-        keep = None
-        for (b0, b1) in blocks:
+        for (b0, b1, erows_out, ixs) in self._plan:
             nb = b1 - b0
-            n_out = self.n_e_halo if single else 0
             ev[0].record()
-            e_buf = ops.CellMatrix.empty(nb + n_out, G, self.dtype)
-            Sx_b = e_buf.rows(0, nb)
-            Ux_b = ops.CellMatrix.empty(nb, G, self.dtype)
+            Sx_b, Ux_b = self._ebuf.rows(0, nb), self._ubuf.rows(0, nb)
             self._pool(self.cS, self.fS, slice(b0, b1), Sx_b)
             self._pool(self.cU, self.fU, slice(b0, b1), Ux_b)
             ev[1].record()
             mom += ops.fit_slope_moments(Ux_b, Sx_b)
             ev[2].record()
-            self.peak_block_bytes = max(self.peak_block_bytes, (e_buf.t.numel() + Ux_b.t.numel()) * e_buf.t.element_size())
-            if single:
-                keep = (e_buf, Ux_b)
             if timed:
                 torch.cuda.synchronize()
                 tA += ev[0].elapsed_time(ev[1]); tB += ev[1].elapsed_time(ev[2])
@@ -203,25 +220,16 @@ class AtlasPath:
         if timed:
             torch.cuda.synchronize()
             tB += ev[0].elapsed_time(ev[1])
-        # ---- pass 2: C + D per block.  e rows = [block | sampled neighbours outside the block]
-        for (b0, b1) in blocks:
-            nb = b1 - b0
-            nb_ix = self.neigh[b0:b1]
+        # ---- pass 2: C + D per block.  e rows = [block | sampled neighbours outside the block]; one block = everything is
+        #      still in the buffers from pass 1 (resident mode) and only the halo rows are pooled
+        for (b0, b1, erows_out, ixs) in self._plan:
+            nb, n_out = b1 - b0, int(erows_out.numel())
             ev[0].record()
-            if single:
-                e_buf, Ux_b = keep
-                self._pool(self.cS, self.fS, slice(self.nloc, self.nloc + self.n_e_halo), e_buf.rows(nb, nb + self.n_e_halo))   # the E halo rows
-                ixs = ops.localize_rows(nb_ix, self.c0, self.c1, self.e_out)
-            else:
-                g = torch.unique(nb_ix.reshape(-1).long())                           # ascending global numbers
-                outside = g[(g < self.c0 + b0) | (g >= self.c0 + b1)]
-                e_buf = ops.CellMatrix.empty(nb + int(outside.numel()), G, self.dtype)
-                Ux_b = ops.CellMatrix.empty(nb, G, self.dtype)
+            e_buf, Ux_b = self._ebuf.rows(0, nb + n_out), self._ubuf.rows(0, nb)
+            if not single:
                 self._pool(self.cS, self.fS, slice(b0, b1), e_buf.rows(0, nb))
-                self._pool(self.cS, self.fS, self._e_rows_of(outside), e_buf.rows(nb, nb + int(outside.numel())))
                 self._pool(self.cU, self.fU, slice(b0, b1), Ux_b)
-                ixs = ops.localize_rows(nb_ix, self.c0 + b0, self.c0 + b1, outside)
-                self.peak_block_bytes = max(self.peak_block_bytes, (e_buf.t.numel() + Ux_b.t.numel()) * e_buf.t.element_size())
+            self._pool(self.cS, self.fS, erows_out, e_buf.rows(nb, nb + n_out))
             ev[1].record()
             ops.coldeltacor_partial_fused(e_buf, Ux_b, gamma, None, ixs, ops.SQRT, ops.RULES_PARTIAL, self.psc, cell0=0, u_row0=0,
                                           out=self.corr[b0:b1], validate=False)
@@ -230,7 +238,7 @@ class AtlasPath:
                 torch.cuda.synchronize()
                 tA += ev[0].elapsed_time(ev[1]); tD += ev[1].elapsed_time(ev[2])
         if single:
-            self._resident = keep
+            self._resident = (self._ebuf, self._ubuf)
         if timed:
             self.stage_ms += np.array([tA, tB, tK, tD])
         return self.corr

@@ -671,6 +671,8 @@ def knn_search(space, k: int, include_self: bool = False, q0: int = 0, Q: Option
     x64 = (torch.from_numpy(np.array(space, dtype=np.float64, order="C")) if not isinstance(space, torch.Tensor) else space.double()).to(dev).contiguous()
     C, P = x64.shape
     Q = C - q0 if Q is None else Q
+    if C > KNN_SEGMENT and k + 9 <= 128:
+        return _knn_search_segmented(x64, k, include_self, q0, Q, query_block)
     ldx = (C + 63) // 64 * 64
     xt = torch.zeros((P, ldx), dtype=torch.float32, device=dev)
     xt[:, :C] = x64.t().float()
@@ -683,6 +685,49 @@ def knn_search(space, k: int, include_self: bool = False, q0: int = 0, Q: Option
         n = min(qb, Q - s)
         _lib.check(L.vcy_knn_search(xt.data_ptr(), x64.data_ptr(), idx[s:s + n].data_ptr(), dist[s:s + n].data_ptr(), ws.data_ptr(),
                                     C, P, ldx, q0 + s, n, k, int(include_self), _stream()), "knn_search")
+    return idx, dist
+
+
+# The row-free search kernel keeps a candidate's position inside its thread's strided slice in the low 10 mantissa bits of
+# the tracked distance words, which caps one launch at 1022 x 256 candidates; larger point sets (atlas scale) are searched
+# segment by segment and the per-segment lists merged.  The alternative inside the library - materialising the (queries x
+# candidates) distance rows - measured 9 x slower per candidate at 400k cells.
+KNN_SEGMENT = 1008 * 256
+
+
+def _knn_search_segmented(x64: torch.Tensor, k: int, include_self: bool, q0: int, Q: int, query_block: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Exact kNN over more than KNN_SEGMENT candidates: the queries against every segment of the point set (vcy_knn_query,
+    k + 1 nearest, nothing excluded), then a merge by (distance, index) and the removal of the query itself.  Distances are
+    the same exact fp64 sums the one-launch search returns, every segment's list is sorted by (distance, index) and segments
+    are visited in index order, so a stable sort by distance reproduces the one-launch order, ties by index included."""
+    C = x64.shape[0]
+    kk = k if include_self else k + 1
+    qs = x64[q0:q0 + Q]
+    ds, ix = [], []
+    for s0 in range(0, C, KNN_SEGMENT):
+        s1 = min(C, s0 + KNN_SEGMENT)
+        if s1 - s0 <= kk:                                   # a short last segment: borrow from the previous one
+            s0 = max(0, s1 - kk - 1)
+        i, d = knn_query(x64[s0:s1], qs, kk, query_block)
+        ds.append(d)
+        ix.append(i + s0)
+    d_all, order = torch.sort(torch.cat(ds, 1), dim=1, stable=True)
+    i_all = torch.gather(torch.cat(ix, 1), 1, order)
+    keep = torch.ones_like(i_all, dtype=torch.bool)
+    if not include_self:
+        keep = i_all != torch.arange(q0, q0 + Q, device=i_all.device, dtype=i_all.dtype)[:, None]
+    # a borrowed overlap lists a candidate twice (adjacent after the sort): keep its first copy
+    dup = torch.zeros_like(keep)
+    dup[:, 1:] = (i_all[:, 1:] == i_all[:, :-1]) & (d_all[:, 1:] == d_all[:, :-1])
+    keep &= ~dup
+    pos = torch.cumsum(keep.to(torch.int32), 1)
+    sel = keep & (pos <= k)
+    rows, cols = torch.nonzero(sel, as_tuple=True)
+    idx = torch.empty((Q, k), dtype=torch.int32, device=x64.device)
+    dist = torch.empty((Q, k), dtype=torch.float64, device=x64.device)
+    dst = (pos[rows, cols] - 1).long()
+    idx[rows, dst] = i_all[rows, cols]
+    dist[rows, dst] = d_all[rows, cols]
     return idx, dist
 
 
