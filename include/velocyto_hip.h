@@ -182,6 +182,10 @@ int vcy_knn_pool_csr(const int64_t *indptr, const int32_t *indices, const void *
  * Any k < C: candidate lists up to ~4k entries are sorted in LDS, larger ones in the workspace.
  * workspace: vcy_knn_workspace_bytes(C, Q, k) bytes.                                     */
 size_t vcy_knn_workspace_bytes(int64_t C, int64_t Q, int64_t k);
+/* 1 when a search of k neighbours among C points takes the kernel that keeps its candidates in registers (k + 8 <= 128,
+ * C <= 261 632): its workspace is one scratch row per 8 queries, so all queries fit one launch; 0: the (Q, C) distance
+ * rows are materialised and callers walk the queries in blocks.                                                        */
+int vcy_knn_row_free(int64_t C, int64_t k);
 int vcy_knn_search(const float *xt, const double *x64, int32_t *idx, double *dist, void *workspace,
                    int64_t C, int64_t P, int64_t ldx, int64_t q0, int64_t Q, int64_t k, int include_self,
                    vcy_stream stream);

@@ -48,6 +48,7 @@ SIGNATURES = {
     "vcy_knn_pool_csr": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64,
                                  c_int, c_int, c_int, c_vp]),
     "vcy_knn_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
+    "vcy_knn_row_free": (c_int, [c_i64, c_i64]),
     "vcy_knn_search": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_vp]),
     "vcy_knn_query": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp]),
     "vcy_balance_knn_host": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp]),

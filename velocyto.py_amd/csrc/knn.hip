@@ -42,7 +42,7 @@ namespace vcy {
 constexpr int KNN_QB = 8;
 constexpr int KNN_MAXSEL = 4096;
 constexpr int KNN_MARGIN = 8;
-constexpr int KNN_NC = 2;          // candidates per thread per pass of the distance loop
+constexpr int KNN_NC = 4;          // candidates per thread per pass of the distance loop
 
 __device__ __forceinline__ uint32_t f32_key(float f)
 {
@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void k_knn_search(const float *__restrict__ xt
         for (int c = 0; c < KNN_NC; ++c)
 #pragma unroll
             for (int qq = 0; qq < KNN_QB; ++qq) acc[c][qq] = 0.f;
+#pragma unroll 4
         for (int p = 0; p < P; ++p) {
             float xv[KNN_NC];
 #pragma unroll
@@ -383,14 +384,32 @@ static int knn_plan(int64_t C, int64_t k, int include_self, int64_t *ksel_out, i
     return 0;
 }
 
+// does this search take the kernel that never materialises the distance rows?
+static bool knn_row_free(int64_t C, int64_t ksel, bool large, int *nb_out)
+{
+    int nb = 1;                                                   // bits for a thread's slice position: jc = tid + 256 * pos
+    while (((int64_t)1 << nb) < (C + 255) / 256 + KNN_NC) ++nb;
+    if (nb_out) *nb_out = nb;
+    // the threshold comes from 2 words per thread: with Ksel near 512 it is loose and most threads overflow
+    return !(large || ksel > 128 || nb > 10 || env_int("VCY_KNN_ROWS", 0) == 1);   // VCY_KNN_ROWS=1 forces the row kernel (A/B testing)
+}
+
 extern "C" size_t vcy_knn_workspace_bytes(int64_t C, int64_t Q, int64_t k)
 {
     const int64_t qpad = (Q + KNN_QB - 1) / KNN_QB * KNN_QB;
-    size_t bytes = (size_t)qpad * (size_t)C * sizeof(float);
     int64_t ksel; int nsort; bool large;
     knn_plan(C, k, 1, &ksel, &nsort, &large);
+    // row-free kernel: one scratch row per workgroup (the rare fallback of a single query); otherwise the (Q, C) distance rows
+    size_t bytes = (size_t)(knn_row_free(C, ksel, large, nullptr) ? qpad / KNN_QB : qpad) * (size_t)C * sizeof(float);
     if (large) bytes += (size_t)(qpad / KNN_QB) * (size_t)nsort * (sizeof(double) + sizeof(int)) + 256;
     return bytes;
+}
+
+extern "C" int vcy_knn_row_free(int64_t C, int64_t k)
+{
+    int64_t ksel; int nsort; bool large;
+    knn_plan(C, k, 1, &ksel, &nsort, &large);
+    return knn_row_free(C, ksel, large, nullptr) ? 1 : 0;
 }
 
 static int knn_search_impl(const float *xt, const double *x64, const float *qt, const double *q64, int64_t ldq, int32_t *idx, double *dist,
@@ -404,15 +423,12 @@ static int knn_search_impl(const float *xt, const double *x64, const float *qt, 
     int64_t ksel; int nsort; bool large;
     knn_plan(C, k, include_self, &ksel, &nsort, &large);
     const int64_t qpad = (Q + KNN_QB - 1) / KNN_QB * KNN_QB;
-    char *ws_sort = (char *)workspace + (((size_t)qpad * (size_t)C * sizeof(float) + 255) & ~(size_t)255);
+    char *ws_sort = (char *)workspace + (((size_t)qpad * (size_t)C * sizeof(float) + 255) & ~(size_t)255);      // (large searches always hold the rows)
     const unsigned blocks = (unsigned)((Q + KNN_QB - 1) / KNN_QB);
     const size_t lds = (large ? 0 : (size_t)nsort * (sizeof(double) + sizeof(int))) + (size_t)KNN_QB * P * sizeof(float);
     VCY_REQUIRE(lds <= 150 * 1024, "knn_search: feature dimension too large for LDS");
-    int nb = 1;                                                   // bits for a thread's slice position: jc = tid + 256 * pos
-    while (((int64_t)1 << nb) < (C + 255) / 256 + KNN_NC) ++nb;
-    const int rows_pref = env_int("VCY_KNN_ROWS", 0);             // VCY_KNN_ROWS=1 forces the row-materialising kernel (A/B testing)
-    // the threshold comes from 2 words per thread: with Ksel near 512 it is loose and most threads overflow
-    const bool rows = large || ksel > 128 || nb > 10 || rows_pref == 1;
+    int nb = 1;
+    const bool rows = !knn_row_free(C, ksel, large, &nb);
 #define VCY_KNN_LAUNCH(L, R)                                                                                                       \
     do {                                                                                                                           \
         { const int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(k_knn_search<L, R>), lds); if (rc_) return rc_; }    \

@@ -663,6 +663,14 @@ def knn_pool_counts(cS: CountMatrix, cU: Optional[CountMatrix], scaleS, scaleU, 
     return (out, out2) if cU is not None else out
 
 
+def _knn_query_block(L, C: int, Q: int, k: int, query_block: int, budget: int = 8 << 30) -> int:
+    """Queries per launch: everything at once (up to `budget` bytes of scratch rows) when the search keeps its candidates
+    in registers, `query_block` when it materialises the distance rows."""
+    if not L.vcy_knn_row_free(C, k):
+        return min(Q, query_block)
+    return min(Q, max(query_block, (2 * budget // max(C, 1)) // 8 * 8))
+
+
 def knn_search(space, k: int, include_self: bool = False, q0: int = 0, Q: Optional[int] = None,
                query_block: int = 8192) -> Tuple[torch.Tensor, torch.Tensor]:
     """Exact Euclidean kNN of rows q0..q0+Q of `space` (C, P) among all C rows.
@@ -679,7 +687,10 @@ def knn_search(space, k: int, include_self: bool = False, q0: int = 0, Q: Option
     idx = torch.empty((Q, k), dtype=torch.int32, device=dev)
     dist = torch.empty((Q, k), dtype=torch.float64, device=dev)
     L = _lib.lib()
-    qb = min(Q, query_block)
+    # the register-resident search needs one scratch row per 8 queries: all queries in ONE launch (6250 workgroups at 50k
+    # cells, so that the selection phase of one workgroup overlaps the distance phase of others); the row-materialising
+    # search holds (queries x C) distances and walks the queries in blocks
+    qb = _knn_query_block(L, C, Q, k, query_block)
     ws = torch.empty(int(L.vcy_knn_workspace_bytes(C, qb, k)), dtype=torch.uint8, device=dev)
     for s in range(0, Q, qb):
         n = min(qb, Q - s)
@@ -747,7 +758,7 @@ def knn_query(points, queries, k: int, query_block: int = 8192) -> Tuple[torch.T
     idx = torch.empty((Q, k), dtype=torch.int32, device=dev)
     dist = torch.empty((Q, k), dtype=torch.float64, device=dev)
     L = _lib.lib()
-    qb = min(Q, query_block)
+    qb = _knn_query_block(L, C, Q, k, query_block)
     ws = torch.empty(int(L.vcy_knn_workspace_bytes(C, qb, k)), dtype=torch.uint8, device=dev)
     for s in range(0, Q, qb):
         n = min(qb, Q - s)
