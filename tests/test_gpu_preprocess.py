@@ -224,3 +224,30 @@ def test_default_drivers(vcy, golden, dtype):
     close(vf.Sx_sz, g["dfp_Sx_sz"], 1e-8, 1e-9)
     close(vf.Ux_sz, g["dfp_Ux_sz"], 2e-6, 1e-9)
     assert int(np.where(np.diff(np.diff(np.cumsum(vf.pca.explained_variance_ratio_)) > 0.002))[0][0]) == int(g["dfp_n_comps_rule"])
+
+
+def test_pca_subspace_iteration_matches_the_exact_route():
+    """perform_PCA on wide input: the converged subspace iteration that replaces the O(G^3) covariance
+    eigensolver when few components of a large matrix are asked for (scikit-learn's own `auto` rule switches to a
+    randomised solver there) against the exact route on the same matrix."""
+    import velocyto_amd
+    from velocyto_amd import ops
+    from velocyto_amd.preprocess import DevicePCA
+    dev = ops.require_gpu()
+    gen = torch.Generator(device=dev).manual_seed(5)
+    C, G, r = 6000, 5000, 12
+    # low-rank signal with a decaying spectrum + noise: a gap behind the leading components, like real expression data
+    L = torch.randn((C, r), generator=gen, device=dev, dtype=torch.float64) * torch.linspace(12, 3, r, device=dev, dtype=torch.float64)
+    X = L @ torch.randn((r, G), generator=gen, device=dev, dtype=torch.float64) + torch.randn((C, G), generator=gen, device=dev, dtype=torch.float64) + 2.0
+    M = ops.CellMatrix.from_cells_major(X, torch.float64)
+    exact = DevicePCA(n_components=10, svd_solver="full")
+    p_exact = exact.fit_transform(M)
+    auto = DevicePCA(n_components=10)                       # min(C, G) > 4096 and 10 << 5000: takes the subspace route
+    p_auto = auto.fit_transform(M)
+    assert hasattr(auto, "n_iter_") and not hasattr(exact, "n_iter_") and auto.n_iter_ < 60
+    np.testing.assert_allclose(auto.explained_variance_, exact.explained_variance_, rtol=1e-8)
+    np.testing.assert_allclose(auto.explained_variance_ratio_, exact.explained_variance_ratio_, rtol=1e-8)
+    np.testing.assert_allclose(np.abs(np.sum(auto.components_ * exact.components_, 1)), 1.0, atol=1e-8)      # same directions
+    np.testing.assert_allclose(auto.components_, exact.components_, atol=1e-6)                                  # same signs (svd_flip)
+    np.testing.assert_allclose(p_auto, p_exact, atol=1e-5 * np.abs(p_exact).max())
+    np.testing.assert_allclose(auto.mean_, exact.mean_, rtol=1e-13)

@@ -559,6 +559,12 @@ def _coldeltacor_full_linear_gemm(e: CellMatrix, d: CellMatrix, cell0: int, C_ou
         r = cov / torch.sqrt(va * vb)
         idx = torch.arange(r0, r1, device=r.device)
         r[idx - r0, cell0 + idx] = float("nan")
+        # duplicate cells (e_i == e_c) and constant d_c: the reference's centred sums are exactly zero there (0 * inf = NaN);
+        # the expanded moments leave rounding noise of either sign - treat variances below the noise floor of the
+        # expansion (a few ulps of the terms that cancel) as zero
+        noise_a = 64 * torch.finfo(torch.float64).eps * (See[None, :] + See[cell0 + r0:cell0 + r1, None])
+        noise_b = (64 * torch.finfo(torch.float64).eps * sbb)[:, None]
+        r[(va <= noise_a) | (vb <= noise_b)] = float("nan")
         r = r.to(rm.dtype)
         if accumulate:
             rm[r0:r1] += r
