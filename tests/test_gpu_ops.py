@@ -87,6 +87,8 @@ def test_coldeltacor_full_golden(ops, golden, dtype, key, transform, psc_key):
     degenerate = np.eye(C, dtype=bool)
     degenerate[3, 7] = degenerate[7, 3] = True
     np.testing.assert_allclose(rm[~degenerate], ref[~degenerate], atol=CORR_ATOL[dtype])
+    if transform in ("linear", "sqrt"):      # identical cells 3 and 7: zero variance of A -> NaN, as the reference's 0 * inf (also on the GEMM route)
+        assert np.isnan(rm[3, 7]) and np.isnan(rm[7, 3]) and np.isnan(rm[5, 5])
     # row-block + accumulate semantics (rm[c,i] += ...)
     blk = ops.coldeltacor_full(e, d, ops.TRANSFORMS[transform], psc, cell0=8, C_out=17)
     if transform == "linear":      # library GEMM: a row block may be tiled differently from the full product

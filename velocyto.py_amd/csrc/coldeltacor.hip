@@ -67,11 +67,14 @@ template <> __device__ __forceinline__ float xform<float, VCY_SQRT, VCY_RULES_PA
 // accumulate A[g] - K with K = f(0), the value of the transform where the two cells agree (log10(psc) = -10 for the
 // default psc of 1e-10).  On count data most genes of a pair agree, so without the shift sum A^2 and (sum A)^2 / n are
 // two numbers near 100 n whose difference - the variance - sits in the last digits of an f32 accumulator; with it the
-// agreeing genes contribute exact zeros and the single-pass raw moments keep their accuracy in f32.  sqrt and linear
-// have f(0) = 0 (or -sqrt(psc), 1e-5) and need no shift.
+// agreeing genes contribute exact zeros and the single-pass raw moments keep their accuracy in f32.  The full-rule sqrt
+// variant has f(0) = -sqrt(psc) (t > 0 fails at 0): shifted too, so that identical cells give an exact zero variance
+// (NaN, like the reference's centred sums) instead of f32 rounding noise.  Partial sqrt and linear have f(0) = 0.
+template <int TR, int RULES> struct Shifted { static constexpr bool value = TR == VCY_LOG10 || (TR == VCY_SQRT && RULES == VCY_RULES_FULL); };   // f(0) != 0
+
 template <typename T, int TR, int RULES> __device__ __forceinline__ T xform_shift(T psc)
 {
-    if (TR != VCY_LOG10) return T(0);
+    if (!Shifted<TR, RULES>::value) return T(0);
     const T k = xform<T, TR, RULES>(T(0), psc);
     return (k - k == T(0)) ? k : T(0);             // psc = 0 gives -inf: every agreeing gene is NaN in the reference as well
 }
@@ -93,7 +96,7 @@ template <> __device__ __forceinline__ float xform_shift<float, VCY_LOG10, VCY_R
 template <typename T, int TR, int RULES> __device__ __forceinline__ T xform_s(T t, T psc, T K)
 {
     const T a = xform<T, TR, RULES>(t, psc);
-    return TR == VCY_LOG10 ? a - K : a;
+    return Shifted<TR, RULES>::value ? a - K : a;
 }
 template <> __device__ __forceinline__ float xform_s<float, VCY_LOG10, VCY_RULES_PARTIAL>(float t, float psc, float K)
 {
