@@ -74,6 +74,7 @@ def parse():
                     help="cfg3: dense count layers, everything resident (the headline); cfg5: CSR layers, block-streamed (atlas.py)")
     ap.add_argument("--density", type=float, default=0.08, help="cfg5: fraction of non-zero counts per cell")
     ap.add_argument("--block-cells", type=int, default=0, help="cfg5: cells per streamed block (0 = chosen from free HBM)")
+    ap.add_argument("--knn", choices=["auto", "brute", "pruned"], default="auto", help="cfg5: exact kNN search by brute force or projection-pruned (auto: pruned from 100k cells)")
     ap.add_argument("--counts", choices=["auto", "u16"], default="auto",
                     help="storage of the resident count layers: auto = uint8 when no count exceeds 255, else uint16; u16 forces uint16")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32", help="arithmetic / storage type of the path (f64 = the reference's)")

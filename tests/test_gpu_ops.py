@@ -708,3 +708,26 @@ def test_knn_search_segmented_equals_one_launch(ops, monkeypatch):
         assert torch.equal(i, ref_i) and torch.equal(d, ref_d), seg
         i, d = ops.knn_search(X, k, include_self=True, q0=500, Q=700)
         assert torch.equal(i, ref_is) and torch.equal(d, ref_ds), seg
+
+
+def test_knn_search_pruned_is_exact(ops):
+    """Projection-pruned search (atlas scale) == the brute-force search: indices, order (ties by index) and fp64 distances -
+    on data whose leading coordinates separate the points (pruning bites), with duplicates and exact ties, and on isotropic
+    data where the radius has to grow (the verification step), for a query range in the middle of the point set."""
+    rng = np.random.default_rng(9)
+    C, P, k = 20000, 12, 15
+    X = np.concatenate([rng.uniform(0, 40, (C, 2)), rng.normal(0, 0.3, (C, P - 2))], 1)
+    X[500] = X[40]; X[9000] = X[40]
+    X[:, 5] = np.round(X[:, 5], 1)
+    ref_i, ref_d = ops.knn_search(X, k, include_self=False)
+    st = {}
+    i, d = ops.knn_search_pruned(X, k, tile=1024, stats=st)
+    assert torch.equal(i, ref_i) and torch.equal(d, ref_d)
+    assert st["distance_evaluations"] < 0.25 * st["brute_force_evaluations"], st
+    i, d = ops.knn_search_pruned(X, k, q0=3000, Q=5000, tile=700)
+    assert torch.equal(i, ref_i[3000:8000]) and torch.equal(d, ref_d[3000:8000])
+    Y = rng.normal(size=(6000, 10))                      # no preferred directions: the projection bound is weak, results still exact
+    ri, rd = ops.knn_search(Y, 8, include_self=False)
+    st2 = {}
+    i, d = ops.knn_search_pruned(Y, 8, tile=512, stats=st2)
+    assert torch.equal(i, ri) and torch.equal(d, rd)

@@ -34,6 +34,7 @@ from . import distributed as D
 from . import ops
 
 KEY_CHUNK = 4096          # cells per deterministic block of the synthetic generator and of the sampling keys
+PRUNE_FROM = 100_000      # cells from which the kNN search in the PCA space is projection-pruned (AtlasPath(knn="auto"))
 
 
 def _keyed_uniform(rows0: int, rows1: int, ncol: int, seed: int, dev) -> torch.Tensor:
@@ -78,8 +79,10 @@ class AtlasPath:
 
     def __init__(self, cS: ops.CsrCounts, cU: ops.CsrCounts, fS: torch.Tensor, fU: torch.Tensor, pcs: torch.Tensor, embedding: torch.Tensor, *,
                  c0: int = 0, C_total: Optional[int] = None, k: int = 30, n_neighbors: int = 500, sampled_fraction: float = 0.5,
-                 sampling_probs=(0.5, 0.1), block_cells: int = 0, dtype=torch.float32, psc: float = 1e-10, seed: int = 15071990):
+                 sampling_probs=(0.5, 0.1), block_cells: int = 0, dtype=torch.float32, psc: float = 1e-10, seed: int = 15071990,
+                 knn: str = "auto"):
         self.dev = dev = cS.indptr.device
+        self.knn_mode = knn
         self.dtype = ops.resolve_dtype(dtype)
         self.G, self.k, self.psc = cS.G, int(k), float(psc)
         self.rank, self.world = D.world()
@@ -94,7 +97,8 @@ class AtlasPath:
         pcs_full = D.all_gather_rows(pcs.double().contiguous(), self.C)
         emb_full = D.all_gather_rows(embedding.double().contiguous(), self.C)
         # ---- kNN graph of the own cells (analysis.py:1005-1010): nearest-first, self excluded; weights (knn > 0) with diag = 1
-        idx, dist_ = ops.knn_search(pcs_full, self.k, include_self=False, q0=self.c0, Q=self.nloc)
+        self.knn_stats: Dict[str, float] = {}
+        idx, dist_ = self._knn(pcs_full)
         conn = (dist_ > 0).to(self.dtype)
         wrow = torch.cat([torch.ones((self.nloc, 1), device=dev, dtype=self.dtype), conn], 1)
         wrow = (wrow / wrow.sum(1, keepdim=True)).contiguous()
@@ -139,6 +143,14 @@ class AtlasPath:
         self._resident = None
         self._plan = None
         self.peak_block_bytes = 0
+
+    def _knn(self, pcs_full: torch.Tensor):
+        """Exact kNN of the own cells among all cells: brute force up to PRUNE_FROM cells, projection-pruned beyond (the
+        brute-force search is O(C^2): 2.1 s per pass at 1M cells; the pruned one evaluates a few % of the pairs and returns
+        the same lists, ops.knn_search_pruned)."""
+        if self.knn_mode == "pruned" or (self.knn_mode == "auto" and self.C >= PRUNE_FROM):
+            return ops.knn_search_pruned(pcs_full, self.k, q0=self.c0, Q=self.nloc, stats=self.knn_stats)
+        return ops.knn_search(pcs_full, self.k, include_self=False, q0=self.c0, Q=self.nloc)
 
     # ------------------------------------------------------------------ pooling of arbitrary E rows
     def _e_rows_of(self, g: torch.Tensor) -> torch.Tensor:
@@ -194,7 +206,7 @@ class AtlasPath:
         #      does not change between passes - the count-row halo was built from it - but the search is part of
         #      knn_imputation and of the metric, so every pass repeats it
         ev[0].record()
-        ops.knn_search(self._pcs_full, self.k, include_self=False, q0=self.c0, Q=self.nloc)
+        self._knn(self._pcs_full)
         ev[1].record()
         if timed:
             torch.cuda.synchronize()
@@ -352,7 +364,7 @@ def bench_main(a, dev, rank: int, world: int) -> Optional[dict]:
         free = torch.cuda.mem_get_info(dev)[0] - 8192 * C * 4 - (6 << 30)
         block = int(max(4096, min(nloc, free * 0.6 // (2.6 * ops.padded_ld(G) * 4))))
     path = AtlasPath(cS, cU, fS, fU, pcs, emb, c0=c0, C_total=C, k=a.k, n_neighbors=a.n_neighbors, sampled_fraction=a.sampled_fraction,
-                     block_cells=block, dtype=torch.float32)
+                     block_cells=block, dtype=torch.float32, knn=getattr(a, "knn", "auto"))
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
     for _ in range(a.warmup):
@@ -397,6 +409,7 @@ def bench_main(a, dev, rank: int, world: int) -> Optional[dict]:
                                f"colDeltaCorSqrtpartial(nrndm={path.nrndm})",
                    "cells": C, "genes": G, "k": a.k, "nrndm": path.nrndm, "blocks_per_rank": len(path.blocks()), "block_cells": path.block_cells,
                    "e_sharded": True, "count_row_halo": path.n_count_halo, "e_halo_rows": path.n_e_halo,
+                   "knn_search": ({"mode": "exact, projection-pruned", **path.knn_stats} if path.knn_stats else {"mode": "exact, brute force"}),
                    "stage_ms": {"A_knn_search": st[2], "A_pooling_from_csr (own cells + e rows outside the block)": st[0], "B_fit_slope": st[1],
                                 "D_coldeltacor": st[3]},
                    "setup_s": setup_s,

@@ -748,6 +748,77 @@ def _knn_search_segmented(x64: torch.Tensor, k: int, include_self: bool, q0: int
     return idx, dist
 
 
+def knn_search_pruned(space, k: int, q0: int = 0, Q: Optional[int] = None, tile: int = 4096, stats: Optional[dict] = None
+                      ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Exact kNN (query excluded) with projection pruning for large point sets: the same result as knn_search, from far fewer
+    distance evaluations when the two leading coordinates separate the points (PCA scores: they carry the most variance).
+
+    ||q - x|| >= ||q[:2] - x[:2]||, so a point whose projection lies farther than R from a query cannot be among its k
+    nearest once k points within R are known.  Queries are cut into tiles of `tile` points that are compact in the projection
+    (sort by the first coordinate into strips, by the second inside a strip); a tile is searched (vcy_knn_query, brute force,
+    exact fp64 distances) against the points inside its bounding box grown by R, and the search is accepted only if every
+    query's k-th distance is <= R - otherwise that tile is searched again with R = 1.05 x the largest k-th distance it found
+    (which then holds by construction).  R starts from the k-th distances of a pilot sample searched against everything.
+    Candidates keep their global order inside a tile's subset, so ties come out by global index as in knn_search."""
+    dev = require_gpu()
+    x64 = (torch.from_numpy(np.array(space, dtype=np.float64, order="C")) if not isinstance(space, torch.Tensor) else space.double()).to(dev).contiguous()
+    C, P = x64.shape
+    Q = C - q0 if Q is None else Q
+    assert 0 < k < C and P >= 2
+    z = x64[:, :2].contiguous()
+    # ---- pilot: k-th distance of a spread sample -> a starting radius
+    npilot = min(Q, 2048)
+    pilot = q0 + (torch.arange(npilot, device=dev) * (Q / npilot)).long()
+    _, dp = knn_query(x64, x64[pilot], k + 1)
+    R0 = float(dp[:, k].max()) * 1.1                     # a tile holds thousands of queries: start from the pilot's LARGEST k-th distance
+    # ---- tiles of queries, compact in the projection (sort-tile partition)
+    ntile = max(1, (Q + tile - 1) // tile)
+    nstrip = max(1, int(round(ntile ** 0.5)))
+    qz = z[q0:q0 + Q]
+    by_x = torch.argsort(qz[:, 0])
+    idx = torch.empty((Q, k), dtype=torch.int32, device=dev)
+    dist = torch.empty((Q, k), dtype=torch.float64, device=dev)
+    n_eval, n_redo, n_tiles = 0, 0, 0
+    per_strip = (Q + nstrip - 1) // nstrip
+    for s0 in range(0, Q, per_strip):
+        strip = by_x[s0:s0 + per_strip]
+        strip = strip[torch.argsort(qz[strip, 1])]
+        for t0 in range(0, int(strip.numel()), tile):
+            qs = torch.sort(strip[t0:t0 + tile]).values                    # local query numbers of the tile, ascending
+            zq = qz[qs]
+            lo, hi = zq.min(0).values, zq.max(0).values
+            R = R0
+            for attempt in range(3):
+                inside = ((z[:, 0] >= lo[0] - R) & (z[:, 0] <= hi[0] + R) & (z[:, 1] >= lo[1] - R) & (z[:, 1] <= hi[1] + R))
+                cand = torch.nonzero(inside, as_tuple=False).ravel()       # ascending global numbers
+                if int(cand.numel()) <= k + 1:
+                    R *= 2.0
+                    continue
+                li, ld = knn_query(x64[cand], x64[q0 + qs], k + 1)
+                n_eval += int(cand.numel()) * int(qs.numel())
+                gi = cand[li.long()]
+                keep = gi != (q0 + qs)[:, None]
+                pos = torch.cumsum(keep.to(torch.int32), 1)
+                sel = keep & (pos <= k)
+                rows, cols = torch.nonzero(sel, as_tuple=True)
+                ti = torch.empty((int(qs.numel()), k), dtype=torch.int32, device=dev)
+                td = torch.empty((int(qs.numel()), k), dtype=torch.float64, device=dev)
+                ti[rows, (pos[rows, cols] - 1).long()] = gi[rows, cols].to(torch.int32)
+                td[rows, (pos[rows, cols] - 1).long()] = ld[rows, cols]
+                worst = float(td[:, k - 1].max())
+                if worst <= R or int(cand.numel()) == C:
+                    break
+                R = worst * 1.05                                           # every k-th distance found is an upper bound of the true one
+                n_redo += 1
+            else:
+                raise RuntimeError("knn_search_pruned: radius did not settle")      # cannot happen: the second radius holds by construction
+            idx[qs], dist[qs] = ti, td
+            n_tiles += 1
+    if stats is not None:
+        stats.update(distance_evaluations=n_eval, brute_force_evaluations=Q * C, tiles=n_tiles, tiles_searched_twice=n_redo, start_radius=R0)
+    return idx, dist
+
+
 def knn_query(points, queries, k: int, query_block: int = 8192) -> Tuple[torch.Tensor, torch.Tensor]:
     """k nearest of `points` (C, P) for every row of `queries` (Q, P): (idx int32 (Q,k), dist float64 (Q,k))."""
     dev = require_gpu()
