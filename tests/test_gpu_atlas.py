@@ -144,8 +144,9 @@ ARGS = ["--workload", "cfg5", "--no-cpu-baseline", "--cells", "9000", "--genes",
         "--steps", "1", "--warmup", "0"]
 
 
-def _run_bench(world, dump, extra=(), port=29801):
-    env = dict(os.environ, VCY_SINGLE_DEVICE="1", VCY_DIST_BACKEND="gloo", VCY_FORCE_COLLECTIVES="1", MASTER_PORT=str(port), MASTER_ADDR="127.0.0.1")
+def _run_bench(world, dump, extra=(), port=29801, backend="gloo"):
+    env = dict(os.environ, VCY_SINGLE_DEVICE="1", VCY_DIST_BACKEND=backend, VCY_FORCE_COLLECTIVES="1", MASTER_PORT=str(port), MASTER_ADDR="127.0.0.1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
     for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(key, None)
     if world == 1:
@@ -241,3 +242,15 @@ def test_atlas_fullsize_200k_cells_30k_genes(ops, oracle):
         got = corr[c].cpu().numpy()
         okc = np.isfinite(ref)
         np.testing.assert_allclose(got[okc], ref[okc], atol=5e-5)
+
+
+def test_atlas_path_on_the_rccl_transport(tmp_path):
+    """The atlas path's collectives (all-gather of pcs / embedding, halo masks, graph-row and ragged count-row all-to-alls,
+    all-reduce of the fit moments) on backend "nccl" (= RCCL) at world size 1, against the gloo run of the same problem."""
+    from velocyto_amd import ops
+    ops.require_gpu()
+    ref = _run_bench(1, str(tmp_path / "gloo.npz"), port=29861)
+    got = _run_bench(1, str(tmp_path / "rccl.npz"), port=29862, backend="nccl")
+    assert np.array_equal(ref["neigh"], got["neigh"]) and np.array_equal(ref["gamma"], got["gamma"])
+    fin = np.isfinite(ref["corr"])
+    assert np.array_equal(np.isfinite(got["corr"]), fin) and np.array_equal(got["corr"][fin], ref["corr"][fin])
