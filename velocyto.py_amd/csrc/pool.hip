@@ -184,7 +184,9 @@ __global__ __launch_bounds__(256) void k_knn_pool_counts(const CT *__restrict__ 
             }
         }
         // 16-byte stores (a lane's NE outputs are contiguous): element-wise 4-byte stores at a 32/64-byte lane stride made this
-        // kernel write-bound (13.5 of 15 ms with a single neighbour per cell).  Output rows are padded to a multiple of 64
+        // kernel write-bound (13.5 of 15 ms with a single neighbour per cell).  (Round 2: turning the wave's 64 x NE block
+        // through LDS so that every store instruction covers a contiguous 1 KiB measured SLOWER - uint8 8.1 -> 10.1 ms,
+        // uint16 10.9 -> 15.5 ms: the 64-byte lane stride already fills whole lines over a lane's four stores.)  Output rows are padded to a multiple of 64
         // elements, so a vector that starts inside a row ends inside it; elements past G are written as zeros.
         using OV = typename Vec<T>::type;
         constexpr int ON = Vec<T>::N;
