@@ -269,6 +269,7 @@ class Pipeline:
         mom = ops.fit_slope_moments(self.Ux_loc, self.Sx_loc)
         self.D.all_reduce_sum(mom)
         gamma = ops.fit_slope_from_moments(mom)
+        gamma[~torch.isfinite(gamma)] = 0.0          # fit_gammas' policy for genes without signal (analysis.py:1260)
         ev[2].record()
         # ---- C: predict_U -> velocity -> shift -> signed-sqrt dmat.  Default: folded into stage D's staging of d[c]
         #         (vcy_coldeltacor_partial_fused, bit-identical); --no-fuse materialises dmat with k_velocity_chain.

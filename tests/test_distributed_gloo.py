@@ -128,3 +128,61 @@ def test_shard_bounds_cover_and_balance():
     assert D.world() == (0, 1)
     t = torch.arange(6.0).reshape(3, 2)
     assert D.all_gather_rows(t, 3) is t and D.all_reduce_sum(t) is t       # world size 1: no-ops
+
+
+def _ragged_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import velocyto_amd
+        from velocyto_amd import distributed as D
+        rng = np.random.default_rng(11)                       # the same "dataset" on every rank: CSR rows of 37 cells
+        C, G = 37, 50
+        lens_all = rng.integers(0, 9, C)
+        lens_all[5] = 0                                       # an empty row travels as a zero-length segment
+        ptr = np.concatenate([[0], np.cumsum(lens_all)])
+        idx_all = np.concatenate([np.sort(rng.choice(G, n, replace=False)) for n in lens_all]).astype(np.int32)
+        dat_all = rng.integers(1, 200, idx_all.size).astype(np.uint8)
+        c0, c1 = D.shard_bounds(C, world, rank)
+        need = torch.zeros(C, dtype=torch.bool)
+        need[torch.as_tensor(rng.choice(C, 12, replace=False))] = True      # same draw on every rank, then make it rank-specific
+        need = torch.roll(need, 5 * rank)
+        need[c0:c1] = True
+        plan = D.HaloPlan(need, C)
+        lens = torch.as_tensor(lens_all[c0:c1])
+        own_idx, own_dat = torch.as_tensor(idx_all[ptr[c0]:ptr[c1]]), torch.as_tensor(dat_all[ptr[c0]:ptr[c1]])
+        lens_h, idx_h, dat_h = plan.fetch_ragged(lens, own_idx, own_dat)
+        rows = plan.recv_idx.numpy()                          # global numbers of the halo rows, ascending
+        assert np.array_equal(rows, np.nonzero(need.numpy() & ~np.isin(np.arange(C), np.arange(c0, c1)))[0])
+        assert np.array_equal(lens_h.numpy(), lens_all[rows])
+        assert np.array_equal(idx_h.numpy(), np.concatenate([idx_all[ptr[r]:ptr[r + 1]] for r in rows] + [np.empty(0, np.int32)]))
+        assert np.array_equal(dat_h.numpy(), np.concatenate([dat_all[ptr[r]:ptr[r + 1]] for r in rows] + [np.empty(0, np.uint8)]))
+        # small per-row vectors (graph rows, size factors) ride the same plan
+        f = torch.as_tensor(np.arange(C, dtype=np.float64)[c0:c1] * 1.5)
+        assert np.array_equal(plan.fetch(f.reshape(-1, 1)).reshape(-1).numpy(), rows * 1.5)
+        # and the renumbering into [own | halo]
+        some = torch.as_tensor(np.concatenate([rows[:3], np.arange(c0, min(c1, c0 + 2))]))
+        loc = plan.localize(some)
+        exp = np.concatenate([(c1 - c0) + np.arange(min(3, rows.size)), np.arange(min(c1 - c0, 2))])
+        assert np.array_equal(loc.numpy(), exp)
+        q.put(rank)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ragged_count_row_halo(world):
+    """The count-row halo of the atlas path (atlas.py): ragged CSR rows, row lengths and per-row vectors travel through one
+    HaloPlan (all-to-all with uneven splits; gloo point-to-point here) and arrive in ascending global row order."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    done = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert done == list(range(world))

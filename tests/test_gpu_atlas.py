@@ -110,6 +110,7 @@ def _dense_reference(ops, atlas, cS, cU, fS, fU, pcs, emb, k, n_neighbors, frac)
     ptr = torch.arange(0, (C + 1) * (k + 1), k + 1, device=idx.device, dtype=torch.int64)
     Sx, Ux = ops.knn_pool_counts(cS.to_dense(), cU.to_dense(), fS, fU, ptr, ind, w, dtype=torch.float32, validate=False)
     gamma = ops.fit_slope_from_moments(ops.fit_slope_moments(Ux, Sx))
+    gamma[~torch.isfinite(gamma)] = 0.0                      # analysis.py:1260
     neigh = atlas.sample_neighbors(emb.double(), 0, C, n_neighbors, frac)
     corr = ops.coldeltacor_partial_fused(Sx, Ux, gamma, None, neigh, ops.SQRT, ops.RULES_PARTIAL, 1e-10, validate=False)
     return Sx, Ux, gamma, neigh, corr
@@ -254,3 +255,34 @@ def test_atlas_path_on_the_rccl_transport(tmp_path):
     assert np.array_equal(ref["neigh"], got["neigh"]) and np.array_equal(ref["gamma"], got["gamma"])
     fin = np.isfinite(ref["corr"])
     assert np.array_equal(np.isfinite(got["corr"]), fin) and np.array_equal(got["corr"][fin], ref["corr"][fin])
+
+
+def test_loom_file_to_atlas_path(ops, tmp_path):
+    """A .loom file straight into the atlas path: layers read in hyperslabs of cells into device CSR (never dense), size
+    factors from the CSR row sums, AtlasPath in three blocks - against the dense facade-level route on the same file."""
+    import velocyto_amd
+    from velocyto_amd import atlas, loom_io
+    dev = ops.require_gpu()
+    rng = np.random.default_rng(21)
+    G, C, k = 900, 700, 10
+    lam = rng.gamma(0.3, 1.0, (G, 1)) * rng.gamma(2.0, 0.5, (1, C))
+    S, U = rng.poisson(lam).astype(np.uint16), rng.poisson(0.4 * lam).astype(np.uint16)
+    S[3, 5] = 3000                                                     # beyond a byte: uint16 counts on the device
+    path = str(tmp_path / "atlas.loom")
+    loom_io.write_loom(path, {"spliced": S, "unspliced": U, "ambiguous": np.zeros_like(S)}, {"CellID": np.arange(C)}, {"Gene": np.arange(G)})
+    cS, cU = loom_io.read_layer_csr(path, "spliced", cell_block=256), loom_io.read_layer_csr(path, "unspliced", cell_block=256)
+    assert cS.data.dtype == torch.int16 and cU.data.dtype == torch.uint8 and cS.nnz == int((S != 0).sum())
+    fS, fU = atlas.size_factors(cS.row_sums(), cU.row_sums(), C)
+    pcs = torch.as_tensor(rng.normal(size=(C, 6)), device=dev)
+    emb = pcs[:, :2].contiguous()
+    a = atlas.AtlasPath(cS, cU, fS, fU, pcs, emb, k=k, n_neighbors=60, sampled_fraction=0.5, block_cells=250, knn="brute")
+    corr = a.run()
+    # the dense route: facade normalisation (analysis.py:535-582) gives the same size factors; pooling + fit + fused stage D
+    vlm = velocyto_amd.analysis.VelocytoLoom(path, dtype="float32")
+    vlm.normalize("both", size=True, log=False)
+    np.testing.assert_allclose((vlm.S_sz[:, 7] / np.maximum(S[:, 7], 1))[S[:, 7] > 0], float(fS[7]), rtol=1e-6)
+    Sx, Ux, gamma, neigh, ref = _dense_reference(ops, atlas, cS, cU, fS, fU, pcs, emb, k, 60, 0.5)
+    assert torch.equal(a.neigh, neigh)
+    torch.testing.assert_close(a.gamma, gamma, rtol=2e-6, atol=1e-9)
+    fin = torch.isfinite(ref)
+    assert torch.equal(torch.isfinite(corr), fin) and float((corr[fin] - ref[fin]).abs().max()) <= 2e-6

@@ -227,7 +227,9 @@ class AtlasPath:
                 tA += ev[0].elapsed_time(ev[1]); tB += ev[1].elapsed_time(ev[2])
         ev[0].record()
         D.all_reduce_sum(mom)
-        self.gamma = gamma = ops.fit_slope_from_moments(mom)
+        gamma = ops.fit_slope_from_moments(mom)
+        gamma[~torch.isfinite(gamma)] = 0.0          # fit_gammas' policy for genes without signal (analysis.py:1260); NaN would poison every d[c]
+        self.gamma = gamma
         ev[1].record()
         if timed:
             torch.cuda.synchronize()
