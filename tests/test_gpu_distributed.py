@@ -26,13 +26,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ARGS = ["--no-cpu-baseline", "--cells", "4100", "--genes", "1536", "--n-neighbors", "100", "--k", "12", "--steps", "1", "--warmup", "1"]
 
 
-def run(world, dump, extra=(), port=29611, backend="gloo", force="1"):
+def run(world, dump, extra=(), port=29611, backend="gloo", force="1", self_launch=False):
     env = dict(os.environ, VCY_SINGLE_DEVICE="1", VCY_DIST_BACKEND=backend, VCY_FORCE_COLLECTIVES=force, MASTER_PORT=str(port),
                MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    if world == 1:
-        cmd = [sys.executable, "bench.py", "--gpus", "1", *ARGS, "--dump", dump, *extra]
+    if world == 1 or self_launch:            # self_launch: bench.py spawns its own ranks (no torch.distributed.run wrapper)
+        cmd = [sys.executable, "bench.py", "--gpus", str(world), *ARGS, "--dump", dump, *extra]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), "bench.py", "--gpus", str(world), *ARGS, "--dump", dump, *extra]
@@ -74,3 +74,16 @@ def test_rccl_collectives_on_one_gpu(tmp_path):
         fin = np.isfinite(ref["corr"])
         assert np.array_equal(np.isfinite(got["corr"]), fin)
         np.testing.assert_array_equal(got["corr"][fin], ref["corr"][fin])
+
+
+def test_bench_self_launch_equals_torchrun(tmp_path):
+    """`python bench.py --gpus 2` without a launcher spawns one process per rank itself (torch.multiprocessing) and must give
+    what the torch.distributed.run launch gives."""
+    from velocyto_amd import ops
+    ops.require_gpu()
+    a, _ = run(2, str(tmp_path / "torchrun.npz"), port=29751)
+    b, line = run(2, str(tmp_path / "self.npz"), port=29752, self_launch=True)
+    assert '"n_gpus": 2' in line
+    assert np.array_equal(a["neigh"], b["neigh"]) and np.array_equal(a["gamma"], b["gamma"])
+    fin = np.isfinite(a["corr"])
+    assert np.array_equal(np.isfinite(b["corr"]), fin) and np.array_equal(b["corr"][fin], a["corr"][fin])
