@@ -59,6 +59,8 @@ template <typename T, int TR, int RULES> __device__ __forceinline__ T xform(T t,
 // f32 differences of values above 1e-9) sees a ramp instead of a hard zero.  The f64 parity build keeps the literal rule.
 template <> __device__ __forceinline__ float xform<float, VCY_SQRT, VCY_RULES_PARTIAL>(float t, float psc)
 {
+    // (measured in the kernel, round 2: `|t| + psc -> sqrt -> v_med3(s, -s, t * 2^100)` 96.5 ms and psc held in a VGPR
+    //  102.1 ms against 96.7 ms for this form - the instruction mix is not what the launch waits for at the margin)
     const float c = __builtin_amdgcn_fmed3f(fabsf(t) * 0x1p54f, 0.0f, 1.0f);
     return copysignf(fast_sqrt<float>(fmaf(psc, c, fabsf(t))), t);
 }
@@ -532,14 +534,18 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
         auto eval_row = [&](const V (&x)[NV], int r) {
             const int p0 = seg[r], p1 = seg[r + 1];
             for (int p = p0; p < p1; ++p) {
-                const int m0 = (int)((keys[p] >> 12) & 15);
+                const int m0 = (int)((keys[p] >> 12) & 15);       // (reading the next pair's key a pair ahead: no gain, 96.2 vs 95.9 ms)
                 T a0, b0, c0, d0;
                 pair_moments(x, m0, fullchunk, a0, b0, c0, d0);
                 // the three (dual: four) wave totals in one transposing reduction: row r of `tot` holds moment r; lane 16 r
                 // adds it to acc[AS p + r] (the single-control kernel feeds a fourth value nobody reads, so that both
                 // variants sum in the same order: the dual outputs equal those of two single launches bit for bit)
                 const T tot = wave_sum_rows(a0, b0, c0, d0);
-                if ((lane & 15) == 0 && (lane >> 4) < AS) acc[AS * p + (lane >> 4)] += tot;
+                // ds_add_f32 without return: the wave that owns the pair is the only writer of acc[p][.], so the order of the
+                // additions is its program order (deterministic) and nothing waits for the old value (read-modify-write with
+                // its s_waitcnt: 96.7 -> 95.8 ms)
+                if ((lane & 15) == 0 && (lane >> 4) < AS)
+                    __hip_atomic_fetch_add(&acc[AS * p + (lane >> 4)], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         };
         {
