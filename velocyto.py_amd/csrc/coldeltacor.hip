@@ -470,9 +470,10 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
         // the DPP reductions and the LDS accumulator updates).
         auto pair_moments = [&](const V (&x)[NV], int m, bool full, T &tA, T &tAA, T &tAb, T &tAb2) {
             const T *em = ec + m * GCHUNK, *bm = dc + m * GCHUNK, *bm2 = dc2 + m * GCHUNK;
-            T sA[N], sAA[N], sAb[N], sAb2[N];
+            T sA[2], sAA[2], sAb[2], sAb2[2];          // two partial sums per moment and lane: elements (0, 1) and (2, 3) of a vector fold into the SAME
+                                                        // packed accumulator pair (6 registers for three moments; four partials each cost 12)
 #pragma unroll
-            for (int k = 0; k < N; ++k) { sA[k] = T(0); sAA[k] = T(0); sAb[k] = T(0); sAb2[k] = T(0); }
+            for (int k = 0; k < 2; ++k) { sA[k] = T(0); sAA[k] = T(0); sAb[k] = T(0); sAb2[k] = T(0); }
             if (full) {
                 constexpr int HB = DUAL ? 1 : 2;                 // LDS reads batched: 2*HB (dual: 3*HB) b128 in flight per batch
 #pragma unroll
@@ -493,10 +494,10 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
 #pragma unroll
                         for (int k = 0; k < N; ++k) {
                             T a = xform_s<T, TR, RULES>(xp[k] - ep[k], psc, K);
-                            sA[k] += a;
-                            sAA[k] = fma(a, a, sAA[k]);
-                            sAb[k] = fma(a, bp[k], sAb[k]);
-                            if (DUAL) sAb2[k] = fma(a, bp2[k], sAb2[k]);
+                            sA[k & 1] += a;
+                            sAA[k & 1] = fma(a, a, sAA[k & 1]);
+                            sAb[k & 1] = fma(a, bp[k], sAb[k & 1]);
+                            if (DUAL) sAb2[k & 1] = fma(a, bp2[k], sAb2[k & 1]);
                         }
                     }
                 }
@@ -518,21 +519,21 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
                         for (int k = 0; k < N; ++k) {
                             T a = xform_s<T, TR, RULES>(xp[k] - ep[k], psc, K);
                             if (k >= valid) a = T(0);
-                            sA[k] += a;
-                            sAA[k] = fma(a, a, sAA[k]);
-                            sAb[k] = fma(a, bp[k], sAb[k]);
-                            if (DUAL) sAb2[k] = fma(a, bp2[k], sAb2[k]);
+                            sA[k & 1] += a;
+                            sAA[k & 1] = fma(a, a, sAA[k & 1]);
+                            sAb[k & 1] = fma(a, bp[k], sAb[k & 1]);
+                            if (DUAL) sAb2[k & 1] = fma(a, bp2[k], sAb2[k & 1]);
                         }
                     }
                 }
             }
-            tA = sA[0]; tAA = sAA[0]; tAb = sAb[0]; tAb2 = sAb2[0];
-#pragma unroll
-            for (int k = 1; k < N; ++k) { tA += sA[k]; tAA += sAA[k]; tAb += sAb[k]; tAb2 += sAb2[k]; }
+            tA = sA[0] + sA[1]; tAA = sAA[0] + sAA[1]; tAb = sAb[0] + sAb[1]; tAb2 = sAb2[0] + sAb2[1];
         };
         const bool fullchunk = (gl == GCHUNK);
         auto eval_row = [&](const V (&x)[NV], int r) {
             const int p0 = seg[r], p1 = seg[r + 1];
+            // (two pairs of a row evaluated together - shared row registers, interleaved operand reads and reductions, same
+            //  arithmetic per pair - measured 95.0 vs 95.5 ms: within noise, not kept)
             for (int p = p0; p < p1; ++p) {
                 const int m0 = (int)((keys[p] >> 12) & 15);       // (reading the next pair's key a pair ahead: no gain, 96.2 vs 95.9 ms)
                 T a0, b0, c0, d0;
