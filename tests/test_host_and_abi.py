@@ -240,3 +240,18 @@ def test_choice_stream_host_hypothesis(lib):
         assert _rng_state_equal(np.random.get_state(), after)
 
     run()
+
+
+def test_atlas_memory_plan_for_one_million_cells():
+    """The per-rank memory plan of the atlas path is plain arithmetic: 1M cells x 30k genes on 8 ranks must fit
+    288 GB per rank with room to spare in resident mode, and a streamed single rank must stay O(block)."""
+    import velocyto_amd
+    from velocyto_amd import atlas
+    plan = atlas.memory_plan(1_000_000, 30_000, 2400, 8, 0, nrndm=250, k=30, count_bytes=1, halo_e=0.1, halo_k=0.25)
+    assert plan["cells_per_rank"] == 125_000
+    assert 2.5 < plan["csr_layers_with_halo_GB"] < 4.5 and 28 < plan["block_Sx_Ux_GB"] < 34
+    assert plan["total_GB"] < 0.3 * 288
+    one = atlas.memory_plan(1_000_000, 30_000, 2400, 1, 50_000, nrndm=250, k=30, count_bytes=1)
+    assert one["block_Sx_Ux_GB"] < 20 and one["csr_layers_with_halo_GB"] < 40 and one["total_GB"] < 288
+    dense = 1_000_000 * 30_016 * 4 * 2 / 1e9
+    assert one["total_GB"] < 0.5 * dense                   # against Sx + Ux resident (240 GB)
