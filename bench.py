@@ -79,6 +79,8 @@ def parse():
                     help="storage of the resident count layers: auto = uint8 when no count exceeds 255, else uint16; u16 forces uint16")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32", help="arithmetic / storage type of the path (f64 = the reference's)")
     ap.add_argument("--no-extra", action="store_true", help="skip the f64 / uint16 / randomised-control lines")
+    ap.add_argument("--literal-rule", action="store_true", help="stage D with the literal partial-sqrt rule (pseudocount kept) instead of the "
+                                                                "three-instruction f32 form ops.partial_rules_for picks")
     ap.add_argument("--slab", type=int, default=0, help="gene slab of the pooling kernel (0 = library default)")
     ap.add_argument("--no-fuse", dest="fuse", action="store_false",
                     help="materialise dmat with k_velocity_chain instead of folding the velocity chain into stage D")
@@ -180,6 +182,7 @@ class Pipeline:
         from velocyto_amd import ops, distributed
         self.ops, self.D = ops, distributed
         self.a, self.dev, self.rank, self.world, self.dtype = args, dev, rank, world, dtype
+        self.rules = None                        # stage-D branch rule, decided on the first pooled matrix
         C, G = args.cells, args.genes
         # resident inputs: the loom's count layers + per-cell size factors (S_sz = fS * S is never materialised)
         self.cS, self.cU, self.fS, self.fU, self.pcs = data if data is not None else synth_counts(C, G, args.pca_dims, dev)
@@ -278,12 +281,16 @@ class Pipeline:
             dmat = ops.velocity_chain(self.Sx_loc, self.Ux_loc, gamma, None, want=("dmat",), transform=ops.SQRT, psc=1e-10)["dmat"]
         ev[3].record()
         # ---- D: colDeltaCorSqrtpartial; sharded: every rank needs the rows of e = Sx_sz its neighbour lists reference
+        if self.rules is None:                   # decided once, on the first pooled matrix (one host sync; see ops.partial_rules_for)
+            self.rules = ops.RULES_PARTIAL if a.literal_rule else ops.partial_rules_for(self.Sx_loc, ops.SQRT, 1e-10)
+        rules = self.rules
+
         def stage_d(order):
             if a.fuse:
-                ops.coldeltacor_partial_fused(self.e_rows, self.Ux_loc, gamma, None, self.neigh_k, ops.SQRT, ops.RULES_PARTIAL, 1e-10,
+                ops.coldeltacor_partial_fused(self.e_rows, self.Ux_loc, gamma, None, self.neigh_k, ops.SQRT, rules, 1e-10,
                                               cell0=self.e_cell0, u_row0=self.e_cell0, order=order, out=self.corr_loc, validate=False)
             else:
-                ops.coldeltacor_partial(self.e_rows, dmat, self.neigh_k, ops.SQRT, ops.RULES_PARTIAL, 1e-10, cell0=self.e_cell0,
+                ops.coldeltacor_partial(self.e_rows, dmat, self.neigh_k, ops.SQRT, rules, 1e-10, cell0=self.e_cell0,
                                         d_row0=self.e_cell0, order=order, out=self.corr_loc, validate=False)
         if self.sched is not None:
             handle = self.plan.begin(self.Sx_loc.t, recv_out=self.e_rows.t[nloc:])    # halo rows packed, all_to_all_single started (async on RCCL)
@@ -335,10 +342,10 @@ class Pipeline:
             for _ in range(reps):
                 e0.record()
                 if dual:
-                    ops.coldeltacor_partial_fused_dual(self.e_rows, self.Ux_loc, gamma, None, d_r, self.neigh_k, ops.SQRT, ops.RULES_PARTIAL, 1e-10,
+                    ops.coldeltacor_partial_fused_dual(self.e_rows, self.Ux_loc, gamma, None, d_r, self.neigh_k, ops.SQRT, self.rules, 1e-10,
                                                        cell0=self.e_cell0, u_row0=self.e_cell0, order=self.order, out=self.corr_loc, out_rndm=out_r, validate=False)
                 else:
-                    ops.coldeltacor_partial_fused(self.e_rows, self.Ux_loc, gamma, None, self.neigh_k, ops.SQRT, ops.RULES_PARTIAL, 1e-10,
+                    ops.coldeltacor_partial_fused(self.e_rows, self.Ux_loc, gamma, None, self.neigh_k, ops.SQRT, self.rules, 1e-10,
                                                   cell0=self.e_cell0, u_row0=self.e_cell0, order=self.order, out=self.corr_loc, validate=False)
                 e1.record()
                 torch.cuda.synchronize()

@@ -43,7 +43,16 @@ typedef enum { VCY_LINEAR = 0, VCY_SQRT = 1, VCY_LOG10 = 2 } vcy_transform;
 
 /* Which family's branch rules apply at t == 0 (speedboosted.pyx:110-114,195-199 vs
  * :372-378,469-473). */
-typedef enum { VCY_RULES_FULL = 0, VCY_RULES_PARTIAL = 1 } vcy_rules;
+typedef enum {
+    VCY_RULES_FULL = 0,
+    VCY_RULES_PARTIAL = 1,
+    /* The partial rule with the pseudocount dropped: A = sign(t) sqrt|t| (0 at t == 0).  VCY_SQRT on VCY_F32 matrices in the
+     * vcy_coldeltacor_partial* entries only (anything else: VCY_ERR_INVALID).  In f32 `|t| + psc` rounds to `|t|` for every
+     * |t| >= 2^24 psc (1.7e-3 at the reference's default psc = 1e-10); below that the two rules differ by at most
+     * psc / (2 sqrt|t|) per gene.  Three VALU instructions per gene instead of five: the caller opts in when psc is far
+     * below the scale of the matrix (the Python layer: psc <= 1e-9 and mean |e| >= 1e-4).                              */
+    VCY_RULES_PARTIAL_NOPSC = 2
+} vcy_rules;
 
 typedef void *vcy_stream;  /* hipStream_t */
 

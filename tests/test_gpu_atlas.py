@@ -112,7 +112,7 @@ def _dense_reference(ops, atlas, cS, cU, fS, fU, pcs, emb, k, n_neighbors, frac)
     gamma = ops.fit_slope_from_moments(ops.fit_slope_moments(Ux, Sx))
     gamma[~torch.isfinite(gamma)] = 0.0                      # analysis.py:1260
     neigh = atlas.sample_neighbors(emb.double(), 0, C, n_neighbors, frac)
-    corr = ops.coldeltacor_partial_fused(Sx, Ux, gamma, None, neigh, ops.SQRT, ops.RULES_PARTIAL, 1e-10, validate=False)
+    corr = ops.coldeltacor_partial_fused(Sx, Ux, gamma, None, neigh, ops.SQRT, ops.partial_rules_for(Sx, ops.SQRT, 1e-10), 1e-10, validate=False)
     return Sx, Ux, gamma, neigh, corr
 
 

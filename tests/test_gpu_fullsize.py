@@ -109,21 +109,23 @@ def test_fullsize_pipeline_properties_and_spot_checks(world, oracle):
         okc = np.isfinite(ref)
         np.testing.assert_allclose(dmat.t[c, :G].double().cpu().numpy()[okc], ref[okc], rtol=1e-4, atol=2e-3)
     del out
-    # ---------------- D: correlation properties
-    corr = ops.coldeltacor_partial(Sx, dmat, neigh, ops.SQRT, ops.RULES_PARTIAL, 1e-10, validate=True)
+    # ---------------- D: correlation properties (the rule the callers use on this matrix: f32 -> the no-pseudocount form)
+    rules = ops.partial_rules_for(Sx, ops.SQRT, 1e-10)
+    assert rules == ops.RULES_PARTIAL_NOPSC
+    corr = ops.coldeltacor_partial(Sx, dmat, neigh, ops.SQRT, rules, 1e-10, validate=True)
     fin = torch.isfinite(corr)
     assert fin.float().mean().item() > 0.999
     assert corr[fin].abs().max().item() <= 1 + 1e-5
     neg = ops.CellMatrix(-dmat.t, G)
-    c_neg = ops.coldeltacor_partial(Sx, neg, neigh, ops.SQRT, ops.RULES_PARTIAL, 1e-10, validate=False)
+    c_neg = ops.coldeltacor_partial(Sx, neg, neigh, ops.SQRT, rules, 1e-10, validate=False)
     assert torch.equal(torch.isfinite(c_neg), fin) and torch.equal(c_neg[fin], -corr[fin]), "corr(e, -d) must be exactly -corr(e, d)"
     neg.t.mul_(-3.0)                                    # now 3 * dmat
-    c_scaled = ops.coldeltacor_partial(Sx, neg, neigh, ops.SQRT, ops.RULES_PARTIAL, 1e-10, validate=False,
+    c_scaled = ops.coldeltacor_partial(Sx, neg, neigh, ops.SQRT, rules, 1e-10, validate=False,
                                        order=ops.morton_order(pcs[:, :2], 2))
     assert (c_scaled[fin] - corr[fin]).abs().max().item() < 2e-5
     del neg, c_neg, c_scaled
     # velocity chain folded into the kernel == materialised dmat, bit for bit, main part and last-round tiles alike
-    fused = ops.coldeltacor_partial_fused(Sx, Ux, gam, None, neigh, ops.SQRT, ops.RULES_PARTIAL, 1e-10, validate=False)
+    fused = ops.coldeltacor_partial_fused(Sx, Ux, gam, None, neigh, ops.SQRT, rules, 1e-10, validate=False)
     assert torch.equal(torch.nan_to_num(fused, nan=7.0), torch.nan_to_num(corr, nan=7.0))
     del fused
     # ---------------- D: spot check against the fp64 oracle on the rows the sampled cells touch
@@ -194,7 +196,9 @@ def test_fullsize_f32_against_f64_all_pairs(world):
     for dt in (torch.float32, torch.float64):
         Sx, Ux = ops.knn_pool_counts(cS, cU, fS, fU, indptr, indices, wrow.to(dt), dtype=dt, validate=False)
         gam = ops.fit_slope(Ux, Sx)
-        corr = ops.coldeltacor_partial_fused(Sx, Ux, gam, None, neigh, ops.SQRT, ops.RULES_PARTIAL, 1e-10, validate=False,
+        rules = ops.partial_rules_for(Sx, ops.SQRT, 1e-10)      # what the facade and the bench pass: f32 drops the pseudocount, f64 is literal
+        assert rules == (ops.RULES_PARTIAL_NOPSC if dt == torch.float32 else ops.RULES_PARTIAL)
+        corr = ops.coldeltacor_partial_fused(Sx, Ux, gam, None, neigh, ops.SQRT, rules, 1e-10, validate=False,
                                              order=ops.hilbert_order(pcs[:, :2].contiguous()))
         if dt == torch.float32:
             res[dt] = (Sx.t.clone(), Ux.t.clone(), gam.clone(), corr.clone())

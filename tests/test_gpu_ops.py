@@ -731,3 +731,76 @@ def test_knn_search_pruned_is_exact(ops):
     st2 = {}
     i, d = ops.knn_search_pruned(Y, 8, tile=512, stats=st2)
     assert torch.equal(i, ri) and torch.equal(d, rd)
+
+
+# ---------------------------------------------------------------- the no-pseudocount form of the partial sqrt rule (f32)
+def _nopsc_problem(seed, G, C, nr, scale=1.0):
+    rng = np.random.default_rng(seed)
+    e = rng.gamma(2.0, 1.0, (G, C)) * (rng.random((G, C)) < 0.6) * scale
+    e[:, 1] = e[:, 0]                                 # identical cells: zero-variance pair (NaN in every rule)
+    e[: G // 2, 3] = e[: G // 2, 2]                   # half of the genes agree exactly: the zero rule matters
+    d = rng.normal(size=(G, C))
+    ixs = np.stack([rng.choice(C, nr, replace=False) for _ in range(C)])
+    ixs[0, 0] = 1
+    return e, d, ixs
+
+
+@pytest.mark.parametrize("G,C,nr", [(3000, 64, 24), (1537, 40, 9), (50, 33, 8)])
+def test_partial_nopsc_rule_against_the_literal_rule(ops, oracle, G, C, nr):
+    """VCY_RULES_PARTIAL_NOPSC (f32, sqrt: A = sign(t) sqrt|t| by v_rsq_f32 + v_mul_legacy_f32) against the literal rule
+    of speedboosted.pyx:372-378 with the default pseudocount: same NaN pattern, correlations within 2e-6 of the literal f32
+    kernel and within the f32 tolerance of the f64 oracle; single and dual-control kernels, grouped and small-problem paths."""
+    e, d, ixs = _nopsc_problem(G + C, G, C, nr)
+    want = oracle.coldeltacor_partial_compact(e, d, ixs, "sqrt", 1e-10)
+    E, D = ops.CellMatrix.from_genes_major(e, "float32"), ops.CellMatrix.from_genes_major(d, "float32")
+    assert ops.partial_rules_for(E, ops.SQRT, 1e-10) == ops.RULES_PARTIAL_NOPSC
+    lit = ops.coldeltacor_partial(E, D, ixs, ops.SQRT, ops.RULES_PARTIAL, 1e-10).cpu().numpy()
+    fast = ops.coldeltacor_partial(E, D, ixs, ops.SQRT, ops.RULES_PARTIAL_NOPSC, 1e-10).cpu().numpy()
+    assert np.array_equal(np.isnan(fast), np.isnan(want)) and np.array_equal(np.isnan(lit), np.isnan(want))
+    assert np.isnan(fast[0, 0])
+    ok = np.isfinite(want)
+    assert np.abs(fast[ok] - lit[ok]).max() < 2e-6
+    np.testing.assert_allclose(fast[ok], want[ok], atol=CORR_ATOL["float32"])
+    D2 = ops.CellMatrix.from_genes_major(d[::-1].copy(), "float32")
+    a, b = ops.coldeltacor_partial_dual(E, D, D2, ixs, ops.SQRT, ops.RULES_PARTIAL_NOPSC, 1e-10)
+    b1 = ops.coldeltacor_partial(E, D2, ixs, ops.SQRT, ops.RULES_PARTIAL_NOPSC, 1e-10)
+    assert torch.allclose(a.nan_to_num(7.0), torch.from_numpy(fast).to(a.device).nan_to_num(7.0), atol=2e-6)
+    assert torch.allclose(b.nan_to_num(7.0), b1.nan_to_num(7.0), atol=2e-6)
+    sub = torch.arange(0, C, 3, dtype=torch.int32)    # a schedule over a third of the cells: the small-problem kernel
+    out = torch.full((C, nr), 5.0, dtype=torch.float32, device=E.t.device)
+    ops.coldeltacor_partial(E, D, ixs, ops.SQRT, ops.RULES_PARTIAL_NOPSC, 1e-10, order=sub, out=out)
+    got = out.cpu().numpy()[::3]
+    sel = np.isfinite(want[::3])
+    np.testing.assert_allclose(got[sel], want[::3][sel], atol=CORR_ATOL["float32"])
+
+
+def test_partial_rules_for_keeps_the_literal_rule_when_the_pseudocount_counts(ops, oracle):
+    """The helper that picks the rule: literal for f64, for log10 / linear, for a pseudocount above 1e-9 and for a matrix whose
+    scale the pseudocount is NOT negligible against - where the two rules really differ and only the literal one matches
+    the oracle."""
+    e, d, ixs = _nopsc_problem(5, 2000, 48, 16, scale=1e-8)
+    E32, D32 = ops.CellMatrix.from_genes_major(e, "float32"), ops.CellMatrix.from_genes_major(d, "float32")
+    E64 = ops.CellMatrix.from_genes_major(e, "float64")
+    big = ops.CellMatrix.from_genes_major(e * 1e8, "float32")
+    assert ops.partial_rules_for(E32, ops.SQRT, 1e-10) == ops.RULES_PARTIAL            # tiny scale
+    assert ops.partial_rules_for(big, ops.SQRT, 1e-10) == ops.RULES_PARTIAL_NOPSC
+    assert ops.partial_rules_for(big, ops.SQRT, 1e-6) == ops.RULES_PARTIAL             # pseudocount not negligible
+    assert ops.partial_rules_for(big, ops.LOG10, 1e-10) == ops.RULES_PARTIAL
+    assert ops.partial_rules_for(E64, ops.SQRT, 1e-10) == ops.RULES_PARTIAL
+    want = oracle.coldeltacor_partial_compact(e, d, ixs, "sqrt", 1e-10)
+    ok = np.isfinite(want)
+    lit = ops.coldeltacor_partial(E32, D32, ixs, ops.SQRT, ops.partial_rules_for(E32, ops.SQRT, 1e-10), 1e-10).cpu().numpy()
+    np.testing.assert_allclose(lit[ok], want[ok], atol=CORR_ATOL["float32"])
+    fast = ops.coldeltacor_partial(E32, D32, ixs, ops.SQRT, ops.RULES_PARTIAL_NOPSC, 1e-10).cpu().numpy()
+    # this is the case the helper guards: at |t| ~ 1e-8 the pseudocount is 1 % of a difference and dropping it shows
+    assert np.abs(fast[ok] - want[ok]).max() > 4 * max(np.abs(lit[ok] - want[ok]).max(), 1e-6)
+
+
+def test_partial_nopsc_is_rejected_where_it_is_not_defined(ops):
+    e, d, ixs = _nopsc_problem(9, 64, 40, 8)
+    E64, D64 = ops.CellMatrix.from_genes_major(e, "float64"), ops.CellMatrix.from_genes_major(d, "float64")
+    E32, D32 = ops.CellMatrix.from_genes_major(e, "float32"), ops.CellMatrix.from_genes_major(d, "float32")
+    with pytest.raises(ValueError, match="NOPSC"):
+        ops.coldeltacor_partial(E64, D64, ixs, ops.SQRT, ops.RULES_PARTIAL_NOPSC, 1e-10)
+    with pytest.raises(ValueError, match="NOPSC"):
+        ops.coldeltacor_partial(E32, D32, ixs, ops.LOG10, ops.RULES_PARTIAL_NOPSC, 1e-10)

@@ -530,13 +530,14 @@ class VelocytoLoom(PreprocessMixin):
             self._neigh = neigh
             sched = ops.hilbert_order(embedding) if embedding.shape[1] >= 2 else None      # scheduling only: same numbers in any order
             self.__dict__["_embed_order"] = sched
+            rules = ops.partial_rules_for(e, kern, psc)     # f32 sqrt with a negligible pseudocount: the three-instruction form
             if calculate_randomized:
                 # the reference's two colDeltaCor*partial calls (:1578-1601) share e and the neighbour lists, hence every
                 # A = f(e_i - e_c): one dual-control pass instead of two launches (vcy_coldeltacor_partial_dual)
-                self._corr, self._corr_random = ops.coldeltacor_partial_dual(e, dmat, dmat_r, neigh, kern, ops.RULES_PARTIAL, psc,
+                self._corr, self._corr_random = ops.coldeltacor_partial_dual(e, dmat, dmat_r, neigh, kern, rules, psc,
                                                                              validate=False, order=sched)
             else:
-                self._corr = ops.coldeltacor_partial(e, dmat, neigh, kern, ops.RULES_PARTIAL, psc, validate=False, order=sched)
+                self._corr = ops.coldeltacor_partial(e, dmat, neigh, kern, rules, psc, validate=False, order=sched)
             if ops.corr_fixup(self._corr, neigh, zero_self=True, fix_nan=True, nan_to=1.0):                      # :1604-1607
                 logging.warning("Nans encountered in corrcoef and corrected to 1s. If not identical cells were present it is probably a small isolated cluster converging after imputation.")
             if calculate_randomized:

@@ -86,6 +86,7 @@ class AtlasPath:
         self.knn_mode = knn
         self.dtype = ops.resolve_dtype(dtype)
         self.G, self.k, self.psc = cS.G, int(k), float(psc)
+        self.rules = None                  # ops.partial_rules_for(...) of the first pooled block
         self.rank, self.world = D.world()
         self.c0, self.nloc = int(c0), cS.C
         self.c1 = self.c0 + self.nloc
@@ -246,7 +247,9 @@ class AtlasPath:
                 self._pool(self.cU, self.fU, slice(b0, b1), Ux_b)
             self._pool(self.cS, self.fS, erows_out, e_buf.rows(nb, nb + n_out))
             ev[1].record()
-            ops.coldeltacor_partial_fused(e_buf, Ux_b, gamma, None, ixs, ops.SQRT, ops.RULES_PARTIAL, self.psc, cell0=0, u_row0=0,
+            if self.rules is None:                    # decided once, on the first pooled block (one host sync)
+                self.rules = ops.partial_rules_for(e_buf, ops.SQRT, self.psc)
+            ops.coldeltacor_partial_fused(e_buf, Ux_b, gamma, None, ixs, ops.SQRT, self.rules, self.psc, cell0=0, u_row0=0,
                                           out=self.corr[b0:b1], validate=False)
             ev[2].record()
             if timed:
@@ -413,6 +416,7 @@ def bench_main(a, dev, rank: int, world: int) -> Optional[dict]:
                    "cells": C, "genes": G, "k": a.k, "nrndm": path.nrndm, "blocks_per_rank": len(path.blocks()), "block_cells": path.block_cells,
                    "e_sharded": True, "count_row_halo": path.n_count_halo, "e_halo_rows": path.n_e_halo,
                    "knn_search": ({"mode": "exact, projection-pruned", **path.knn_stats} if path.knn_stats else {"mode": "exact, brute force"}),
+                   "stage_D_rule": ops.RULE_NAMES.get(path.rules, str(path.rules)),
                    "stage_ms": {"A_knn_search": st[2], "A_pooling_from_csr (own cells + e rows outside the block)": st[0], "B_fit_slope": st[1],
                                 "D_coldeltacor": st[3]},
                    "setup_s": setup_s,

@@ -18,6 +18,7 @@
 // VALU/transcendental-bound instead.
 #include <stdlib.h>
 #include "common.h"
+#include <type_traits>
 
 namespace vcy {
 
@@ -38,12 +39,11 @@ template <typename T, int TR, int RULES> __device__ __forceinline__ T xform(T t,
     if (TR == VCY_LINEAR) return t;
     const T a = fabs(t) + psc;
     const T s = (TR == VCY_SQRT) ? fast_sqrt<T>(a) : fast_log10<T>(a);
-    if (TR == VCY_SQRT && RULES == VCY_RULES_PARTIAL)        // hot variant: one v_bfi (copysign) + one compare/select
+    if (TR == VCY_SQRT && RULES != VCY_RULES_FULL)           // partial sqrt: one v_bfi (copysign) + one compare/select
         return (fabs(t) < T(1e-16)) ? T(0) : copysign(s, t);
     T r;
     if (TR == VCY_LOG10 && RULES == VCY_RULES_PARTIAL) r = (t >= T(0)) ? s : -s;
     else r = (t > T(0)) ? s : -s;
-    if (TR == VCY_SQRT && RULES == VCY_RULES_PARTIAL) r = (fabs(t) < T(1e-16)) ? T(0) : r;
     return r;
 }
 
@@ -59,10 +59,22 @@ template <typename T, int TR, int RULES> __device__ __forceinline__ T xform(T t,
 // f32 differences of values above 1e-9) sees a ramp instead of a hard zero.  The f64 parity build keeps the literal rule.
 template <> __device__ __forceinline__ float xform<float, VCY_SQRT, VCY_RULES_PARTIAL>(float t, float psc)
 {
-    // (measured in the kernel, round 2: `|t| + psc -> sqrt -> v_med3(s, -s, t * 2^100)` 96.5 ms and psc held in a VGPR
-    //  102.1 ms against 96.7 ms for this form - the instruction mix is not what the launch waits for at the margin)
+    // (measured in the kernel, round 2: `|t| + psc -> sqrt -> v_med3(s, -s, t * 2^100)` and psc held in a VGPR change nothing)
     const float c = __builtin_amdgcn_fmed3f(fabsf(t) * 0x1p54f, 0.0f, 1.0f);
     return copysignf(fast_sqrt<float>(fmaf(psc, c, fabsf(t))), t);
+}
+
+// VCY_RULES_PARTIAL_NOPSC (f32, sqrt): A = sign(t) sqrt|t| as t * rsq|t| with the legacy multiply (0 * anything = 0: the zero
+// rule of speedboosted.pyx:372 for free, the sign from t) - three instructions (v_sub, v_rsq_f32, v_mul_legacy_f32) where
+// the literal rule needs five.  The pseudocount is dropped: in f32 `|t| + psc` IS `|t|` for every |t| >= 2^24 psc (1.7e-3 at
+// the default 1e-10), below that the two rules differ by sqrt(|t| + psc) - sqrt|t| <= psc / (2 sqrt|t|).  The caller opts in
+// (velocyto_hip.h; the Python layer does when psc <= 1e-9 and the matrix is of ordinary scale); the f64 build has no such
+// form.  llvm.amdgcn.fmul.legacy has no clang builtin in ROCm 7.2: declared by its intrinsic name, so that the compiler
+// (not an asm statement) places it and keeps the wait state a trans result needs before its first use.
+extern "C" __device__ float vcy_fmul_legacy(float, float) __asm("llvm.amdgcn.fmul.legacy");
+template <> __device__ __forceinline__ float xform<float, VCY_SQRT, VCY_RULES_PARTIAL_NOPSC>(float t, float)
+{
+    return vcy_fmul_legacy(t, __builtin_amdgcn_rsqf(fabsf(t)));
 }
 
 // Shifted moments.  Pearson's r does not change when a constant is subtracted from every A[g], so the log10 variants
@@ -299,13 +311,14 @@ __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, c
 // order in which a pair's moments are summed: dual results equal those of two single launches to rounding, not bit for bit.
 constexpr int GRP_NV = 6, GRP_NV_DUAL = 4;
 constexpr int GRP_GC = 8;
+constexpr int GRP_GC_F64 = 6, GRP_NV_F64 = 8;                   // f64, single control: 6 cells, chunks of 8 vectors per lane (1024 genes)
 
 // dynamic LDS of one workgroup: staged rows, sort keys, per-pair accumulators, segment heads, scalars (also used by the host)
 template <typename T> __host__ __device__ inline size_t grouped_lds_bytes(int gc, int nv, bool dual, int64_t maxpairs, int npad)
 {
     const int as = dual ? 4 : 3;
     return (size_t)(dual ? 3 : 2) * gc * nv * 64 * 16 + (size_t)npad * 8 + sizeof(T) * (size_t)as * ((maxpairs + 1) & ~(int64_t)1) +
-           sizeof(int) * (size_t)((maxpairs + 3) & ~(int64_t)1) + (size_t)(64 + 4 * gc) * sizeof(double) + (size_t)(gc + 18) * sizeof(int) + 16;
+           8 * (size_t)(maxpairs + 2) + (size_t)(64 + 4 * gc) * sizeof(double) + (size_t)(gc + 18) * sizeof(int) + 16;
 }
 
 template <typename T, int TR, int RULES, int GC, int NV, bool DUAL>
@@ -327,8 +340,8 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
     T *dc2 = dc + GC * GCHUNK;                                  // [GC][GCHUNK] (DUAL only)
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(dc + (DUAL ? 2 : 1) * GC * GCHUNK);   // [npad]
     T *acc = reinterpret_cast<T *>(keys + npad);                // [AS * maxpairs]
-    int *seg = reinterpret_cast<int *>(acc + AS * ((maxpairs + 1) & ~1));   // [maxpairs + 2]
-    double *part = reinterpret_cast<double *>(seg + ((maxpairs + 3) & ~1)); // [64] per-wave d-moment partials
+    unsigned long long *desc = reinterpret_cast<unsigned long long *>(acc + AS * ((maxpairs + 1) & ~1));   // [maxpairs + 2] row descriptors
+    double *part = reinterpret_cast<double *>(desc + maxpairs + 2);        // [64] per-wave d-moment partials
     // (no static __shared__: statics would precede the dynamic region and break its 16-byte alignment)
     double *s_sb = part + 64, *s_sbb = s_sb + GC, *s_sb2 = s_sbb + GC, *s_sbb2 = s_sb2 + GC;   // [GC] each
     int *s_cells = reinterpret_cast<int *>(s_sbb2 + GC);        // [GC]
@@ -383,12 +396,20 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
             __syncthreads();
         }
     }
-    // segment heads -> seg[] via a block-wide exclusive scan (each thread owns a contiguous run)
+    // rows: a run of pairs with the same neighbour (its members ascend; a member listed twice for one neighbour starts a
+    // new run).  desc[r] = neighbour << 19 | member mask << 11 | first pair: everything a wave needs to fetch the row and to
+    // walk its pairs comes from ONE LDS word (block-wide exclusive scan: each thread owns a contiguous run of keys)
     {
+        static_assert(GC <= 8, "member mask is 8 bits");
+        auto head = [&](int t) {
+            if (t == 0) return true;
+            const unsigned long long a = keys[t] >> 12, b = keys[t - 1] >> 12;
+            return (a >> 4) != (b >> 4) || a == b;
+        };
         const int per = (npad + blockDim.x - 1) / blockDim.x;
         const int t0 = tid * per, t1 = min(npairs, t0 + per);
         int cnt = 0;
-        for (int t = t0; t < t1; ++t) cnt += (t == 0 || (keys[t] >> 16) != (keys[t - 1] >> 16)) ? 1 : 0;
+        for (int t = t0; t < t1; ++t) cnt += head(t) ? 1 : 0;
         int incl = cnt;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
@@ -398,10 +419,14 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
         for (int w = 0; w < wave; ++w) base += s_wavetot[w];
         int rank = base + incl - cnt;
         for (int t = t0; t < t1; ++t)
-            if (t == 0 || (keys[t] >> 16) != (keys[t - 1] >> 16)) seg[rank++] = t;
+            if (head(t)) {
+                unsigned mask = 0;
+                int q = t;
+                do { mask |= 1u << (unsigned)((keys[q] >> 12) & 15); ++q; } while (q < npairs && !head(q));
+                desc[rank++] = ((keys[t] >> 16) << 19) | ((unsigned long long)mask << 11) | (unsigned)t;
+            }
         if (tid == blockDim.x - 1) { s_U = base + incl; }
         __syncthreads();
-        if (tid == 0) seg[s_U] = npairs;
     }
     for (int t = tid; t < AS * npairs; t += blockDim.x) acc[t] = T(0);
     if (tid < 64) part[tid] = 0.0;
@@ -452,124 +477,123 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
                 }
             }
         }
+        if (gl < GCHUNK && sh < snh && sm < gcount)             // short last chunk: the lanes beyond it see zeros (f(0 - 0) adds nothing)
+            for (int v = nvec + sh * 64 + lane; v < NV * 64; v += 64 * snh) {
+                reinterpret_cast<V *>(ec + sm * GCHUNK)[v] = V{};
+                reinterpret_cast<V *>(dc + sm * GCHUNK)[v] = V{};
+                if (DUAL) reinterpret_cast<V *>(dc2 + sm * GCHUNK)[v] = V{};
+            }
         __syncthreads();
-        // rows of this wave, software-pipelined: the next row's chunk is in flight (registers xb) while the
-        // pairs of the current row (xa) are evaluated -- without it every wave sits out a full HBM latency per row
-        auto load_row = [&](V (&x)[NV], int r) {
-            const int i = (int)(keys[seg[r]] >> 16);
-            const T *row = e + (int64_t)i * ld + g0;
+        // ---- rows of this wave.  Nothing in here waits for a latency it could have started earlier:
+        //  * the next row's chunk is in flight (registers xb) while the pairs of the current row (xa) are evaluated;
+        //  * rows are drawn four at a time from an LDS counter (dynamic: rows carry 1..GC pairs, a static split leaves waves
+        //    idle at the chunk barrier); the ticket for the next four is requested at the start of a quad and read two rows
+        //    later, their descriptors are requested then and read one row later;
+        //  * the operand vectors (ec, dc[, dc2] of the pair's member) are read one vector ahead of the arithmetic, across
+        //    pair boundaries too (the first vector of the next pair before this pair's reduction); two register buffers
+        //    alternate (NV is even: no copies at the loop edge).
+        static_assert(NV % 2 == 0, "operand buffers alternate");
+#define VCY_FENCE() __builtin_amdgcn_sched_barrier(0)
+        constexpr int RQ = 4;
+        const int nvu = (nvec + 63) >> 6;                        // vectors per lane that hold genes of this chunk
+        auto load_row = [&](V (&x)[NV], unsigned long long dsc) {
+            const T *row = e + (int64_t)(dsc >> 19) * ld + g0;
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 const int v = lane + 64 * u;
                 if (v < nvec) x[u] = reinterpret_cast<const V *>(row)[v];
+                else x[u] = V{};                                 // short last chunk: zeros against the zeros staged below
             }
         };
-        // pair evaluation.  FULLCHUNK (all NV vectors valid, no ragged tail) is branch-free so that the
-        // compiler batches the 2*NV ds_read_b128 ahead of the arithmetic instead of exposing one LDS
-        // latency per vector; two pairs of a row are evaluated together (independent chains -> ILP for
-        // the DPP reductions and the LDS accumulator updates).
-        auto pair_moments = [&](const V (&x)[NV], int m, bool full, T &tA, T &tAA, T &tAb, T &tAb2) {
-            const T *em = ec + m * GCHUNK, *bm = dc + m * GCHUNK, *bm2 = dc2 + m * GCHUNK;
-            T sA[2], sAA[2], sAb[2], sAb2[2];          // two partial sums per moment and lane: elements (0, 1) and (2, 3) of a vector fold into the SAME
-                                                        // packed accumulator pair (6 registers for three moments; four partials each cost 12)
+        auto eval_row = [&](const V (&x)[NV], unsigned long long dsc) {
+            int p = (int)(dsc & 2047);
+            unsigned mask = (unsigned)(dsc >> 11) & 255u;
+            int m = __builtin_ctz(mask);
+            V eA, bA, b2A, eB, bB, b2B;
+            auto rd = [&](V &ev, V &bv, V &b2v, int mm, int u) {
+                ev = reinterpret_cast<const V *>(ec + mm * GCHUNK)[lane + 64 * u];
+                bv = reinterpret_cast<const V *>(dc + mm * GCHUNK)[lane + 64 * u];
+                if (DUAL) b2v = reinterpret_cast<const V *>(dc2 + mm * GCHUNK)[lane + 64 * u];
+            };
+            rd(eA, bA, b2A, m, 0);
+            while (mask) {
+                mask &= mask - 1;
+                const int mn = mask ? __builtin_ctz(mask) : m;
+                T sA[2], sAA[2], sAb[2], sAb2[2];          // two partial sums per moment and lane: elements (0, 1) and (2, 3) of a vector fold into the SAME
+                                                            // accumulator pair (6 registers for three moments; four partials each cost 12)
 #pragma unroll
-            for (int k = 0; k < 2; ++k) { sA[k] = T(0); sAA[k] = T(0); sAb[k] = T(0); sAb2[k] = T(0); }
-            if (full) {
-                constexpr int HB = DUAL ? 1 : 2;                 // LDS reads batched: 2*HB (dual: 3*HB) b128 in flight per batch
+                for (int k = 0; k < 2; ++k) { sA[k] = T(0); sAA[k] = T(0); sAb[k] = T(0); sAb2[k] = T(0); }
+                auto fold = [&](const V &xv, const V &ev, const V &bv, const V &b2v) {
+                    const T *xp = reinterpret_cast<const T *>(&xv);
+                    const T *ep = reinterpret_cast<const T *>(&ev);
+                    const T *bp = reinterpret_cast<const T *>(&bv);
+                    const T *bp2 = reinterpret_cast<const T *>(&b2v);
 #pragma unroll
-                for (int h = 0; h < NV / HB; ++h) {
-                    V ecv[HB], dcv[HB], dcv2[HB];
-#pragma unroll
-                    for (int u = 0; u < HB; ++u) {
-                        ecv[u] = reinterpret_cast<const V *>(em)[lane + 64 * (h * HB + u)];
-                        dcv[u] = reinterpret_cast<const V *>(bm)[lane + 64 * (h * HB + u)];
-                        if (DUAL) dcv2[u] = reinterpret_cast<const V *>(bm2)[lane + 64 * (h * HB + u)];
+                    for (int k = 0; k < N; ++k) {
+                        T a = xform_s<T, TR, RULES>(xp[k] - ep[k], psc, K);
+                        sA[k & 1] += a;
+                        sAA[k & 1] = fma(a, a, sAA[k & 1]);
+                        sAb[k & 1] = fma(a, bp[k], sAb[k & 1]);
+                        if (DUAL) sAb2[k & 1] = fma(a, bp2[k], sAb2[k & 1]);
                     }
+                };
 #pragma unroll
-                    for (int u = 0; u < HB; ++u) {
-                        const T *xp = reinterpret_cast<const T *>(&x[h * HB + u]);
-                        const T *ep = reinterpret_cast<const T *>(&ecv[u]);
-                        const T *bp = reinterpret_cast<const T *>(&dcv[u]);
-                        const T *bp2 = reinterpret_cast<const T *>(&dcv2[u]);
-#pragma unroll
-                        for (int k = 0; k < N; ++k) {
-                            T a = xform_s<T, TR, RULES>(xp[k] - ep[k], psc, K);
-                            sA[k & 1] += a;
-                            sAA[k & 1] = fma(a, a, sAA[k & 1]);
-                            sAb[k & 1] = fma(a, bp[k], sAb[k & 1]);
-                            if (DUAL) sAb2[k & 1] = fma(a, bp2[k], sAb2[k & 1]);
-                        }
-                    }
+                for (int u = 0; u < NV; u += 2) {
+                    rd(eB, bB, b2B, m, u + 1);
+                    VCY_FENCE();
+                    fold(x[u], eA, bA, b2A);
+                    VCY_FENCE();
+                    if (u + 2 < NV) rd(eA, bA, b2A, m, u + 2); else rd(eA, bA, b2A, mn, 0);
+                    VCY_FENCE();
+                    fold(x[u + 1], eB, bB, b2B);
+                    VCY_FENCE();
                 }
-            } else {
-#pragma unroll
-                for (int u = 0; u < NV; ++u) {
-                    const int v = lane + 64 * u;
-                    if (v < nvec) {
-                        const V ecv = reinterpret_cast<const V *>(em)[v];
-                        const V dcv = reinterpret_cast<const V *>(bm)[v];
-                        V dcv2;
-                        if (DUAL) dcv2 = reinterpret_cast<const V *>(bm2)[v];
-                        const T *xp = reinterpret_cast<const T *>(&x[u]);
-                        const T *ep = reinterpret_cast<const T *>(&ecv);
-                        const T *bp = reinterpret_cast<const T *>(&dcv);
-                        const T *bp2 = reinterpret_cast<const T *>(&dcv2);
-                        const int valid = (ragged && v == nvec - 1) ? (gl - v * N) : N;
-#pragma unroll
-                        for (int k = 0; k < N; ++k) {
-                            T a = xform_s<T, TR, RULES>(xp[k] - ep[k], psc, K);
-                            if (k >= valid) a = T(0);
-                            sA[k & 1] += a;
-                            sAA[k & 1] = fma(a, a, sAA[k & 1]);
-                            sAb[k & 1] = fma(a, bp[k], sAb[k & 1]);
-                            if (DUAL) sAb2[k & 1] = fma(a, bp2[k], sAb2[k & 1]);
-                        }
-                    }
-                }
-            }
-            tA = sA[0] + sA[1]; tAA = sAA[0] + sAA[1]; tAb = sAb[0] + sAb[1]; tAb2 = sAb2[0] + sAb2[1];
-        };
-        const bool fullchunk = (gl == GCHUNK);
-        auto eval_row = [&](const V (&x)[NV], int r) {
-            const int p0 = seg[r], p1 = seg[r + 1];
-            // (two pairs of a row evaluated together - shared row registers, interleaved operand reads and reductions, same
-            //  arithmetic per pair - measured 95.0 vs 95.5 ms: within noise, not kept)
-            for (int p = p0; p < p1; ++p) {
-                const int m0 = (int)((keys[p] >> 12) & 15);       // (reading the next pair's key a pair ahead: no gain, 96.2 vs 95.9 ms)
-                T a0, b0, c0, d0;
-                pair_moments(x, m0, fullchunk, a0, b0, c0, d0);
                 // the three (dual: four) wave totals in one transposing reduction: row r of `tot` holds moment r; lane 16 r
                 // adds it to acc[AS p + r] (the single-control kernel feeds a fourth value nobody reads, so that both
-                // variants sum in the same order: the dual outputs equal those of two single launches bit for bit)
-                const T tot = wave_sum_rows(a0, b0, c0, d0);
+                // variants sum in the same order)
+                const T tot = wave_sum_rows(sA[0] + sA[1], sAA[0] + sAA[1], sAb[0] + sAb[1], sAb2[0] + sAb2[1]);
                 // ds_add_f32 without return: the wave that owns the pair is the only writer of acc[p][.], so the order of the
-                // additions is its program order (deterministic) and nothing waits for the old value (read-modify-write with
-                // its s_waitcnt: 96.7 -> 95.8 ms)
+                // additions is its program order (deterministic) and nothing waits for the old value
                 if ((lane & 15) == 0 && (lane >> 4) < AS)
                     __hip_atomic_fetch_add(&acc[AS * p + (lane >> 4)], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                ++p;
+                m = mn;
             }
         };
+        (void)nvu;
         {
-            // dynamic row scheduling: waves draw the next row from an LDS counter (rows carry 1..GC pairs, a
-            // static round-robin leaves waves idle at the chunk barrier); one row is always in flight ahead
-            auto next_row = [&]() {
-                int r = 0;
-                if (lane == 0) r = atomicAdd(s_next, 1);
-                return __builtin_amdgcn_readfirstlane(r);
+            auto ticket = [&]() { int t = 0; if (lane == 0) t = atomicAdd(s_next, RQ); return t; };     // lane 0 holds the value
+            auto uni = [&](unsigned long long v) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+                return ((unsigned long long)hi << 32) | lo;
             };
             // (rows stay in ascending neighbour order: a longest-first queue measured 4 % slower - it trades the
             //  last few % of balance for scattered HBM pages)
             V xa[NV], xb[NV];
-            int r0 = next_row();
-            if (r0 < U) load_row(xa, r0);
-            while (r0 < U) {
-                const int r1 = next_row();
-                if (r1 < U) load_row(xb, r1);
-                eval_row(xa, r0);
-                if (r1 >= U) break;
-                r0 = next_row();
-                if (r0 < U) load_row(xa, r0);
-                eval_row(xb, r1);
+            int tv = ticket();
+            int q = __builtin_amdgcn_readfirstlane(tv);
+            unsigned long long d0 = 0, d1 = 0, d2_ = 0, d3 = 0;
+            if (q < U) { d0 = uni(desc[q]); d1 = uni(desc[min(q + 1, U - 1)]); d2_ = uni(desc[min(q + 2, U - 1)]); d3 = uni(desc[min(q + 3, U - 1)]); }
+            if (q < U) load_row(xa, d0);
+            while (q < U) {
+                tv = ticket();
+                if (q + 1 < U) load_row(xb, d1);
+                eval_row(xa, d0);
+                if (q + 1 >= U) break;
+                if (q + 2 < U) load_row(xa, d2_);
+                eval_row(xb, d1);
+                const int qn = __builtin_amdgcn_readfirstlane(tv);
+                unsigned long long n0 = 0, n1 = 0, n2 = 0, n3 = 0;                     // requested here, read after the next row
+                if (qn < U) { n0 = desc[qn]; n1 = desc[min(qn + 1, U - 1)]; n2 = desc[min(qn + 2, U - 1)]; n3 = desc[min(qn + 3, U - 1)]; }
+                if (q + 2 >= U) break;
+                if (q + 3 < U) load_row(xb, d3);
+                eval_row(xa, d2_);
+                if (q + 3 >= U) break;
+                if (qn < U) { n0 = uni(n0); n1 = uni(n1); n2 = uni(n2); n3 = uni(n3); }
+                if (qn < U) load_row(xa, n0);
+                eval_row(xb, d3);
+                q = qn; d0 = n0; d1 = n1; d2_ = n2; d3 = n3;
             }
         }
     }
@@ -703,6 +727,7 @@ static int launch_grouped(const void *e, const void *d, const void *d2, const in
     // of `out` (the reference default n_neighbors = C/5, sampled_fraction 0.3 gives nrndm = 3000: 12 tiles; rows of ixs
     // sorted by neighbour index make the tiles of adjacent cells overlap)
     constexpr int64_t TILE_MAX = 256;
+    static_assert(GC * TILE_MAX <= 2048, "a row descriptor holds the first pair of the row in 11 bits");
     *done = false;
     const size_t budget_g = (size_t)(dev.lds_optin > 163840 ? 163840 : dev.lds_optin);
     int64_t ntiles = (nrndm + TILE_MAX - 1) / TILE_MAX, tile = 0;
@@ -755,8 +780,12 @@ static int launch_partial(const void *e, const void *d, const void *d2, const in
     if (rc) return rc;
     if (env_int("VCY_CDC_GROUP", GRP_GC) == GRP_GC) {            // VCY_CDC_GROUP=0: one cell per workgroup (A/B testing)
         bool done = false;
-        rc = d2 ? launch_grouped<T, TR, RULES, GRP_GC, GRP_NV_DUAL, true>(e, d, d2, ixs, out, out2, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st, fuse, dev, &done)
-                : launch_grouped<T, TR, RULES, GRP_GC, GRP_NV, false>(e, d, nullptr, ixs, out, nullptr, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st, fuse, dev, &done);
+        if (d2)
+            rc = launch_grouped<T, TR, RULES, GRP_GC, GRP_NV_DUAL, true>(e, d, d2, ixs, out, out2, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st, fuse, dev, &done);
+        else if constexpr (sizeof(T) == 8)      // f64: 6 cells x 1024 genes (8 vectors per lane) measured 4.5 % faster than 8 x 768
+            rc = launch_grouped<T, TR, RULES, GRP_GC_F64, GRP_NV_F64, false>(e, d, nullptr, ixs, out, nullptr, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st, fuse, dev, &done);
+        else
+            rc = launch_grouped<T, TR, RULES, GRP_GC, GRP_NV, false>(e, d, nullptr, ixs, out, nullptr, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st, fuse, dev, &done);
         if (rc || done) return rc;
     }
     if (d2) {   // small problems: the one-cell-per-workgroup kernel once per control (never fused: d2 is a materialised matrix)
@@ -798,7 +827,9 @@ static int dispatch_partial(const void *e, const void *d, const void *d2, const 
     VCY_CASE(VCY_SQRT, VCY_RULES_FULL)
     VCY_CASE(VCY_LOG10, VCY_RULES_PARTIAL)
     VCY_CASE(VCY_LOG10, VCY_RULES_FULL)
+    if constexpr (std::is_same<T, float>::value) { VCY_CASE(VCY_SQRT, VCY_RULES_PARTIAL_NOPSC) }
 #undef VCY_CASE
+    if (rules == VCY_RULES_PARTIAL_NOPSC) return fail(VCY_ERR_INVALID, "%s: VCY_RULES_PARTIAL_NOPSC is defined for VCY_SQRT on VCY_F32 only", "coldeltacor_partial");
     return fail(VCY_ERR_INVALID, "%s: bad transform/rules", "coldeltacor_partial");
 }
 

@@ -55,7 +55,7 @@ def _partial(emat, dmat, ixs, transform: int, psc: float, dtype) -> np.ndarray:
     ixs = np.require(ixs, requirements="C").astype(np.intp)  # estimation.py:60
     if ixs.ndim != 2 or ixs.shape[0] != C:
         raise ValueError(f"ixs must be (ncells, nneighbours); got {ixs.shape} for {C} cells")
-    comp = ops.coldeltacor_partial(e, d, ixs, transform, ops.RULES_PARTIAL, psc)
+    comp = ops.coldeltacor_partial(e, d, ixs, transform, ops.partial_rules_for(e, transform, psc), psc)
     out = np.zeros((C, C))                                   # estimation.py:58
     blk = _dense_rows_block(C, comp.element_size())
     ix_dev = torch.from_numpy(ixs.astype(np.int32)).to(comp.device)

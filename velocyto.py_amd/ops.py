@@ -20,7 +20,10 @@ from . import _lib
 
 F32, F64, U16, U8 = 0, 1, 2, 3
 LINEAR, SQRT, LOG10 = 0, 1, 2
-RULES_FULL, RULES_PARTIAL = 0, 1
+RULES_FULL, RULES_PARTIAL, RULES_PARTIAL_NOPSC = 0, 1, 2
+PSC_NEGLIGIBLE = 1e-9       # f32 sqrt: a pseudocount at or below this is a candidate for RULES_PARTIAL_NOPSC ...
+RULE_NAMES = {0: "full", 1: "partial (literal, speedboosted.pyx:372-378)", 2: "partial, pseudocount below f32 resolution dropped: sign(t) sqrt|t|"}
+SCALE_ORDINARY = 1e-4       # ... on a matrix whose mean |e| is at least this (psc / scale <= 1e-5, see partial_rules_for)
 TRANSFORMS = {"linear": LINEAR, "sqrt": SQRT, "log10": LOG10, "log": LOG10}
 
 _DT = {torch.float32: F32, torch.float64: F64}
@@ -382,6 +385,19 @@ def _sorted_rows(ix: torch.Tensor, out: torch.Tensor):
     srt, perm = torch.sort(ix, dim=1)
     # the launch buffer starts as the caller's rows in sorted column order: rows the schedule does not name round-trip
     return srt.contiguous(), (perm, out.gather(1, perm)), out
+
+
+def partial_rules_for(e: CellMatrix, transform: int, psc: float) -> int:
+    """The rules value the callers of the *partial kernels pass for the reference's partial rule on this matrix:
+    RULES_PARTIAL_NOPSC (A = sign(t) sqrt|t|, three instructions per gene instead of five) for the sqrt transform on an f32
+    matrix when the pseudocount cannot be told from zero at the matrix's scale - psc <= 1e-9 and mean |e| >= 1e-4 (sampled
+    rows; one device->host sync, so callers decide once per matrix, not per launch) - else RULES_PARTIAL, the literal rule.
+    In f32 `|t| + psc` equals `|t|` for |t| >= 2^24 psc; below that the forms differ by at most psc / (2 sqrt|t|) per gene,
+    which at these scales moves a correlation by less than the f32 rounding of its moment sums (tests/test_gpu_ops.py)."""
+    if transform != SQRT or e.dtype != torch.float32 or not (0.0 <= float(psc) <= PSC_NEGLIGIBLE) or e.C == 0:
+        return RULES_PARTIAL
+    rows = e.t[:: max(1, e.C // 64), : e.G]
+    return RULES_PARTIAL_NOPSC if float(rows.abs().mean()) >= SCALE_ORDINARY else RULES_PARTIAL
 
 
 def coldeltacor_partial(e: CellMatrix, d: CellMatrix, ixs, transform: int, rules: int = RULES_PARTIAL, psc: float = 0.0,
