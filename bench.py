@@ -46,10 +46,13 @@ HBM_PEAK = 8.0e12                 # B/s, MI355X spec (MI355X_MICROARCH.md)
 # VALU issue peak: 256 CUs x 4 SIMD-32, one wave64 instruction per 2 clocks per SIMD at 2.4 GHz (MI355X_MICROARCH.md
 # "Per-instruction cycle constants": v_fma_f32 2 cyc; tools/ubench/valu_issue.hip measures 2.25 for the plain 2-operand ops)
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
-# Issue cost of the instruction mix the transform + three moment updates NEED per element, at the rates measured by
-# tools/ubench/valu_issue.hip (profiles/r02_valu_issue.txt; clocks per wave64 instruction per SIMD): packed sub 4.27/2,
-# |t|*2^54 clamp 2.5, fma with the psc SGPR 4.16, v_sqrt_f32 8.1, v_bfi_b32 4.2, packed add 4.27/2, two packed fma 4.27
-MIX_CLK_PER_ELEMENT = 4.27 / 2 + 2.53 + 4.16 + 8.12 + 4.2 + 4.27 / 2 + 4.27
+# Issue cost of the instruction mix the transform + three moment updates NEED per element, measured as a mix by
+# tools/ubench/valu_issue.hip (profiles/r02_valu_issue.txt; clocks per wave64 instruction per SIMD, 4 waves per SIMD), by branch rule:
+#   1 literal partial sqrt (speedboosted.pyx:372-378): sub, |t|*2^54 clamp, fma with psc, v_sqrt_f32, v_bfi_b32, add, two fma -
+#     "cdc element pair" 4.59 clocks x 6.04 instructions
+#   2 pseudocount dropped (VCY_RULES_PARTIAL_NOPSC, f32): v_sub, v_rsq_f32, v_mul_legacy_f32, v_add, two v_fmac -
+#     "cdc no-psc element" 3.89 clocks x 6 instructions (the parts alone sum to 19.8: a transcendental between plain ops costs more)
+MIX_CLK_PER_ELEMENT = {1: 27.7, 2: 23.3}
 COUNTERS_FILE = os.path.join(ROOT, "profiles", "r02_cdc_counters.json")     # written by tools/summarize_profiles.py from the rocprofv3 passes
 
 
@@ -352,9 +355,23 @@ class Pipeline:
                 best = min(best, e0.elapsed_time(e1))
             return best
         single, dual = run(False), run(True)
-        return {"D_single_ms": single, "D_dual_ms": dual, "dual_over_single": dual / single,
-                "note": "estimate_transition_prob(calculate_randomized=True): real + randomised-control correlations from one "
-                        "vcy_coldeltacor_partial_fused_dual launch; two launches would cost 2.0 x"}
+        out = {"D_single_ms": single, "D_dual_ms": dual, "dual_over_single": dual / single,
+               "note": "estimate_transition_prob(calculate_randomized=True): real + randomised-control correlations from one "
+                       "vcy_coldeltacor_partial_fused_dual launch; two launches would cost 2.0 x"}
+        if self.rules == ops.RULES_PARTIAL_NOPSC:
+            # the same launch with the literal branch rule (pseudocount kept): its cost, and how far ALL correlations move
+            fast = self.corr_loc.clone()
+            e0.record()
+            lit = ops.coldeltacor_partial_fused(self.e_rows, self.Ux_loc, gamma, None, self.neigh_k, ops.SQRT, ops.RULES_PARTIAL, 1e-10,
+                                                cell0=self.e_cell0, u_row0=self.e_cell0, order=self.order, validate=False)
+            e1.record()
+            torch.cuda.synchronize()
+            ok = torch.isfinite(lit)
+            out["literal_rule"] = {"D_single_ms": e0.elapsed_time(e1), "max_abs_dcorr_all_pairs": float((lit[ok] - fast[ok]).abs().max()),
+                                   "nan_pattern_equal": bool(torch.equal(torch.isnan(lit), torch.isnan(fast))),
+                                   "note": "stage D with VCY_RULES_PARTIAL (sign(t) sqrt(|t| + psc), speedboosted.pyx:372-378) instead of the "
+                                           "no-pseudocount form the timed run uses on f32 matrices (ops.partial_rules_for)"}
+        return out
 
 
 def cpu_baseline(pipe, args):
@@ -462,32 +479,39 @@ def run(a, rank, local_rank, world):
         s = 8 if a.dtype == "f64" else 4
         d_ms = float(np.mean(pipe.d_ms))
         stage = pipe.stage_ms / a.steps
-        # ---- dominant kernel.  Work of one launch: pair-genes, and pair-chunks of 1536 (f32) / 768 (f64) genes
+        # ---- dominant kernel.  Work of one launch: pair-genes, and pair-chunks of 1536 (f32) / 1024 (f64) genes
         pair_genes = float(nloc) * nr * G
-        chunk = 6 * 64 * (16 // s)
+        chunk = (6 if s == 4 else 8) * 64 * (16 // s)               # genes per chunk: f32 8 cells x 6 vectors, f64 6 cells x 8 vectors
         pair_chunks = float(nloc) * nr * ((G + chunk - 1) // chunk)
         alg_bytes = nloc * ((nr + 2) * G * s + nr * (4 + s))            # (nrndm+2)*G*s + nrndm*(idx+out) per cell, no reuse credited
         cnt = load_counters() if a.dtype == "f32" else {}
+        if cnt.get("rules") != pipe.rules:                               # the committed counters are of the other branch rule
+            cnt = {}
         instr = cnt.get("valu_insts_per_pair_chunk", None)
         default_wl = (C, G, nr, a.k, world, a.order, a.fuse, a.curve, a.dtype, a.counts) == (50000, 30000, 250, 30, 1, "embedding", True, "hilbert", "f32", "auto")
         traffic = a.traffic_bytes if a.traffic_bytes is not None else (cnt.get("hbm_bytes_per_launch") if default_wl else None)
-        roof = {"bound": "valu", "kernel": f"k_cdc_partial_grouped<{'float' if s == 4 else 'double'}, SQRT, PARTIAL, 8 cells, 6 vectors> (velocity chain folded in)",
+        rule_name = pipe.ops.RULE_NAMES.get(pipe.rules, str(pipe.rules))
+        shape = "8 cells, 6 vectors" if s == 4 else "6 cells, 8 vectors"
+        roof = {"bound": "valu", "kernel": f"k_cdc_partial_grouped<{'float' if s == 4 else 'double'}, SQRT, rules {pipe.rules}, {shape}> (velocity chain folded in)",
+                "branch_rule": rule_name,
                 "unit": "Ginstr/s", "peak": VALU_ISSUE_PEAK / 1e9, "avg_launch_ms": d_ms,
                 "peak_is": "VALU issue: 1024 SIMD-32 x 2.4 GHz / 2 clocks per wave64 instruction (MI355X_MICROARCH.md); f32 plain ops measure 2.25 clocks"}
         if instr is not None:
             achieved = instr * pair_chunks / (d_ms * 1e-3)
             roof.update({"achieved": achieved / 1e9, "frac": achieved / VALU_ISSUE_PEAK,
-                         "valu_insts_per_launch": instr * pair_chunks, "counters_from": os.path.relpath(COUNTERS_FILE, ROOT)})
-            mix_floor_ms = pair_genes * MIX_CLK_PER_ELEMENT / 64.0 / (1024 * 2.4e9) * 1e3
-            roof.update({"mix_floor_ms": mix_floor_ms, "frac_of_mix_floor": mix_floor_ms / d_ms})
+                         "valu_insts_per_launch": instr * pair_chunks, "counters_from": os.path.relpath(COUNTERS_FILE, ROOT),
+                         "wave_time": cnt.get("wave_time")})
         else:
             roof.update({"achieved": None, "frac": None, "counters_from": None})
+        if s == 4 and pipe.rules in MIX_CLK_PER_ELEMENT:
+            mix_floor_ms = pair_genes * MIX_CLK_PER_ELEMENT[pipe.rules] / 64.0 / (1024 * 2.4e9) * 1e3
+            roof.update({"mix_clk_per_element": MIX_CLK_PER_ELEMENT[pipe.rules], "mix_floor_ms": mix_floor_ms, "frac_of_mix_floor": mix_floor_ms / d_ms})
         roof.update({"traffic": traffic, "hbm_frac_measured": (traffic / (d_ms * 1e-3) / HBM_PEAK) if traffic else None,
                      "algorithmic_bytes_per_launch": alg_bytes, "vs_noreuse_model": alg_bytes / (d_ms * 1e-3) / HBM_PEAK,
                      "note": "VALU-issue-bound: `achieved` = SQ_INSTS_VALU of this kernel (rocprofv3 pass in counters_from, per pair-chunk, scaled "
                              "by this run's exact pair-chunk count) / HIP-event launch time; `frac` is against the issue peak of one plain "
-                             "instruction per 2 clocks per SIMD.  The mix the arithmetic needs is slower than that (v_sqrt_f32 8 clocks, packed "
-                             "ops / v_bfi / SGPR-operand VOP3 4): `mix_floor_ms` is the issue time of that mix alone at the measured rates "
+                             "instruction per 2 clocks per SIMD.  The mix the arithmetic needs is slower than that (v_rsq_f32 / v_sqrt_f32 8 clocks, "
+                             "v_bfi / SGPR-operand VOP3 4): `mix_floor_ms` is the issue time of that mix alone at the measured rates "
                              "(tools/ubench/valu_issue.hip), `frac_of_mix_floor` = mix_floor_ms / launch time.  HBM is not the limit: "
                              "`traffic` (2*FETCH_SIZE + WRITE_SIZE of the PMC passes) is `hbm_frac_measured` of 8 TB/s; `vs_noreuse_model` "
                              "is SURVEY 8(d)'s no-reuse byte model over launch time over 8 TB/s (above 1: neighbour rows are shared by the "
@@ -522,6 +546,7 @@ def run(a, rank, local_rank, world):
                                       ", all-gather of correlation rows",
                        "stage_ms": {"A_knn_imputation": stage[0], "B_fit_slope": stage[1], "C_velocity_chain": stage[2],
                                     "D_exchange": stage[3], "D_coldeltacor": stage[4]},
+                       "stage_D_rule": rule_name,
                        "velocity_chain": "folded into the staging of d[c] in the stage-D kernel" if a.fuse else "k_velocity_chain (dmat materialised)",
                        "cell_order_D": a.order + (f" ({a.curve} curve)" if a.order == "embedding" else "")},
             "roofline": roof, "stages": stages,

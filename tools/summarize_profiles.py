@@ -62,14 +62,20 @@ dur = [d / n for (cn, kn), (n, v, d) in acc.items() if "k_cdc_partial_grouped<fl
 if "SQ_INSTS_VALU" in cdc:
     cells, genes, nrndm = 50000, 30000, 250                       # the default workload of bench.py, which profile_round.sh runs
     pair_chunks = cells * nrndm * ((genes + 1535) // 1536)
-    rec = {"profile": f"profiles/{tag}_bench_50kx30k_pmc.csv", "kernel": "k_cdc_partial_grouped<float, SQRT, PARTIAL, 8, 6> (FuseArgs)",
+    kname = next(kn for (cn, kn) in acc if "k_cdc_partial_grouped<float" in kn and cn == "SQ_INSTS_VALU")
+    rule = {"1": "partial (literal)", "2": "partial, pseudocount dropped (VCY_RULES_PARTIAL_NOPSC)", "0": "full"}.get(kname.split("<")[1].split(",")[2].strip(), "?")
+    wc = cdc.get("SQ_WAVE_CYCLES")
+    rec = {"profile": f"profiles/{tag}_bench_50kx30k_pmc.csv", "kernel": kname.split("(")[0].replace("void vcy::", ""), "rules": int(kname.split("<")[1].split(",")[2]),
+           "rule": rule,
            "workload": {"cells": cells, "genes": genes, "nrndm": nrndm, "pair_chunks_per_launch": pair_chunks},
            "SQ_INSTS_VALU_per_launch": cdc["SQ_INSTS_VALU"], "valu_insts_per_pair_chunk": cdc["SQ_INSTS_VALU"] / pair_chunks,
            "valu_insts_per_pair_gene": cdc["SQ_INSTS_VALU"] / (float(cells) * nrndm * genes),
            "FETCH_SIZE_KiB": cdc.get("FETCH_SIZE"), "WRITE_SIZE_KiB": cdc.get("WRITE_SIZE"),
            "hbm_bytes_per_launch": (2 * cdc["FETCH_SIZE"] + cdc["WRITE_SIZE"]) * 1024 if "FETCH_SIZE" in cdc and "WRITE_SIZE" in cdc else None,
            "profiled_launch_ms": dur[0] / 1e6 if dur else None,
-           "SQ_ACTIVE_INST_VALU_x4_over_SQ_WAVE_CYCLES": (4 * cdc["SQ_ACTIVE_INST_VALU"] / cdc["SQ_WAVE_CYCLES"]) if "SQ_WAVE_CYCLES" in cdc and "SQ_ACTIVE_INST_VALU" in cdc else None,
+           # where a wave's time goes (fractions of SQ_WAVE_CYCLES; the three are disjoint, MI355X_MICROARCH.md counters table)
+           "wave_time": {k: (cdc[c] / wc if wc and c in cdc else None) for k, c in
+                         (("parked_at_waitcnt_or_barrier", "SQ_WAIT_ANY"), ("waiting_to_issue", "SQ_WAIT_INST_ANY"), ("issuing", "SQ_ACTIVE_INST_ANY"))},
            "note": "counters of ONE launch under rocprofv3 --pmc (separate passes for FETCH_SIZE, WRITE_SIZE and the SQ set); HBM-side read bytes = 2 x "
                    "FETCH_SIZE x 1024 on gfx950 (MI355X_MICROARCH.md, HBM)"}
     with open(os.path.join(OUT, "r02_cdc_counters.json"), "w") as f:

@@ -78,6 +78,20 @@
 #define PSWAP16(x) asm volatile("v_permlane16_swap_b32_e32 %0, %1" : "+v"(x), "+v"(b0));
 #define CNDVCC(x) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(x) : "v"(b1));
 #define DPPSHR(x) asm volatile("v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(x));
+// round 2, second edition: the no-pseudocount element (csrc/coldeltacor.hip, VCY_RULES_PARTIAL_NOPSC): sub, rsq|t|, legacy mul, add, 2 fmac
+#define RSQA(x) asm volatile("v_rsq_f32_e64 %0, |%0|" : "+v"(x));
+#define MULLEG(x) asm volatile("v_mul_legacy_f32 %0, %0, %1" : "+v"(x) : "v"(b1));
+#define SUBV(x) asm volatile("v_sub_f32_e32 %0, %0, %1" : "+v"(x) : "v"(b1));
+#define MIXD(x1, y1, x2, y2) SUBV(x1) SUBV(x2) asm volatile("v_rsq_f32_e64 %0, |%1|" : "=v"(y1) : "v"(x1)); asm volatile("v_rsq_f32_e64 %0, |%1|" : "=v"(y2) : "v"(x2)); \
+    asm volatile("v_mul_legacy_f32 %0, %1, %0" : "+v"(y1) : "v"(x1)); asm volatile("v_mul_legacy_f32 %0, %1, %0" : "+v"(y2) : "v"(x2)); \
+    asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(ac) : "v"(y1)); asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(ad) : "v"(y2)); \
+    asm volatile("v_fmac_f32_e32 %0, %1, %1" : "+v"(ae) : "v"(y1)); asm volatile("v_fmac_f32_e32 %0, %1, %1" : "+v"(af) : "v"(y2)); \
+    asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(aa) : "v"(y1), "v"(b0)); asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(ab) : "v"(y2), "v"(b0));
+#define E8D MIXD(a0, a4, a1, a5) MIXD(a2, a6, a3, a7) MIXD(a0, a8, a1, a9) MIXD(a2, a4, a3, a5)
+K(k_rsqa, A16(RSQA))
+K(k_mulleg, A16(MULLEG))
+K(k_subv, A16(SUBV))
+K(k_elem_d, E8D)
 K(k_pswap32, A16(PSWAP32))
 K(k_pswap16, A16(PSWAP16))
 K(k_cndvcc, A16(CNDVCC))
@@ -151,6 +165,8 @@ int main()
         run("v_add_dpp row_shr:4", k_dppshr, w, 16);
         run("16 v_add + 1 mfma16x16x4f32", k_add16m, w, 16); run("16 v_add + 3 mfma (3 acc)", k_add16m3, w, 16);
         run("cdc mix B (add,sqrt,mul,med3)", k_elem2b, w, 8 * 12); run("cdc mix C (vgpr psc fma)", k_elem2c, w, 8 * 12);
+        run("v_rsq_f32 |v|", k_rsqa, w, 16); run("v_mul_legacy_f32", k_mulleg, w, 16); run("v_sub_f32", k_subv, w, 16);
+        run("cdc no-psc element x8 (6 instr each)", k_elem_d, w, 8 * 6);
         printf("\n");
     }
     return 0;
