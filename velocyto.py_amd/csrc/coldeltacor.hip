@@ -294,12 +294,14 @@ __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, c
 // from HBM once and correlated against each of them out of LDS.  At 50k cells / nrndm 250 a group
 // of 8 shares each row 3.5x on average (tools/neighbor_overlap.py), which moves the kernel from the
 // HBM roofline to the VALU/transcendental one.
-//   1. (neighbour, member, slot) keys of the group are bitonic-sorted in LDS; equal neighbours form
-//      segments (row r -> pairs seg[r]..seg[r+1]).
+//   1. (neighbour, member, slot) keys of the group are bitonic-sorted in LDS; a run of equal neighbours is a ROW and
+//      gets one 8-byte descriptor: neighbour << 19 | mask of the members that list it << 11 | first pair of the run.
 //   2. genes are walked in chunks of NV*64 vectors; e[c_m], d[c_m] of all members are staged in LDS.
-//   3. wave w takes rows r = w, w+nwaves, ...: loads the row chunk ONCE into registers, then for each
-//      pair of the segment accumulates the three raw moments against member m's LDS copy, reduces
-//      over the wave and adds into acc[pair] (owned by that wave: deterministic, no atomics).
+//   3. waves draw rows four at a time from an LDS counter: a wave loads the row chunk ONCE into registers (the next row
+//      is in flight meanwhile), then for each member of the mask accumulates the three raw moments against that member's
+//      LDS copy - operands read one vector ahead of the arithmetic -, reduces over the wave and adds into acc[pair]
+//      (ds_add_f32 by the only wave that owns the pair in this chunk: program order, deterministic).
+//      No LDS round trip is left exposed in the row loop ("the latency chain removed").
 // Dual control (DUAL): estimate_transition_prob's default computes every correlation twice, against d and against the
 // randomised control d2 = f(permute_rows_nsign(delta_S)) (analysis.py:1539-1542, 1578-1601).  Both passes share e, the
 // neighbour lists and therefore every A = f(e_i - e_c); the dual kernel stages d2[c] beside d[c] and keeps a fourth
