@@ -276,6 +276,10 @@ extern "C" int vcy_knn_pool_counts(const void *countsS, const void *countsU, con
     const int64_t blocks = nslab * ((C_out + 7) / 8 * 8);
     VCY_REQUIRE(blocks < (1LL << 31), "knn_pool_counts: grid too large");
     hipStream_t st = as_stream(stream);
+    // (Round 2, measured and not kept: one wave per (cell, 64 x 16-byte slab) that reads all its neighbour indices and weights with
+    //  two vector loads, hands them out by v_readlane and keeps a ring of 5 row gathers in flight - no scalar-load chain per group of
+    //  four neighbours - ran the uint8 layers in 9.0 instead of 7.9 ms and the uint16 layers in 11.5 instead of 10.9: the kernel is
+    //  not waiting on that chain but on the L2 -> CU path, 93 GB of row gathers per pass = 11.6 TB/s at an 88 % L2 hit rate.)
     // one launch per layer: pooling both layers in one launch shares the index / weight reads but doubles the accumulators
     // (uint8: 130 VGPRs, 3 waves per SIMD) and measured slower at 50k x 30k - uint16 11.9 vs 11.0 ms, uint8 9.6 vs 8.4 ms
 #define VCY_POOLC(T, CT)                                                                                                                       \
