@@ -8,9 +8,9 @@ export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline --no-extra --steps 1 --warmup 0"
 one() {
   rm -rf /tmp/pm_$1_a /tmp/pm_$1_b
-  (cd /tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
+  (cd /tmp && timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
       --kernel-trace --output-format csv -d /tmp/pm_$1_a -- $B > /tmp/pm_$1_a.log 2>&1)
-  (cd /tmp && rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_WAIT_INST_LDS \
+  (cd /tmp && timeout 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_WAIT_INST_LDS \
       --kernel-trace --output-format csv -d /tmp/pm_$1_b -- $B > /tmp/pm_$1_b.log 2>&1)
   python - "$1" <<'PY'
 import csv, glob, sys, collections
