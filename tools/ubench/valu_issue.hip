@@ -88,6 +88,22 @@
     asm volatile("v_fmac_f32_e32 %0, %1, %1" : "+v"(ae) : "v"(y1)); asm volatile("v_fmac_f32_e32 %0, %1, %1" : "+v"(af) : "v"(y2)); \
     asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(aa) : "v"(y1), "v"(b0)); asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(ab) : "v"(y2), "v"(b0));
 #define E8D MIXD(a0, a4, a1, a5) MIXD(a2, a6, a3, a7) MIXD(a0, a8, a1, a9) MIXD(a2, a4, a3, a5)
+// the same element, four interleaved (sub x4, rsq x4, mul x4, add x4, fmac x8) and eight interleaved
+#define RSQ2(y, x) asm volatile("v_rsq_f32_e64 %0, |%1|" : "=v"(y) : "v"(x));
+#define MULL2(y, x) asm volatile("v_mul_legacy_f32 %0, %1, %0" : "+v"(y) : "v"(x));
+#define ADD2(s, y) asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(s) : "v"(y));
+#define FMAC2(s, y) asm volatile("v_fmac_f32_e32 %0, %1, %1" : "+v"(s) : "v"(y));
+#define FMAC3(s, y) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(s) : "v"(y), "v"(b0));
+#define MIXD4 SUBV(a0) SUBV(a1) SUBV(a2) SUBV(a3) RSQ2(a4, a0) RSQ2(a5, a1) RSQ2(a6, a2) RSQ2(a7, a3) MULL2(a4, a0) MULL2(a5, a1) MULL2(a6, a2) MULL2(a7, a3) \
+    ADD2(ac, a4) ADD2(ad, a5) ADD2(ac, a6) ADD2(ad, a7) FMAC2(ae, a4) FMAC2(af, a5) FMAC2(ae, a6) FMAC2(af, a7) FMAC3(aa, a4) FMAC3(ab, a5) FMAC3(aa, a6) FMAC3(ab, a7)
+#define MIXD8 SUBV(a0) SUBV(a1) SUBV(a2) SUBV(a3) SUBV(p0.x) SUBV(p0.y) SUBV(p1.x) SUBV(p1.y) \
+    RSQ2(a4, a0) RSQ2(a5, a1) RSQ2(a6, a2) RSQ2(a7, a3) RSQ2(p2.x, p0.x) RSQ2(p2.y, p0.y) RSQ2(p3.x, p1.x) RSQ2(p3.y, p1.y) \
+    MULL2(a4, a0) MULL2(a5, a1) MULL2(a6, a2) MULL2(a7, a3) MULL2(p2.x, p0.x) MULL2(p2.y, p0.y) MULL2(p3.x, p1.x) MULL2(p3.y, p1.y) \
+    ADD2(ac, a4) ADD2(ad, a5) ADD2(ac, a6) ADD2(ad, a7) ADD2(ac, p2.x) ADD2(ad, p2.y) ADD2(ac, p3.x) ADD2(ad, p3.y) \
+    FMAC2(ae, a4) FMAC2(af, a5) FMAC2(ae, a6) FMAC2(af, a7) FMAC2(ae, p2.x) FMAC2(af, p2.y) FMAC2(ae, p3.x) FMAC2(af, p3.y) \
+    FMAC3(aa, a4) FMAC3(ab, a5) FMAC3(aa, a6) FMAC3(ab, a7) FMAC3(aa, p2.x) FMAC3(ab, p2.y) FMAC3(aa, p3.x) FMAC3(ab, p3.y)
+K(k_elem_d4, MIXD4 MIXD4)
+K(k_elem_d8, MIXD8)
 K(k_rsqa, A16(RSQA))
 K(k_mulleg, A16(MULLEG))
 K(k_subv, A16(SUBV))
@@ -167,6 +183,7 @@ int main()
         run("cdc mix B (add,sqrt,mul,med3)", k_elem2b, w, 8 * 12); run("cdc mix C (vgpr psc fma)", k_elem2c, w, 8 * 12);
         run("v_rsq_f32 |v|", k_rsqa, w, 16); run("v_mul_legacy_f32", k_mulleg, w, 16); run("v_sub_f32", k_subv, w, 16);
         run("cdc no-psc element x8 (6 instr each)", k_elem_d, w, 8 * 6);
+        run("same, 4 elements interleaved", k_elem_d4, w, 8 * 6); run("same, 8 elements interleaved", k_elem_d8, w, 8 * 6);
         printf("\n");
     }
     return 0;
