@@ -33,8 +33,10 @@ def timed(fn, n=3):
     return min(ts) * 1e3
 
 
-single = timed(lambda: ops.coldeltacor_partial(S, d, neigh, ops.SQRT, ops.RULES_PARTIAL, 1e-10, order=order, out=o1, validate=False))
-ops.coldeltacor_partial(S, d2, neigh, ops.SQRT, ops.RULES_PARTIAL, 1e-10, order=order, out=o2, validate=False)
-dual = timed(lambda: ops.coldeltacor_partial_dual(S, d, d2, neigh, ops.SQRT, ops.RULES_PARTIAL, 1e-10, order=order, out=p1, out_rndm=p2, validate=False))
+rules = ops.RULES_PARTIAL if os.environ.get("LITERAL") else ops.partial_rules_for(S, ops.SQRT, 1e-10)
+print("rule:", ops.RULE_NAMES[rules])
+single = timed(lambda: ops.coldeltacor_partial(S, d, neigh, ops.SQRT, rules, 1e-10, order=order, out=o1, validate=False))
+ops.coldeltacor_partial(S, d2, neigh, ops.SQRT, rules, 1e-10, order=order, out=o2, validate=False)
+dual = timed(lambda: ops.coldeltacor_partial_dual(S, d, d2, neigh, ops.SQRT, rules, 1e-10, order=order, out=p1, out_rndm=p2, validate=False))
 same = float(torch.nan_to_num(o1 - p1).abs().max()), float(torch.nan_to_num(o2 - p2).abs().max())
 print(f"single launch {single:.2f} ms   two launches {2 * single:.2f} ms   dual launch {dual:.2f} ms   dual/single {dual / single:.3f}   max |dual - single| {same}")

@@ -307,11 +307,12 @@ __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, c
 // neighbour lists and therefore every A = f(e_i - e_c); the dual kernel stages d2[c] beside d[c] and keeps a fourth
 // running moment sum A*b2 per pair: one more FMA and one more LDS read per element instead of a second launch.
 // Shape of a workgroup: GC cells, chunks of NV 16-byte vectors per lane (NV * 64 * 4 f32 genes).  The dual variant stages
-// three arrays per member in the same 160 KiB, so its chunk is 1024 genes instead of 1536 (30 instead of 20 chunks at 30k
-// genes); measured at 50k x 30k, nrndm 250: 8 cells x 1024 genes 110.0 ms, 6 cells x 1536 genes 118.5 ms, one single-control
-// launch 95.1 ms, i.e. the second correlation costs 16 % instead of 100 % (tools/bench_dual.py).  The chunking sets the
-// order in which a pair's moments are summed: dual results equal those of two single launches to rounding, not bit for bit.
-constexpr int GRP_NV = 6, GRP_NV_DUAL = 4;
+// three arrays per member in the same 160 KiB: 6 cells x 1536 genes (the d-moment partials share the memory of the row
+// descriptors to make it fit).  Same chunk length as the single kernel, hence the same order of summation: each dual output
+// equals the single launch bit for bit.  Measured at 50k x 30k, nrndm 250, literal rule: 6 x 1536 103.2 ms, 8 x 1024 105.3 ms,
+// one single-control launch 90.6 ms (before the row-loop restructure 6 x 1536 lost to 8 x 1024, 118.5 vs 110.0 ms).
+constexpr int GRP_NV = 6;
+constexpr int GRP_GC_DUAL = 6, GRP_NV_DUAL = 6;                 // dual control: three staged arrays per member -> 6 cells at the single kernel's chunk length
 constexpr int GRP_GC = 8;
 constexpr int GRP_GC_F64 = 6, GRP_NV_F64 = 8;                   // f64, single control: 6 cells, chunks of 8 vectors per lane (1024 genes)
 
@@ -320,7 +321,7 @@ template <typename T> __host__ __device__ inline size_t grouped_lds_bytes(int gc
 {
     const int as = dual ? 4 : 3;
     return (size_t)(dual ? 3 : 2) * gc * nv * 64 * 16 + (size_t)npad * 8 + sizeof(T) * (size_t)as * ((maxpairs + 1) & ~(int64_t)1) +
-           8 * (size_t)(maxpairs + 2) + (size_t)(64 + 4 * gc) * sizeof(double) + (size_t)(gc + 18) * sizeof(int) + 16;
+           8 * (size_t)(maxpairs + 2 > 64 + 4 * gc ? maxpairs + 2 : 64 + 4 * gc) + (size_t)(gc + 18) * sizeof(int) + 16;
 }
 
 template <typename T, int TR, int RULES, int GC, int NV, bool DUAL>
@@ -343,10 +344,12 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(dc + (DUAL ? 2 : 1) * GC * GCHUNK);   // [npad]
     T *acc = reinterpret_cast<T *>(keys + npad);                // [AS * maxpairs]
     unsigned long long *desc = reinterpret_cast<unsigned long long *>(acc + AS * ((maxpairs + 1) & ~1));   // [maxpairs + 2] row descriptors
-    double *part = reinterpret_cast<double *>(desc + maxpairs + 2);        // [64] per-wave d-moment partials
+    // the d-moment partials ([64] per wave, then [GC] x 4 totals) are written after the last chunk, when the row descriptors
+    // are dead: they share the descriptors' memory (grouped_lds_bytes sizes it for the larger of the two)
+    double *part = reinterpret_cast<double *>(desc);
     // (no static __shared__: statics would precede the dynamic region and break its 16-byte alignment)
     double *s_sb = part + 64, *s_sbb = s_sb + GC, *s_sb2 = s_sbb + GC, *s_sbb2 = s_sb2 + GC;   // [GC] each
-    int *s_cells = reinterpret_cast<int *>(s_sbb2 + GC);        // [GC]
+    int *s_cells = reinterpret_cast<int *>(desc + max(maxpairs + 2, 64 + 4 * GC));        // [GC]
     int *s_wavetot = s_cells + GC;                              // [16]
     int &s_U = s_wavetot[16];
     int *s_next = s_wavetot + 17;                               // dynamic row counter
@@ -431,7 +434,6 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
         __syncthreads();
     }
     for (int t = tid; t < AS * npairs; t += blockDim.x) acc[t] = T(0);
-    if (tid < 64) part[tid] = 0.0;
     __syncthreads();
     const int U = s_U;
     const T K = xform_shift<T, TR, RULES>(psc);
@@ -601,6 +603,7 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
     }
     psb = wave_sum(psb); psbb = wave_sum(psbb);
     if (DUAL) { psb2 = wave_sum(psb2); psbb2 = wave_sum(psbb2); }
+    __syncthreads();                                            // every wave is through with the row descriptors: `part` takes their place
     if (lane == 0) {
         part[PW * wave] = psb; part[PW * wave + 1] = psbb;
         if (DUAL) { part[PW * wave + 2] = psb2; part[PW * wave + 3] = psbb2; }
@@ -783,7 +786,7 @@ static int launch_partial(const void *e, const void *d, const void *d2, const in
     if (env_int("VCY_CDC_GROUP", GRP_GC) == GRP_GC) {            // VCY_CDC_GROUP=0: one cell per workgroup (A/B testing)
         bool done = false;
         if (d2)
-            rc = launch_grouped<T, TR, RULES, GRP_GC, GRP_NV_DUAL, true>(e, d, d2, ixs, out, out2, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st, fuse, dev, &done);
+            rc = launch_grouped<T, TR, RULES, GRP_GC_DUAL, GRP_NV_DUAL, true>(e, d, d2, ixs, out, out2, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st, fuse, dev, &done);
         else if constexpr (sizeof(T) == 8)      // f64: 6 cells x 1024 genes (8 vectors per lane) measured 4.5 % faster than 8 x 768
             rc = launch_grouped<T, TR, RULES, GRP_GC_F64, GRP_NV_F64, false>(e, d, nullptr, ixs, out, nullptr, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st, fuse, dev, &done);
         else
