@@ -105,9 +105,10 @@ int vcy_coldeltacor_partial_fused(const void *Sx_sz, const void *Ux_sz, const fl
  * reference's default (analysis.py:1539-1542: delta_S_rndm = permute_rows_nsign(delta_S); :1578-1601: the second
  * colDeltaCor*partial call with dmat_rndm on the SAME e and neighbour lists), in ONE pass: A = f(e_i - e_c) is evaluated
  * once per pair and gene and correlated against both d[c] and d_rndm[c].  out_rndm has the shape of out; d_rndm the row
- * range of d.  Each output equals what vcy_coldeltacor_partial returns for that d alone up to the rounding of the moment
- * sums (the dual kernel walks the genes in shorter chunks; f32 1e-6, f64 1e-13 absolute on the correlations); problems
- * too small for the grouped kernel (< 8 neighbours or < 32 cells) run the single kernel twice.                          */
+ * range of d.  Each output equals what vcy_coldeltacor_partial returns for that d alone: bit for bit on
+ * VCY_F32 (same chunk length, hence the same order of summation), up to the rounding of the moment sums on VCY_F64 (the
+ * f64 single kernel walks longer chunks; 1e-13 absolute on the correlations); problems too small for the grouped kernel
+ * (< 8 neighbours or < 24 cells) run the single kernel twice.                                                           */
 int vcy_coldeltacor_partial_dual(const void *e, const void *d, const void *d_rndm, const int32_t *ixs, void *out, void *out_rndm,
                                  const int32_t *order, int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int64_t d_row0,
                                  int64_t nrndm, int transform, int rules, double psc, int dtype, vcy_stream stream);
