@@ -1,0 +1,39 @@
+"""Stage D alone on the shapes the documents quote besides the headline: the first 1/8, 1/4, 1/2 and all of the 50 000 cells
+(what one rank of an 8 / 4 / 2 / 1-GPU run computes; last-round tiles) and the reference's default list width
+(n_neighbors = C/5, sampled_fraction = 0.3 -> nrndm = 3000, walked in column tiles)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import velocyto_amd
+from velocyto_amd import ops
+import bench
+
+dev = ops.require_gpu()
+C, G = int(os.environ.get("C", 50000)), int(os.environ.get("G", 30000))
+S, U, pcs = bench.synth(C, G, 30, dev)
+emb = pcs[:, :2].contiguous()
+d = ops.CellMatrix(torch.randn_like(S.t), G)
+rules = ops.partial_rules_for(S, ops.SQRT, 1e-10)
+print("rule:", ops.RULE_NAMES[rules])
+
+
+def best(f, reps=3):
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); f(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    return min(ts) * 1e3
+
+
+neigh, _ = bench.sample_neighbors_device(emb, 500, 0.5, dev)
+perm = ops.hilbert_order(emb).long()                     # a rank's cells are a contiguous piece of the curve
+for n in (C // 8, C // 4, C // 2, C):
+    cells = perm[:n].to(torch.int32).contiguous()        # schedule over a subset: only those rows are written
+    out = torch.empty((C, neigh.shape[1]), dtype=torch.float32, device=dev)
+    ms = best(lambda: ops.coldeltacor_partial(S, d, neigh, ops.SQRT, rules, 1e-10, order=cells, out=out, validate=False))
+    print(f"nrndm {neigh.shape[1]:5d}  cells {n:6d}  {ms:8.2f} ms  {ms / n * 1e3:6.3f} us per cell")
+if not os.environ.get("SKIP_WIDE"):
+    wide, _ = bench.sample_neighbors_device(emb, C // 5, 0.3, dev)
+    out = torch.empty((C, wide.shape[1]), dtype=torch.float32, device=dev)
+    order = ops.hilbert_order(emb)
+    ms = best(lambda: ops.coldeltacor_partial(S, d, wide, ops.SQRT, rules, 1e-10, order=order, out=out, validate=False), reps=2)
+    print(f"nrndm {wide.shape[1]:5d}  cells {C:6d}  {ms:8.2f} ms  {ms / C * 1e3:6.3f} us per cell")
