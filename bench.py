@@ -553,6 +553,11 @@ def run(a, rank, local_rank, world):
         }
         if world == 1 and not a.no_extra and a.dtype == "f32" and a.counts == "auto":
             res["extra"] = extra_lines(a, dev, pipe)
+            lit = res["extra"].get("randomised_control", {}).get("literal_rule")
+            if lit:                                  # the whole pass with the literal rule in stage D: this run's other stages + the literal launch
+                ms_lit = ms_per_step - d_ms + lit["D_single_ms"]
+                lit["whole_pass_ms"] = ms_lit
+                lit["whole_pass_cells_per_s"] = C / (ms_lit * 1e-3)
         if not a.no_cpu_baseline and world == 1:     # reported on rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(pipe, a)
     finish(res, rank)
