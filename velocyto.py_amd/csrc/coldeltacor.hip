@@ -499,7 +499,6 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
         static_assert(NV % 2 == 0, "operand buffers alternate");
 #define VCY_FENCE() __builtin_amdgcn_sched_barrier(0)
         constexpr int RQ = 4;
-        const int nvu = (nvec + 63) >> 6;                        // vectors per lane that hold genes of this chunk
         auto load_row = [&](V (&x)[NV], unsigned long long dsc) {
             const T *row = e + (int64_t)(dsc >> 19) * ld + g0;
 #pragma unroll
@@ -564,7 +563,6 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
                 m = mn;
             }
         };
-        (void)nvu;
         {
             auto ticket = [&]() { int t = 0; if (lane == 0) t = atomicAdd(s_next, RQ); return t; };     // lane 0 holds the value
             auto uni = [&](unsigned long long v) {
@@ -577,27 +575,27 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
             V xa[NV], xb[NV];
             int tv = ticket();
             int q = __builtin_amdgcn_readfirstlane(tv);
-            unsigned long long d0 = 0, d1 = 0, d2_ = 0, d3 = 0;
-            if (q < U) { d0 = uni(desc[q]); d1 = uni(desc[min(q + 1, U - 1)]); d2_ = uni(desc[min(q + 2, U - 1)]); d3 = uni(desc[min(q + 3, U - 1)]); }
-            if (q < U) load_row(xa, d0);
+            unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0;        // w0..w3: the descriptors of the quad in hand, n0..n3: of the next
+            if (q < U) { w0 = uni(desc[q]); w1 = uni(desc[min(q + 1, U - 1)]); w2 = uni(desc[min(q + 2, U - 1)]); w3 = uni(desc[min(q + 3, U - 1)]); }
+            if (q < U) load_row(xa, w0);
             while (q < U) {
                 tv = ticket();
-                if (q + 1 < U) load_row(xb, d1);
-                eval_row(xa, d0);
+                if (q + 1 < U) load_row(xb, w1);
+                eval_row(xa, w0);
                 if (q + 1 >= U) break;
-                if (q + 2 < U) load_row(xa, d2_);
-                eval_row(xb, d1);
+                if (q + 2 < U) load_row(xa, w2);
+                eval_row(xb, w1);
                 const int qn = __builtin_amdgcn_readfirstlane(tv);
                 unsigned long long n0 = 0, n1 = 0, n2 = 0, n3 = 0;                     // requested here, read after the next row
                 if (qn < U) { n0 = desc[qn]; n1 = desc[min(qn + 1, U - 1)]; n2 = desc[min(qn + 2, U - 1)]; n3 = desc[min(qn + 3, U - 1)]; }
                 if (q + 2 >= U) break;
-                if (q + 3 < U) load_row(xb, d3);
-                eval_row(xa, d2_);
+                if (q + 3 < U) load_row(xb, w3);
+                eval_row(xa, w2);
                 if (q + 3 >= U) break;
                 if (qn < U) { n0 = uni(n0); n1 = uni(n1); n2 = uni(n2); n3 = uni(n3); }
                 if (qn < U) load_row(xa, n0);
-                eval_row(xb, d3);
-                q = qn; d0 = n0; d1 = n1; d2_ = n2; d3 = n3;
+                eval_row(xb, w3);
+                q = qn; w0 = n0; w1 = n1; w2 = n2; w3 = n3;
             }
         }
     }
