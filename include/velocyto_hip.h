@@ -50,7 +50,8 @@ typedef enum {
      * vcy_coldeltacor_partial* entries only (anything else: VCY_ERR_INVALID).  In f32 `|t| + psc` rounds to `|t|` for every
      * |t| >= 2^24 psc (1.7e-3 at the reference's default psc = 1e-10); below that the two rules differ by at most
      * psc / (2 sqrt|t|) per gene.  Three VALU instructions per gene instead of five: the caller opts in when psc is far
-     * below the scale of the matrix (the Python layer: psc <= 1e-9 and mean |e| >= 1e-4).                              */
+     * below the scale of the matrix (the Python layer: psc <= 1e-9, mean |e| >= 1e-4, no non-zero entry below 1e-20:
+     * v_rsq_f32 reads denormal differences, |t| < 2^-126, as zero and the product would be infinite).                  */
     VCY_RULES_PARTIAL_NOPSC = 2
 } vcy_rules;
 

@@ -390,14 +390,19 @@ def _sorted_rows(ix: torch.Tensor, out: torch.Tensor):
 def partial_rules_for(e: CellMatrix, transform: int, psc: float) -> int:
     """The rules value the callers of the *partial kernels pass for the reference's partial rule on this matrix:
     RULES_PARTIAL_NOPSC (A = sign(t) sqrt|t|, three instructions per gene instead of five) for the sqrt transform on an f32
-    matrix when the pseudocount cannot be told from zero at the matrix's scale - psc <= 1e-9 and mean |e| >= 1e-4 (sampled
-    rows; one device->host sync, so callers decide once per matrix, not per launch) - else RULES_PARTIAL, the literal rule.
+    matrix when the pseudocount cannot be told from zero at the matrix's scale - psc <= 1e-9, mean |e| >= 1e-4 and no non-zero
+    entry below 1e-20 (sampled rows; one device->host sync, so callers decide once per matrix, not per launch) - else
+    RULES_PARTIAL, the literal rule.
     In f32 `|t| + psc` equals `|t|` for |t| >= 2^24 psc; below that the forms differ by at most psc / (2 sqrt|t|) per gene,
     which at these scales moves a correlation by less than the f32 rounding of its moment sums (tests/test_gpu_ops.py)."""
     if transform != SQRT or e.dtype != torch.float32 or not (0.0 <= float(psc) <= PSC_NEGLIGIBLE) or e.C == 0:
         return RULES_PARTIAL
-    rows = e.t[:: max(1, e.C // 64), : e.G]
-    return RULES_PARTIAL_NOPSC if float(rows.abs().mean()) >= SCALE_ORDINARY else RULES_PARTIAL
+    rows = e.t[:: max(1, e.C // 64), : e.G].abs()
+    # (v_rsq_f32 reads a denormal as zero: differences below 2^-126 would come out infinite.  Differences of values above 1e-20 are
+    #  multiples of their ulp, > 1e-27 - the sampled smallest non-zero entry guards that, with the mean, in the same sync)
+    tiny = torch.where(rows > 0, rows, torch.full_like(rows, float("inf"))).min()
+    mean, tiny = (float(x) for x in torch.stack([rows.mean(), tiny]).cpu())
+    return RULES_PARTIAL_NOPSC if (mean >= SCALE_ORDINARY and tiny >= 1e-20) else RULES_PARTIAL
 
 
 def coldeltacor_partial(e: CellMatrix, d: CellMatrix, ixs, transform: int, rules: int = RULES_PARTIAL, psc: float = 0.0,
