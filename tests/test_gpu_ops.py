@@ -785,6 +785,9 @@ def test_partial_rules_for_keeps_the_literal_rule_when_the_pseudocount_counts(op
     assert ops.partial_rules_for(E32, ops.SQRT, 1e-10) == ops.RULES_PARTIAL            # tiny scale
     assert ops.partial_rules_for(big, ops.SQRT, 1e-10) == ops.RULES_PARTIAL_NOPSC
     assert ops.partial_rules_for(big, ops.SQRT, 1e-6) == ops.RULES_PARTIAL             # pseudocount not negligible
+    speck = e * 1e8
+    speck[5, 7] = 1e-25                                                                # one denormal-scale entry: v_rsq_f32 territory
+    assert ops.partial_rules_for(ops.CellMatrix.from_genes_major(speck, "float32"), ops.SQRT, 1e-10) == ops.RULES_PARTIAL
     assert ops.partial_rules_for(big, ops.LOG10, 1e-10) == ops.RULES_PARTIAL
     assert ops.partial_rules_for(E64, ops.SQRT, 1e-10) == ops.RULES_PARTIAL
     want = oracle.coldeltacor_partial_compact(e, d, ixs, "sqrt", 1e-10)
