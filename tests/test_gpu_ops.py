@@ -726,6 +726,13 @@ def test_knn_search_pruned_is_exact(ops):
     assert st["distance_evaluations"] < 0.25 * st["brute_force_evaluations"], st
     i, d = ops.knn_search_pruned(X, k, q0=3000, Q=5000, tile=700)
     assert torch.equal(i, ref_i[3000:8000]) and torch.equal(d, ref_d[3000:8000])
+    seg = ops.PRUNED_SEGMENT                             # candidate sets beyond one launch: searched in pieces and merged
+    try:
+        ops.PRUNED_SEGMENT = 1500
+        i, d = ops.knn_search_pruned(X, k, q0=100, Q=9000, tile=2048)
+    finally:
+        ops.PRUNED_SEGMENT = seg
+    assert torch.equal(i, ref_i[100:9100]) and torch.equal(d, ref_d[100:9100])
     Y = rng.normal(size=(6000, 10))                      # no preferred directions: the projection bound is weak, results still exact
     ri, rd = ops.knn_search(Y, 8, include_self=False)
     st2 = {}

@@ -769,6 +769,10 @@ def _knn_search_segmented(x64: torch.Tensor, k: int, include_self: bool, q0: int
     return idx, dist
 
 
+PRUNED_STREAMS = 4          # concurrent tile searches of knn_search_pruned
+PRUNED_SEGMENT = KNN_SEGMENT  # candidates one tile search takes in one launch (the row-free kernel's limit); more are searched in pieces
+
+
 def knn_search_pruned(space, k: int, q0: int = 0, Q: Optional[int] = None, tile: int = 4096, stats: Optional[dict] = None
                       ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Exact kNN (query excluded) with projection pruning for large point sets: the same result as knn_search, from far fewer
@@ -777,10 +781,11 @@ def knn_search_pruned(space, k: int, q0: int = 0, Q: Optional[int] = None, tile:
     ||q - x|| >= ||q[:2] - x[:2]||, so a point whose projection lies farther than R from a query cannot be among its k
     nearest once k points within R are known.  Queries are cut into tiles of `tile` points that are compact in the projection
     (sort by the first coordinate into strips, by the second inside a strip); a tile is searched (vcy_knn_query, brute force,
-    exact fp64 distances) against the points inside its bounding box grown by R, and the search is accepted only if every
-    query's k-th distance is <= R - otherwise that tile is searched again with R = 1.05 x the largest k-th distance it found
-    (which then holds by construction).  R starts from the k-th distances of a pilot sample searched against everything.
-    Candidates keep their global order inside a tile's subset, so ties come out by global index as in knn_search."""
+    exact fp64 distances) against the points of the grid cells that its bounding box grown by R touches, and the search is
+    accepted only if every query's k-th distance is <= R - otherwise that tile is searched again with R = 1.05 x the largest
+    k-th distance it found (which then holds by construction).  R starts from the k-th distances of a pilot sample searched
+    against everything.  Candidates keep their global order inside a tile's subset, so ties come out by global index as in
+    knn_search.  The host synchronises a fixed number of times (pilot, grid, boxes, one verdict per pass), not once per tile."""
     dev = require_gpu()
     x64 = (torch.from_numpy(np.array(space, dtype=np.float64, order="C")) if not isinstance(space, torch.Tensor) else space.double()).to(dev).contiguous()
     C, P = x64.shape
@@ -791,52 +796,110 @@ def knn_search_pruned(space, k: int, q0: int = 0, Q: Optional[int] = None, tile:
     npilot = min(Q, 2048)
     pilot = q0 + (torch.arange(npilot, device=dev) * (Q / npilot)).long()
     _, dp = knn_query(x64, x64[pilot], k + 1)
-    R0 = float(dp[:, k].max()) * 1.1                     # a tile holds thousands of queries: start from the pilot's LARGEST k-th distance
-    # ---- tiles of queries, compact in the projection (sort-tile partition)
+    zmin, zmax = z.min(0).values, z.max(0).values
+    R0, x0, y0, x1, y1 = (float(v) for v in torch.stack([dp[:, k].max() * 1.1, zmin[0], zmin[1], zmax[0], zmax[1]]).cpu())
+    # a tile holds thousands of queries: the radius starts from the pilot's LARGEST k-th distance
+    # ---- uniform grid over the projection, cell ~ R0 / 8 (at most 1024 x 1024 cells); points sorted by cell, ascending global
+    #      number inside a cell (stable sort), so that the candidates of a box are a few contiguous slices - no per-tile compaction
+    #      (coarse cells cost evaluations: a box grown by R covers ~2 R per side, a cell of R would add 50 % of candidates)
+    h = max(R0 / 8.0, (x1 - x0) / 1024.0, (y1 - y0) / 1024.0, 1e-300)
+    ncx, ncy = int((x1 - x0) / h) + 1, int((y1 - y0) / h) + 1
+    cx = ((z[:, 0] - x0) / h).long().clamp_(0, ncx - 1)
+    cy = ((z[:, 1] - y0) / h).long().clamp_(0, ncy - 1)
+    cell = cy * ncx + cx
+    by_cell = torch.argsort(cell, stable=True)
+    start = torch.searchsorted(cell[by_cell], torch.arange(ncx * ncy + 1, device=dev)).cpu().numpy()
+    # ---- tiles of queries, compact in the projection (sort-tile partition); all boxes go to the host in one transfer
     ntile = max(1, (Q + tile - 1) // tile)
     nstrip = max(1, int(round(ntile ** 0.5)))
     qz = z[q0:q0 + Q]
     by_x = torch.argsort(qz[:, 0])
-    idx = torch.empty((Q, k), dtype=torch.int32, device=dev)
-    dist = torch.empty((Q, k), dtype=torch.float64, device=dev)
-    n_eval, n_redo, n_tiles = 0, 0, 0
     per_strip = (Q + nstrip - 1) // nstrip
+    tiles = []
     for s0 in range(0, Q, per_strip):
         strip = by_x[s0:s0 + per_strip]
         strip = strip[torch.argsort(qz[strip, 1])]
         for t0 in range(0, int(strip.numel()), tile):
-            qs = torch.sort(strip[t0:t0 + tile]).values                    # local query numbers of the tile, ascending
-            zq = qz[qs]
-            lo, hi = zq.min(0).values, zq.max(0).values
-            R = R0
-            for attempt in range(3):
-                inside = ((z[:, 0] >= lo[0] - R) & (z[:, 0] <= hi[0] + R) & (z[:, 1] >= lo[1] - R) & (z[:, 1] <= hi[1] + R))
-                cand = torch.nonzero(inside, as_tuple=False).ravel()       # ascending global numbers
-                if int(cand.numel()) <= k + 1:
-                    R *= 2.0
-                    continue
-                li, ld = knn_query(x64[cand], x64[q0 + qs], k + 1)
-                n_eval += int(cand.numel()) * int(qs.numel())
-                gi = cand[li.long()]
-                keep = gi != (q0 + qs)[:, None]
-                pos = torch.cumsum(keep.to(torch.int32), 1)
-                sel = keep & (pos <= k)
-                rows, cols = torch.nonzero(sel, as_tuple=True)
-                ti = torch.empty((int(qs.numel()), k), dtype=torch.int32, device=dev)
-                td = torch.empty((int(qs.numel()), k), dtype=torch.float64, device=dev)
-                ti[rows, (pos[rows, cols] - 1).long()] = gi[rows, cols].to(torch.int32)
-                td[rows, (pos[rows, cols] - 1).long()] = ld[rows, cols]
-                worst = float(td[:, k - 1].max())
-                if worst <= R or int(cand.numel()) == C:
-                    break
-                R = worst * 1.05                                           # every k-th distance found is an upper bound of the true one
-                n_redo += 1
+            tiles.append(torch.sort(strip[t0:t0 + tile]).values)           # local query numbers of the tile, ascending
+    boxes = torch.stack([torch.cat([qz[qs].min(0).values, qz[qs].max(0).values]) for qs in tiles]).cpu().numpy()
+    idx = torch.empty((Q, k), dtype=torch.int32, device=dev)
+    dist = torch.empty((Q, k), dtype=torch.float64, device=dev)
+    cols = torch.arange(k, device=dev)[None, :]
+    n_eval = 0
+
+    def candidates(box, R):
+        """Points of the grid cells the box grown by R touches (a superset of the box), ascending global numbers."""
+        c0 = min(ncx - 1, max(0, int((box[0] - R - x0) / h))); c1 = min(ncx - 1, max(0, int((box[2] + R - x0) / h)))
+        r0 = min(ncy - 1, max(0, int((box[1] - R - y0) / h))); r1 = min(ncy - 1, max(0, int((box[3] + R - y0) / h)))
+        parts = [by_cell[start[r * ncx + c0]:start[r * ncx + c1 + 1]] for r in range(r0, r1 + 1)]
+        n = sum(int(p_.numel()) for p_ in parts)
+        whole = (c0, r0, c1, r1) == (0, 0, ncx - 1, ncy - 1)
+        return (torch.sort(torch.cat(parts)).values if n else by_cell[:0]), n, whole
+
+    def search(t, R):
+        """One brute-force search of tile t against its candidates; returns the device scalar of its largest k-th distance."""
+        nonlocal n_eval
+        qs = tiles[t]
+        cand, n, whole = candidates(boxes[t], R)
+        while n <= k + 1 and not whole:
+            R *= 2.0
+            cand, n, whole = candidates(boxes[t], R)
+        qg = q0 + qs
+        if n <= PRUNED_SEGMENT:
+            li, ld = knn_query(x64[cand], x64[qg], k + 1)
+            gi = cand[li.long()]
+        else:
+            # more candidates than one row-free launch takes: equal pieces in index order, k + 1 nearest of each, stable merge by
+            # distance (every list is sorted by (distance, index) and the pieces ascend in index: ties still come out by index)
+            npiece = (n + PRUNED_SEGMENT - 1) // PRUNED_SEGMENT
+            gis, lds = [], []
+            for j in range(npiece):
+                piece = cand[j * n // npiece:(j + 1) * n // npiece]
+                li, ld = knn_query(x64[piece], x64[qg], k + 1)
+                gis.append(piece[li.long()]); lds.append(ld)
+            ld, order = torch.sort(torch.cat(lds, 1), dim=1, stable=True)
+            gi, ld = torch.gather(torch.cat(gis, 1), 1, order)[:, :k + 1], ld[:, :k + 1]
+        n_eval += n * int(qs.numel())
+        own = gi == qg[:, None]                                            # the query itself: dropped; absent (k + 1 exact duplicates
+        at = torch.where(own.any(1), own.to(torch.int8).argmax(1), torch.full_like(qg, k))    # in front of it): the last column goes
+        take = cols + (cols >= at[:, None]).long()
+        idx[qs] = gi.gather(1, take).to(torch.int32)
+        td = ld.gather(1, take)
+        dist[qs] = td
+        return td[:, k - 1].max(), R, whole
+
+    # first pass at the pilot radius, no host synchronisation per tile; then ONE transfer of the tiles' largest k-th distances, and
+    # the tiles whose bound does not hold are searched again with R = 1.05 x what they found (an upper bound of every true k-th
+    # distance of the tile, so the second search is final by construction)
+    # A tile is 512 workgroups of 8 queries - half of what the device holds at once: tiles go round-robin over a few streams.
+    cur = torch.cuda.current_stream()
+    streams = [torch.cuda.Stream() for _ in range(PRUNED_STREAMS)] if len(tiles) > 1 and PRUNED_STREAMS > 1 else []
+
+    def sweep(jobs):
+        for s_ in streams:
+            s_.wait_stream(cur)
+        out = []
+        for n_, (t, R) in enumerate(jobs):
+            if streams:
+                with torch.cuda.stream(streams[n_ % len(streams)]):
+                    out.append(search(t, R))
             else:
-                raise RuntimeError("knn_search_pruned: radius did not settle")      # cannot happen: the second radius holds by construction
-            idx[qs], dist[qs] = ti, td
-            n_tiles += 1
+                out.append(search(t, R))
+        for s_ in streams:
+            cur.wait_stream(s_)
+        return out
+
+    first = sweep([(t, R0) for t in range(len(tiles))])
+    worst = torch.stack([f[0] for f in first]).cpu().numpy()
+    redo = [t for t, f in enumerate(first) if worst[t] > f[1] and not f[2]]
+    second = sweep([(t, float(worst[t]) * 1.05) for t in redo])
+    if second:
+        w2 = torch.stack([f[0] for f in second]).cpu().numpy()
+        if any(w2[i] > second[i][1] and not second[i][2] for i in range(len(redo))):
+            raise RuntimeError("knn_search_pruned: radius did not settle")      # cannot happen: the second radius holds by construction
     if stats is not None:
-        stats.update(distance_evaluations=n_eval, brute_force_evaluations=Q * C, tiles=n_tiles, tiles_searched_twice=n_redo, start_radius=R0)
+        stats.update(distance_evaluations=n_eval, brute_force_evaluations=Q * C, tiles=len(tiles), tiles_searched_twice=len(redo), start_radius=R0,
+                     grid=[ncx, ncy])
     return idx, dist
 
 
