@@ -236,13 +236,14 @@ class AtlasPath:
         if timed:
             torch.cuda.synchronize()
             tB += ev[0].elapsed_time(ev[1])
-        # ---- pass 2: C + D per block.  e rows = [block | sampled neighbours outside the block]; one block = everything is
-        #      still in the buffers from pass 1 (resident mode) and only the halo rows are pooled
-        for (b0, b1, erows_out, ixs) in self._plan:
+        # ---- pass 2: C + D per block.  e rows = [block | sampled neighbours outside the block].  The blocks are walked
+        #      backwards: the block pass 1 pooled last is still in the buffers and is not pooled again (one block = resident
+        #      mode: nothing is pooled twice, only the halo rows are added)
+        for n_done, (b0, b1, erows_out, ixs) in enumerate(reversed(self._plan)):
             nb, n_out = b1 - b0, int(erows_out.numel())
             ev[0].record()
             e_buf, Ux_b = self._ebuf.rows(0, nb + n_out), self._ubuf.rows(0, nb)
-            if not single:
+            if n_done > 0:
                 self._pool(self.cS, self.fS, slice(b0, b1), e_buf.rows(0, nb))
                 self._pool(self.cU, self.fU, slice(b0, b1), Ux_b)
             self._pool(self.cS, self.fS, erows_out, e_buf.rows(nb, nb + n_out))
