@@ -64,6 +64,28 @@ template <> __device__ __forceinline__ float xform<float, VCY_SQRT, VCY_RULES_PA
     return copysignf(fast_sqrt<float>(fmaf(psc, c, fabsf(t))), t);
 }
 
+// f64 hot variant (partial sqrt; the parity / reference-precision build).  sqrt(double) expands to v_rsq_f64 + two Goldschmidt steps +
+// two residual corrections, wrapped in a range scaling (inputs below 2^-767) and a 0 / inf fix-up: 7 of its ~17 instructions.
+// Here the argument is |t| + psc with |t| >= 1e-16 whenever the result is used, so the bare iteration - the same operations in the
+// same order, hence the same bits - is enough.
+__device__ __forceinline__ double sqrt_normal_f64(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    d = fma(-g, g, x);
+    return fma(d, h, g);
+}
+template <> __device__ __forceinline__ double xform<double, VCY_SQRT, VCY_RULES_PARTIAL>(double t, double psc)
+{
+    const double s = sqrt_normal_f64(fabs(t) + psc);
+    return (fabs(t) < 1e-16) ? 0.0 : copysign(s, t);
+}
+
 // VCY_RULES_PARTIAL_NOPSC (f32, sqrt): A = sign(t) sqrt|t| as t * rsq|t| with the legacy multiply (0 * anything = 0: the zero
 // rule of speedboosted.pyx:372 for free, the sign from t) - three instructions (v_sub, v_rsq_f32, v_mul_legacy_f32) where
 // the literal rule needs five.  The pseudocount is dropped: in f32 `|t| + psc` IS `|t|` for every |t| >= 2^24 psc (1.7e-3 at
