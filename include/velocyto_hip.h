@@ -248,6 +248,14 @@ int64_t vcy_gene_stats_workspace_bytes(int64_t G);
 int vcy_gene_stats(const void *M, const double *cell_scale, const double *lo, const double *hi, const uint8_t *cell_mask,
                    double *stats, void *workspace, int64_t C, int64_t G, int64_t ld, int dtype, vcy_stream stream);
 
+/* Whole-matrix scale facts of a cells-major matrix, one streaming pass: out3 (fp64, device) = [sum |x|, smallest non-zero |x|
+ * (+inf when every entry is zero; a denormal counts as non-zero), number of non-zero entries] over the G logical columns.
+ * What the host layer needs to pick `rules` for the partial sqrt kernels (VCY_RULES_PARTIAL_NOPSC drops the pseudocount of
+ * speedboosted.pyx:372-378, which is only admissible on a matrix of ordinary scale without sub-normal-range entries).
+ * dtype VCY_F32 / VCY_F64.  workspace: vcy_abs_stats_workspace_bytes().                                                      */
+int64_t vcy_abs_stats_workspace_bytes(void);
+int vcy_abs_stats(const void *M, double *out3, void *workspace, int64_t C, int64_t G, int64_t ld, int dtype, vcy_stream stream);
+
 /* Per-gene order statistics over cells with numpy.percentile's linear interpolation
  * (analysis.py:1183-1218 use np.percentile(M, q, axis=1)).  M: (C, ld) cells-major.
  * qs_host: nq percentiles in [0,100] (host array).  out: (nq, G) fp64.

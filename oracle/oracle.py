@@ -436,12 +436,20 @@ def gamma_weights(Sx, Ux, tmpS, tmpU, weights="maxmin_diag", maxmin_perc=(2, 98)
 
 
 def fit_gammas(Sx, Ux, Sx_sz, Ux_sz, fit_offset=True, fixperc_q=False, weighted=True, weights="maxmin_diag",
-               limit_gamma=False, maxmin_perc=(2, 98), maxmin_weighted_pow=15, use_size_norm=True, exact=False):
-    """VelocytoLoom.fit_gammas with use_imputed_data=True (analysis.py:1120-1260).  Returns gammas, q, R2."""
+               limit_gamma=False, maxmin_perc=(2, 98), maxmin_weighted_pow=15, use_size_norm=True, exact=False, steady_state=None):
+    """VelocytoLoom.fit_gammas with use_imputed_data=True (analysis.py:1120-1260).  Returns gammas, q, R2.
+    `steady_state`: boolean mask over cells; the data are subset as at analysis.py:1223-1257 and - what the reference forgets,
+    so that its weighted fits fail on broadcasting for any mask that drops a cell - the weights W (computed over ALL cells,
+    :1179-1219) are restricted to the same cells."""
     tmpS, tmpU = (Sx_sz, Ux_sz) if use_size_norm else (Sx, Ux)
     R2 = None
     if weighted:
         W = gamma_weights(Sx, Ux, tmpS, tmpU, weights, maxmin_perc, maxmin_weighted_pow)
+    if steady_state is not None:
+        ss = np.asarray(steady_state, dtype=bool)
+        tmpS, tmpU = tmpS[:, ss], tmpU[:, ss]
+        if weighted:
+            W = W[:, ss]
     if fit_offset:
         if weighted:
             g, q, R2 = fit_slope_weighted_offset(tmpU, tmpS, W, limit_gamma=limit_gamma, exact=exact)

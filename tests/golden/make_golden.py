@@ -473,6 +473,34 @@ def golden_cfg1(ana):
          knn_row0=np.sort(vlm.knn[0].indices))
 
 
+def golden_steady(ana):
+    """fit_gammas(steady_state_bool=<list mask>) - the part of the reference's steady-state handling that runs
+    (analysis.py:1159-1162, 1223-1257): the UNWEIGHTED fits on tmpS[:, mask], tmpU[:, mask].  (An ndarray mask raises on
+    `if steady_state_bool:`; the weighted fits fail on broadcasting because W is not subset - both checked here.)
+    Inputs: Sx, Ux of pipeline.npz; the mask is regenerated from its seed by the tests."""
+    g = np.load(os.path.join(HERE, "pipeline.npz"))
+    S, U = g["S"], g["U"]
+    vlm = make_vlm(ana, S, U)
+    vlm.Sx = vlm.Sx_sz = np.array(g["Sx"])
+    vlm.Ux = vlm.Ux_sz = np.array(g["Ux"])
+    C = S.shape[1]
+    mask = np.random.default_rng(20180812).random(C) < 0.6
+    out = dict(mask=mask)
+    vlm.fit_gammas(steady_state_bool=list(mask), fit_offset=False, weighted=False)
+    out["gammas_plain"] = vlm.gammas.copy()
+    vlm.fit_gammas(steady_state_bool=list(mask), fit_offset=True, weighted=False)
+    out["gammas_offset"], out["q_offset"] = vlm.gammas.copy(), vlm.q.copy()
+    vlm.fit_gammas(steady_state_bool=list(mask), fit_offset=False, fixperc_q=True, weighted=False)
+    out["gammas_fixq"], out["q_fixq"] = vlm.gammas.copy(), vlm.q.copy()
+    for bad, exc in ((dict(steady_state_bool=mask, weighted=False), ValueError), (dict(steady_state_bool=list(mask)), ValueError)):
+        try:
+            vlm.fit_gammas(**bad)
+            raise SystemExit(f"the reference was expected to fail on {list(bad)}")
+        except exc as e:
+            print("reference raises as documented:", type(e).__name__, str(e)[:90])
+    save("steady", **out)
+
+
 if __name__ == "__main__":
     est, nb, dif, ana = load_reference()
     which = set(sys.argv[1:])
@@ -488,3 +516,5 @@ if __name__ == "__main__":
         golden_preprocess(ana)
     if not which or "cfg1" in which:
         golden_cfg1(ana)
+    if not which or "steady" in which:
+        golden_steady(ana)

@@ -132,6 +132,37 @@ def test_facade_fit_gammas(vcy, golden, oracle, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_facade_fit_gammas_steady_state(vcy, golden, oracle, dtype):
+    """fit_gammas(steady_state_bool=mask) (analysis.py:1159-1162, 1223-1257): unweighted fits against the reference run with a
+    list mask (golden steady.npz); weighted fits - which the reference cannot run with a mask that drops cells, its W is not
+    subset - against the oracle's restatement with W restricted to the same cells."""
+    g, st = golden("pipeline"), golden("steady")
+    gt = TOL[dtype]["gam"]
+    m = st["mask"]
+    vlm = make_vlm(vcy, g, dtype)
+    vlm.Sx, vlm.Ux, vlm.Sx_sz, vlm.Ux_sz = g["Sx"], g["Ux"], g["Sx"], g["Ux"]
+    vlm.fit_gammas(steady_state_bool=list(m), fit_offset=False, weighted=False)
+    assert np.array_equal(vlm.steady_state, m)
+    close(vlm.gammas, st["gammas_plain"], gt, 0)
+    vlm.fit_gammas(steady_state_bool=m, fit_offset=True, weighted=False)            # ndarray masks work too
+    close(vlm.gammas, st["gammas_offset"], 1e-4, 1e-5)
+    close(vlm.q, st["q_offset"], 1e-4, 1e-5)
+    vlm.fit_gammas(steady_state_bool=m, fit_offset=False, fixperc_q=True, weighted=False)
+    close(vlm.gammas, st["gammas_fixq"], 1e-4, 1e-5)
+    close(vlm.q, st["q_fixq"], max(gt, 1e-5), max(gt, 1e-6))
+    for kw in (dict(), dict(weights="maxmin"), dict(weights="sum"), dict(limit_gamma=True), dict(fit_offset=False, fixperc_q=True)):
+        vlm.fit_gammas(steady_state_bool=m, **kw)
+        ge, qe, r2e = oracle.fit_gammas(g["Sx"], g["Ux"], g["Sx"], g["Ux"], exact=True, steady_state=m, **kw)
+        close(vlm.gammas, ge, max(gt, 1e-5), max(gt, 1e-6))
+        close(vlm.q, qe, max(gt, 1e-5), max(gt, 1e-5))
+    # the whole-dataset fit is untouched by a previous masked call
+    vlm.fit_gammas()
+    assert vlm.steady_state.all()
+    ge, qe, _ = oracle.fit_gammas(g["Sx"], g["Ux"], g["Sx"], g["Ux"], exact=True)
+    close(vlm.gammas, ge, max(gt, 1e-5), max(gt, 1e-6))
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_facade_velocity_chain(vcy, golden, dtype):
     g = golden("pipeline")
     rt, at = TOL[dtype]["mat"]
@@ -609,9 +640,11 @@ def test_reference_quirks_reproduce_or_fix_as_documented(vcy, golden):
     a = vcy.estimation.colDeltaCorpartial(e, d, g["neigh_ixs"], threads=3)
     b = vcy.estimation.colDeltaCorpartial(np.ascontiguousarray(e), np.ascontiguousarray(d), g["neigh_ixs"], threads=None)
     assert np.array_equal(a, b, equal_nan=True)
-    # (4) steady_state_bool: ambiguous truth value in the reference -> explicit NotImplementedError here
-    with pytest.raises(NotImplementedError):
-        vlm.fit_gammas(steady_state_bool=np.ones(C, dtype=bool))
+    # (4) steady_state_bool: an ndarray mask raises in the reference (ambiguous truth value); here it is taken like a list
+    #     (test_facade_fit_gammas_steady_state checks the values)
+    vlm.fit_gammas(steady_state_bool=np.ones(C, dtype=bool))
+    with pytest.raises(ValueError):
+        vlm.fit_gammas(steady_state_bool=np.ones(C + 1, dtype=bool))
     # (8) knn_distance_matrix ignores `metric` unless it is "correlation" (neighbors.py:369-376)
     sp = g["pcs"][:, :4]
     m1 = vcy.neighbors.knn_distance_matrix(sp, metric="cosine", k=4, mode="distance")

@@ -699,6 +699,7 @@ def test_knn_search_segmented_equals_one_launch(ops, monkeypatch):
     C, P, k = 3000, 7, 12
     X = rng.normal(size=(C, P))
     X[100] = X[7]; X[2000] = X[7]; X[2999] = X[1500]          # exact duplicates across segments: distance ties at 0
+    X[2996] = X[2992]; X[2991] = X[2992]                        # ... and inside a short last segment
     X[:, 3] = np.round(X[:, 3], 1)                               # and many exact ties at positive distances
     ref_i, ref_d = ops.knn_search(X, k, include_self=False)
     ref_is, ref_ds = ops.knn_search(X, k, include_self=True, q0=500, Q=700)
@@ -804,6 +805,79 @@ def test_partial_rules_for_keeps_the_literal_rule_when_the_pseudocount_counts(op
     fast = ops.coldeltacor_partial(E32, D32, ixs, ops.SQRT, ops.RULES_PARTIAL_NOPSC, 1e-10).cpu().numpy()
     # this is the case the helper guards: at |t| ~ 1e-8 the pseudocount is 1 % of a difference and dropping it shows
     assert np.abs(fast[ok] - want[ok]).max() > 4 * max(np.abs(lit[ok] - want[ok]).max(), 1e-6)
+
+
+def test_partial_rules_decision_is_a_fact_about_the_whole_matrix(ops, monkeypatch):
+    """ops.partial_rules_for reduces EVERY entry (vcy_abs_stats): one sub-1e-20 or denormal entry anywhere - in particular in a
+    row a strided sample of 64 rows would never visit - forces the literal rule (v_rsq_f32 reads a denormal difference as zero:
+    t * rsq|t| = inf would poison the pair's correlation).  Hypothesis places the speck."""
+    from hypothesis import given, settings, strategies as hst
+    G, C = 257, 1000                                  # stride of the old sample: C // 64 = 15 -> rows 0, 15, 30, ...
+    rng = np.random.default_rng(11)
+    base = (rng.gamma(2.0, 1.0, (C, G)) * (rng.random((C, G)) < 0.6)).astype(np.float32)
+    E = ops.CellMatrix.from_cells_major(base, "float32")
+    st = ops.abs_stats(E).cpu().numpy()
+    nz = base != 0
+    np.testing.assert_allclose(st[0], np.abs(base.astype(np.float64)).sum(), rtol=1e-12)
+    assert st[1] == np.abs(base[nz]).min() and st[2] == nz.sum()
+    assert ops.partial_rules_for(E, ops.SQRT, 1e-10) == ops.RULES_PARTIAL_NOPSC
+
+    @settings(max_examples=25, deadline=None)
+    @given(row=hst.integers(0, C - 1).filter(lambda r: r % 15 != 0), col=hst.integers(0, G - 1),
+           val=hst.sampled_from([1e-21, 3e-30, 1e-38, 1.4e-45, -1e-25, -1.4e-45]))       # down to the smallest f32 denormal, either sign
+    def planted(row, col, val):
+        old = float(E.t[row, col])
+        E.t[row, col] = val
+        try:
+            assert float(ops.abs_stats(E)[1]) == abs(np.float32(val))
+            assert ops.partial_rules_for(E, ops.SQRT, 1e-10) == ops.RULES_PARTIAL
+        finally:
+            E.t[row, col] = old
+    planted()
+    # the padding columns never enter (they are zero) and an all-zero matrix reports +inf / 0
+    Z = ops.CellMatrix.from_cells_major(np.zeros((5, 70), np.float32), "float32")
+    z = ops.abs_stats(Z).cpu().numpy()
+    assert z[0] == 0 and np.isinf(z[1]) and z[2] == 0 and ops.partial_rules_for(Z, ops.SQRT, 1e-10) == ops.RULES_PARTIAL
+    # f64 matrices: same facts (the rule itself stays literal there)
+    E64 = ops.CellMatrix.from_cells_major(base.astype(np.float64) * 1e-300, "float64")
+    s64 = ops.abs_stats(E64).cpu().numpy()
+    assert s64[2] == nz.sum() and s64[1] == (np.abs(base[nz].astype(np.float64)) * 1e-300).min()
+    # explicit opt-outs
+    assert ops.partial_rules_for(E, ops.SQRT, 1e-10, literal=True) == ops.RULES_PARTIAL
+    monkeypatch.setenv("VELOCYTO_AMD_LITERAL_RULE", "1")
+    assert ops.partial_rules_for(E, ops.SQRT, 1e-10) == ops.RULES_PARTIAL
+
+
+@pytest.mark.parametrize("scale", [1e-3, 1e-4, 1e-5, 1e-6])
+def test_partial_nopsc_rule_bound_on_scaled_matrices(ops, oracle, scale):
+    """The a-priori bound stated in ops.partial_rules_for: |r_nopsc - r_literal| <= 2 ||delta||_2 / ||A - mean A||_2 with
+    delta_g = sqrt(|t_g| + psc) - sqrt|t_g| (first order), on matrices scaled down towards the pseudocount; and the helper's
+    decision keeps every correlation within the f32 tolerance of the fp64 oracle at every scale."""
+    psc = 1e-10
+    e, d, ixs = _nopsc_problem(77, 1600, 40, 12, scale=scale)
+    E, D = ops.CellMatrix.from_genes_major(e, "float32"), ops.CellMatrix.from_genes_major(d, "float32")
+    e32 = E.to_genes_major(np.float64)                                       # the values the kernels see
+    lit = ops.coldeltacor_partial(E, D, ixs, ops.SQRT, ops.RULES_PARTIAL, psc).cpu().numpy().astype(np.float64)
+    fast = ops.coldeltacor_partial(E, D, ixs, ops.SQRT, ops.RULES_PARTIAL_NOPSC, psc).cpu().numpy().astype(np.float64)
+    want = oracle.coldeltacor_partial_compact(e32, D.to_genes_major(np.float64), ixs, "sqrt", psc)
+    ok = np.isfinite(want)
+    assert np.array_equal(np.isnan(fast), ~ok)
+    worst_ratio = 0.0
+    for c in range(0, e.shape[1], 3):
+        for n in range(ixs.shape[1]):
+            if not ok[c, n]:
+                continue
+            t = np.abs(e32[:, ixs[c, n]] - e32[:, c])
+            A = np.sqrt(t)
+            delta = np.where(t > 0, np.sqrt(t + psc) - A, 0.0)
+            bound = 2.0 * np.linalg.norm(delta) / np.linalg.norm(A - A.mean())
+            diff = abs(fast[c, n] - lit[c, n])
+            assert diff <= 1.5 * bound + 4e-6, (scale, c, n, diff, bound)            # + the f32 rounding of two single-pass sums
+            worst_ratio = max(worst_ratio, diff / max(bound, 1e-30))
+    rules = ops.partial_rules_for(E, ops.SQRT, psc)
+    assert rules == (ops.RULES_PARTIAL_NOPSC if np.abs(e32).mean() >= ops.SCALE_ORDINARY else ops.RULES_PARTIAL)
+    chosen = fast if rules == ops.RULES_PARTIAL_NOPSC else lit
+    np.testing.assert_allclose(chosen[ok], want[ok], atol=CORR_ATOL["float32"])
 
 
 def test_partial_nopsc_is_rejected_where_it_is_not_defined(ops):

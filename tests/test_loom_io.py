@@ -169,3 +169,42 @@ def test_loompy_layout_to_device(loom_io, version):
 def torch_int16():
     import torch
     return torch.int16
+
+
+def test_array_valued_root_attributes(loom_io, tmp_path):
+    """loompy 2 allows array-valued global attributes; H5Aread writes npoints * size bytes, so the reader must size its buffer
+    from the attribute's dataspace (a one-element buffer was heap corruption from file input).  The attributes are written
+    here straight through libhdf5."""
+    import ctypes
+    path = str(tmp_path / "attrs.loom")
+    loom_io.write_loom(path, {"spliced": np.ones((3, 4), np.uint16), "unspliced": np.ones((3, 4), np.uint16)})
+    L = loom_io._lib()
+    hid, hs = loom_io.hid_t, loom_io.hsize_t
+    L.H5Fopen.restype = hid
+    L.H5Acreate2.restype, L.H5Acreate2.argtypes = hid, [hid, ctypes.c_char_p, hid, hid, hid, hid]
+    L.H5Awrite.restype, L.H5Awrite.argtypes = ctypes.c_int, [hid, hid, ctypes.c_void_p]
+    f = L.H5Fopen(path.encode(), 1, 0)                                  # H5F_ACC_RDWR
+    assert f >= 0
+    root = L.H5Gopen2(f, b"/", 0)
+
+    def put(name, arr, tp):
+        dims = (hs * arr.ndim)(*arr.shape)
+        sp = L.H5Screate_simple(arr.ndim, dims, None)
+        a = L.H5Acreate2(root, name, tp, sp, 0, 0)
+        assert a >= 0 and L.H5Awrite(a, tp, arr.ctypes.data) >= 0
+        L.H5Aclose(a); L.H5Sclose(sp)
+
+    vals = np.arange(1000, dtype=np.float64) * 0.5
+    ints = np.arange(12, dtype=np.int32).reshape(3, 4)
+    put(b"big_float_array", vals, L._native["DOUBLE"])
+    put(b"int_matrix", ints, L._native["INT32"])
+    st = L.H5Tcopy(L._c_s1)
+    L.H5Tset_size(st, 6)
+    words = np.array([b"alpha", b"be", b"gamma!"], dtype="S6")
+    put(b"fixed_strings", words, st)
+    L.H5Tclose(st)
+    L.H5Gclose(root); L.H5Fclose(f)
+    fa = loom_io.read_file_attrs(path)
+    np.testing.assert_array_equal(fa["big_float_array"], vals)
+    np.testing.assert_array_equal(fa["int_matrix"], ints)
+    assert list(fa["fixed_strings"]) == ["alpha", "be", "gamma!"]

@@ -212,6 +212,26 @@ def test_pipeline_fit_gammas(oracle, golden):
     assert np.mean(rel > 1e-4) <= 0.05 and rel.max() < 2e-2, (np.mean(rel > 1e-4), rel.max())
 
 
+def test_fit_gammas_steady_state_mask(oracle, golden):
+    """The unweighted fits on tmpS[:, mask], tmpU[:, mask] (analysis.py:1223-1257) against the reference run with a list mask
+    (tests/golden/make_golden.py golden_steady)."""
+    g, st = golden("pipeline"), golden("steady")
+    Sx, Ux, m = g["Sx"], g["Ux"], st["mask"]
+    assert np.array_equal(m, np.random.default_rng(20180812).random(Sx.shape[1]) < 0.6) and 0 < m.sum() < m.size
+    gm, q, _ = oracle.fit_gammas(Sx, Ux, Sx, Ux, fit_offset=False, weighted=False, steady_state=m)
+    nan_equal_close(gm, st["gammas_plain"], atol=0, rtol=2e-7)
+    gm, q, _ = oracle.fit_gammas(Sx, Ux, Sx, Ux, fit_offset=True, weighted=False, steady_state=m)
+    nan_equal_close(gm, st["gammas_offset"], atol=1e-7, rtol=1e-5)
+    nan_equal_close(q, st["q_offset"], atol=1e-6, rtol=1e-5)
+    gm, q, _ = oracle.fit_gammas(Sx, Ux, Sx, Ux, fit_offset=False, fixperc_q=True, weighted=False, steady_state=m)
+    nan_equal_close(gm, st["gammas_fixq"], atol=1e-6, rtol=2e-5)
+    nan_equal_close(q, st["q_fixq"], atol=1e-7, rtol=1e-6)
+    # an all-true mask is the unmasked fit
+    a = oracle.fit_gammas(Sx, Ux, Sx, Ux, steady_state=np.ones(Sx.shape[1], bool))
+    b = oracle.fit_gammas(Sx, Ux, Sx, Ux)
+    assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a, b))
+
+
 def test_pipeline_velocity(oracle, golden):
     g = golden("pipeline")
     Upred, vel, dS, Sxt = oracle.velocity_chain(g["Sx"], g["Ux"], g["gammas"], g["q"])

@@ -57,6 +57,8 @@ SIGNATURES = {
     "vcy_fit_slope_moments": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]),
     "vcy_fit_slope_from_moments": (c_int, [c_vp, c_vp, c_i64, c_vp]),
     "vcy_gene_moments": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]),
+    "vcy_abs_stats_workspace_bytes": (c_i64, []),
+    "vcy_abs_stats": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]),
     "vcy_gene_stats_workspace_bytes": (c_i64, [c_i64]),
     "vcy_gene_stats": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]),
     "vcy_choice_stream_host": (c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp]),

@@ -335,9 +335,24 @@ class VelocytoLoom(PreprocessMixin):
                    limit_gamma: bool = False, maxmin_perc: List[float] = [2, 98], maxmin_weighted_pow: float = 15) -> None:
         """analysis.py:1120-1260."""
         from .estimation import _fixperc_q, _median_and_up_gamma, _weighted_offset_device
-        if steady_state_bool is not None:
-            raise NotImplementedError("steady_state_bool: the reference's own handling is ambiguous (analysis.py:1159, SURVEY appendix 4)")
-        self.steady_state = np.ones(self.dev("S").C, dtype=bool)
+        C_all = self.dev("S").C
+        # analysis.py:1159-1162 stores the mask and :1223-1257 fits on tmpS[:, steady_state], tmpU[:, steady_state].  Two things of
+        # the reference are fixed here rather than reproduced (SURVEY appendix 4): `if steady_state_bool:` raises on an array of
+        # more than one element (a list works), and the weights W - built from percentiles over ALL cells, :1179-1219 - are not
+        # subset, so the weighted fits fail on broadcasting as soon as the mask drops a cell.  Here any boolean mask of length
+        # `cells` is taken, the thresholds / weights are computed over all cells as in the reference and restricted to the same cells.
+        ss_rows = None
+        if steady_state_bool is None or (np.ndim(steady_state_bool) == 0 and not steady_state_bool):
+            self.steady_state = np.ones(C_all, dtype=bool)
+        else:
+            ss = np.asarray(steady_state_bool)
+            if ss.dtype != np.bool_ or ss.shape != (C_all,):
+                raise ValueError(f"steady_state_bool must be a boolean mask over the {C_all} cells")
+            self.steady_state = ss
+            if not ss.all():
+                if not ss.any():
+                    raise ValueError("steady_state_bool selects no cell")
+                ss_rows = torch.from_numpy(np.flatnonzero(ss)).to(self.dev("S").t.device)
         if use_imputed_data:
             tmpS, tmpU = (self.dev("Sx_sz"), self.dev("Ux_sz")) if use_size_norm else (self.dev("Sx"), self.dev("Ux"))
         else:
@@ -367,6 +382,15 @@ class VelocytoLoom(PreprocessMixin):
                     wmode, wargs = 0, dict(W=ops.gamma_weights(Sx, Ux, 3, q[0], q[1], q2[0], q2[1], dS, dU))
             else:
                 raise ValueError(f"weights={weights!r} is not supported")
+        if ss_rows is not None:                                   # cells-major: the subset of cells is a gather of rows
+            take = lambda m: CellMatrix(m.t.index_select(0, ss_rows).contiguous(), m.G)
+            cache = {}
+            def sub(m):
+                if id(m) not in cache:
+                    cache[id(m)] = take(m)
+                return cache[id(m)]
+            tmpS, tmpU = sub(tmpS), sub(tmpU)
+            wargs = {k: (sub(v) if isinstance(v, CellMatrix) else v) for k, v in wargs.items()}
         R2 = None
         if fit_offset:
             if weighted:
@@ -530,7 +554,9 @@ class VelocytoLoom(PreprocessMixin):
             self._neigh = neigh
             sched = ops.hilbert_order(embedding) if embedding.shape[1] >= 2 else None      # scheduling only: same numbers in any order
             self.__dict__["_embed_order"] = sched
-            rules = ops.partial_rules_for(e, kern, psc)     # f32 sqrt with a negligible pseudocount: the three-instruction form
+            # f32 sqrt with a negligible pseudocount on a matrix of ordinary scale: the three-instruction form (decided from
+            # whole-matrix reductions); `vlm.literal_rule = True` (or VELOCYTO_AMD_LITERAL_RULE=1) keeps the literal rule
+            rules = ops.partial_rules_for(e, kern, psc, literal=bool(getattr(self, "literal_rule", False)))
             if calculate_randomized:
                 # the reference's two colDeltaCor*partial calls (:1578-1601) share e and the neighbour lists, hence every
                 # A = f(e_i - e_c): one dual-control pass instead of two launches (vcy_coldeltacor_partial_dual)

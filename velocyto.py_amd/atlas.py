@@ -86,7 +86,7 @@ class AtlasPath:
         self.knn_mode = knn
         self.dtype = ops.resolve_dtype(dtype)
         self.G, self.k, self.psc = cS.G, int(k), float(psc)
-        self.rules = None                  # ops.partial_rules_for(...) of the first pooled block
+        self.rules = None                  # ops.partial_rules_for(...) from the all-reduced whole-matrix facts of the first pass
         self.rank, self.world = D.world()
         self.c0, self.nloc = int(c0), cS.C
         self.c1 = self.c0 + self.nloc
@@ -215,6 +215,7 @@ class AtlasPath:
             tK = ev[0].elapsed_time(ev[1])
         # ---- pass 1: A (pooling of the own cells) + B (fit_slope moments, estimation.py:267-279), block by block
         mom = torch.zeros((3, G), dtype=torch.float64, device=dev)
+        abs_st = None
         for (b0, b1, erows_out, ixs) in self._plan:
             nb = b1 - b0
             ev[0].record()
@@ -224,9 +225,16 @@ class AtlasPath:
             ev[1].record()
             mom += ops.fit_slope_moments(Ux_b, Sx_b)
             ev[2].record()
+            if self.rules is None:                    # first pass only: the scale facts of e = Sx_sz over ALL cells of ALL ranks
+                st = ops.abs_stats(Sx_b)
+                abs_st = st if abs_st is None else torch.stack([abs_st[0] + st[0], torch.minimum(abs_st[1], st[1]), abs_st[2] + st[2]])
             if timed:
                 torch.cuda.synchronize()
                 tA += ev[0].elapsed_time(ev[1]); tB += ev[1].elapsed_time(ev[2])
+        if self.rules is None:
+            # stage D's branch rule is decided ONCE from whole-matrix reductions, all-reduced: identical on every rank and for
+            # every block size (a per-block or per-rank decision could differ on borderline data)
+            self.rules = ops.partial_rules_for(self._ebuf, ops.SQRT, self.psc, stats=D.all_reduce_abs_stats(abs_st), cells=self.C)
         ev[0].record()
         D.all_reduce_sum(mom)
         gamma = ops.fit_slope_from_moments(mom)
@@ -248,8 +256,6 @@ class AtlasPath:
                 self._pool(self.cU, self.fU, slice(b0, b1), Ux_b)
             self._pool(self.cS, self.fS, erows_out, e_buf.rows(nb, nb + n_out))
             ev[1].record()
-            if self.rules is None:                    # decided once, on the first pooled block (one host sync)
-                self.rules = ops.partial_rules_for(e_buf, ops.SQRT, self.psc)
             ops.coldeltacor_partial_fused(e_buf, Ux_b, gamma, None, ixs, ops.SQRT, self.rules, self.psc, cell0=0, u_row0=0,
                                           out=self.corr[b0:b1], validate=False)
             ev[2].record()
@@ -406,7 +412,7 @@ def bench_main(a, dev, rank: int, world: int) -> Optional[dict]:
     plan_1m = memory_plan(1_000_000, G, nnz, 8, 0, nrndm=path.nrndm, k=a.k, count_bytes=cS.data.element_size(),
                           halo_e=path.n_e_halo / nloc, halo_k=path.n_count_halo / nloc)
     return {
-        "metric": "cells/sec through knn_imputation->fit_slope->colDeltaCor, 50k cells x 30k genes",
+        "metric": f"cells/sec through knn_imputation->fit_slope->colDeltaCor, {C} cells x {G} genes (cfg5: CSR layers, streamed blocks)",
         "value": C / (ms * 1e-3), "unit": "cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "rccl_ranks": dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0,

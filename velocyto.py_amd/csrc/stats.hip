@@ -61,6 +61,68 @@ __global__ void k_gene_stats_reduce(const double *__restrict__ part, double *__r
     stats[g] = s; stats[(int64_t)G + g] = ss; stats[2 * (int64_t)G + g] = nz; stats[3 * (int64_t)G + g] = mx;
 }
 
+// Whole-matrix scale facts behind ops.partial_rules_for (the choice between VCY_RULES_PARTIAL and VCY_RULES_PARTIAL_NOPSC):
+// sum |x| and the smallest non-zero |x| over the G logical columns of every row, one streaming pass (HBM-bound, C*G*s bytes).
+// Non-zero is decided on the bit pattern (a denormal counts: v_rsq_f32 would read it as zero), the minimum is taken on the
+// bits of |x| (monotone for non-negative floats).  Block partials -> one folding block, fixed order (deterministic).
+constexpr int ABS_BLOCKS = 2048;
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_abs_stats(const T *__restrict__ M, double *__restrict__ part, int C, int G, int64_t ld)
+{
+    using V = typename Vec<T>::type;
+    constexpr int N = Vec<T>::N;
+    __shared__ double red[3 * 4];
+    const int nvec = (G + N - 1) / N;                       // rows are padded with zeros to ld >= G rounded up to 64 elements
+    const int64_t total = (int64_t)C * nvec;
+    double s = 0.0, mn = INFINITY, nz = 0.0;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t c = t / nvec;
+        const int v = (int)(t - c * nvec);
+        const V x = reinterpret_cast<const V *>(M + c * ld)[v];
+        const T *xp = reinterpret_cast<const T *>(&x);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            if (v * N + k >= G) continue;
+            const double a = fabs((double)xp[k]);
+            bool nonzero;
+            if (sizeof(T) == 4) nonzero = (__float_as_uint((float)xp[k]) & 0x7fffffffu) != 0u;
+            else nonzero = ((unsigned long long)__double_as_longlong((double)xp[k]) & 0x7fffffffffffffffull) != 0ull;
+            s += a;
+            if (nonzero) { mn = fmin(mn, a); nz += 1.0; }
+        }
+    }
+    s = wave_sum(s); nz = wave_sum(nz);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_xor(mn, off, 64));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave] = s; red[4 + wave] = mn; red[8 + wave] = nz; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[3 * blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        part[3 * blockIdx.x + 1] = fmin(fmin(red[4], red[5]), fmin(red[6], red[7]));
+        part[3 * blockIdx.x + 2] = red[8] + red[9] + red[10] + red[11];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_abs_stats_fold(const double *__restrict__ part, double *__restrict__ out, int nblocks)
+{
+    __shared__ double red[3 * 4];
+    double s = 0.0, mn = INFINITY, nz = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) { s += part[3 * b]; mn = fmin(mn, part[3 * b + 1]); nz += part[3 * b + 2]; }
+    s = wave_sum(s); nz = wave_sum(nz);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_xor(mn, off, 64));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave] = s; red[4 + wave] = mn; red[8 + wave] = nz; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = red[0] + red[1] + red[2] + red[3];
+        out[1] = fmin(fmin(red[4], red[5]), fmin(red[6], red[7]));
+        out[2] = red[8] + red[9] + red[10] + red[11];
+    }
+}
+
 }  // namespace vcy
 
 using namespace vcy;
@@ -83,6 +145,27 @@ extern "C" int vcy_gene_stats(const void *M, const double *cell_scale, const dou
     else return fail(VCY_ERR_INVALID, "%s: bad dtype", "gene_stats");
     VCY_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_gene_stats_reduce, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, (const double *)part, stats, (int)G);
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}
+
+extern "C" int64_t vcy_abs_stats_workspace_bytes(void) { return (int64_t)ABS_BLOCKS * 3 * (int64_t)sizeof(double); }
+
+extern "C" int vcy_abs_stats(const void *M, double *out3, void *workspace, int64_t C, int64_t G, int64_t ld, int dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(M && out3 && workspace, "abs_stats: null pointer");
+    VCY_REQUIRE(C > 0 && G > 0 && ld >= G, "abs_stats: bad shape");
+    VCY_REQUIRE(dtype == VCY_F32 || dtype == VCY_F64, "abs_stats: bad dtype");
+    VCY_REQUIRE(ld % (dtype == VCY_F32 ? 4 : 2) == 0 && (uintptr_t)M % 16 == 0, "abs_stats: rows must be 16-byte aligned");
+    VCY_REQUIRE(ld >= (G + (dtype == VCY_F32 ? 3 : 1)) / (dtype == VCY_F32 ? 4 : 2) * (dtype == VCY_F32 ? 4 : 2), "abs_stats: the last vector of a row must lie inside ld");
+    hipStream_t st = as_stream(stream);
+    const int64_t nvec = (G + (dtype == VCY_F32 ? 3 : 1)) / (dtype == VCY_F32 ? 4 : 2);
+    int blocks = (int)((C * nvec + 255) / 256 > ABS_BLOCKS ? ABS_BLOCKS : (C * nvec + 255) / 256);
+    double *part = (double *)workspace;
+    if (dtype == VCY_F32) hipLaunchKernelGGL(k_abs_stats<float>, dim3(blocks), dim3(256), 0, st, (const float *)M, part, (int)C, (int)G, ld);
+    else hipLaunchKernelGGL(k_abs_stats<double>, dim3(blocks), dim3(256), 0, st, (const double *)M, part, (int)C, (int)G, ld);
+    VCY_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_abs_stats_fold, dim3(1), dim3(256), 0, st, (const double *)part, out3, blocks);
     VCY_LAUNCH_CHECK();
     return VCY_OK;
 }

@@ -3,8 +3,8 @@
 The Markov step ``x <- x . tr`` runs on the device (``vcy_diffuse_step_dense`` for dense
 matrices, ``vcy_diffuse_step_csc`` for scipy sparse ones); modes ``path_integral`` and
 ``time_evolution`` are what ``VelocytoLoom.run_markov`` uses (analysis.py:1887), ``map_trajectory`` /
-``frontier`` reuse the same step.  The two alternative transition-matrix builders use the device kNN query;
-only the stochastic ``trajectory`` mode (host RNG walk) is not provided.
+``frontier`` reuse the same step, and the stochastic ``trajectory`` mode walks the chain on the host with numpy's
+RNG like the reference.  The two alternative transition-matrix builders use the device kNN query.
 """
 from __future__ import annotations
 

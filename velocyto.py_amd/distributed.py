@@ -71,6 +71,22 @@ def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
     return t
 
 
+def all_reduce_abs_stats(st: torch.Tensor, group=None) -> torch.Tensor:
+    """ops.abs_stats vectors [sum |e|, smallest non-zero |e|, non-zero count] of the ranks' shards -> the whole matrix's (sum,
+    min, sum), in place: every rank then takes the same ops.partial_rules_for decision, whatever the sharding."""
+    if active():
+        mn = st[1:2].clone()
+        all_reduce_sum(st, group)
+        if _host_staged(mn, group):
+            h = mn.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MIN, group=group)
+            mn.copy_(h)
+        else:
+            dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=group)
+        st[1:2] = mn
+    return st
+
+
 def all_gather_rows(local: torch.Tensor, n_total: int, out: Optional[torch.Tensor] = None, group=None) -> torch.Tensor:
     """Reassemble a row-sharded (shard_bounds) tensor: local (n_loc, ...) -> (n_total, ...).
     Equal shards use one all_gather_into_tensor straight into `out`; ragged shards pad to the

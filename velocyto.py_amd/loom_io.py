@@ -200,20 +200,33 @@ def read_file_attrs(path: str) -> Dict[str, object]:
             L.H5Aget_name(a, ln + 1, nb)
             tp = L.H5Aget_type(a)
             cls, size = L.H5Tget_class(tp), L.H5Tget_size(tp)
-            if cls == H5T_STRING:
+            # the attribute's dataspace decides the buffer: loompy 2 allows array-valued global attributes, and H5Aread writes
+            # npoints * size bytes whatever the caller allocated
+            sp = L.H5Aget_space(a)
+            nd = L.H5Sget_simple_extent_ndims(sp)
+            dims = (hsize_t * max(nd, 1))()
+            if nd > 0:
+                L.H5Sget_simple_extent_dims(sp, dims, None)
+            shape = tuple(int(dims[j]) for j in range(max(nd, 0)))
+            npts = int(np.prod(shape)) if shape else 1
+            key = nb.value.decode()
+            if cls == H5T_STRING and npts > 0:
                 if L.H5Tis_variable_str(tp) > 0:
-                    buf = ctypes.c_char_p()
-                    L.H5Aread(a, tp, ctypes.byref(buf))
-                    out[nb.value.decode()] = (buf.value or b"").decode("utf-8", "replace")
+                    buf = (ctypes.c_char_p * npts)()
+                    L.H5Aread(a, tp, buf)
+                    vals = [(buf[j] or b"").decode("utf-8", "replace") for j in range(npts)]
+                    L.H5Dvlen_reclaim(tp, sp, H5P_DEFAULT, buf)          # the library allocated the strings: hand them back
                 else:
-                    raw = ctypes.create_string_buffer(size + 1)
+                    raw = ctypes.create_string_buffer(size * npts + 1)
                     L.H5Aread(a, tp, raw)
-                    out[nb.value.decode()] = raw.value.decode("utf-8", "replace")
-            elif cls in (H5T_INTEGER, H5T_FLOAT):
+                    vals = [raw.raw[j * size:(j + 1) * size].split(b"\0", 1)[0].decode("utf-8", "replace") for j in range(npts)]
+                out[key] = vals[0] if not shape else np.array(vals, dtype=object).reshape(shape)
+            elif cls in (H5T_INTEGER, H5T_FLOAT) and npts > 0:
                 dt = np.dtype(np.float32 if size == 4 else np.float64) if cls == H5T_FLOAT else np.dtype(("u" if L.H5Tget_sign(tp) == 0 else "i") + str(size))
-                v = np.empty((), dtype=dt)
+                v = np.empty(shape, dtype=dt)
                 L.H5Aread(a, L._native[_NP2H5[dt]], v.ctypes.data)
-                out[nb.value.decode()] = v[()]
+                out[key] = v[()] if not shape else v
+            L.H5Sclose(sp)
             L.H5Tclose(tp)
             L.H5Aclose(a)
         L.H5Gclose(root)

@@ -387,21 +387,49 @@ def _sorted_rows(ix: torch.Tensor, out: torch.Tensor):
     return srt.contiguous(), (perm, out.gather(1, perm)), out
 
 
-def partial_rules_for(e: CellMatrix, transform: int, psc: float) -> int:
+def abs_stats(e: CellMatrix) -> torch.Tensor:
+    """Device tensor [sum |e|, smallest non-zero |e| (inf if none; denormals count), number of non-zero entries] over the WHOLE
+    matrix (vcy_abs_stats: one streaming pass, ~1 ms per 6 GB)."""
+    L = _lib.lib()
+    out = torch.empty(3, dtype=torch.float64, device=e.t.device)
+    ws = torch.empty(int(L.vcy_abs_stats_workspace_bytes()), dtype=torch.uint8, device=e.t.device)
+    _lib.check(L.vcy_abs_stats(e.t.data_ptr(), out.data_ptr(), ws.data_ptr(), e.C, e.G, e.ld, e.code, _stream()), "abs_stats")
+    return out
+
+
+def literal_rule_forced() -> bool:
+    """VELOCYTO_AMD_LITERAL_RULE=1: never pick the no-pseudocount form (the facade's `literal_rule` attribute does the same per object)."""
+    import os
+    return os.environ.get("VELOCYTO_AMD_LITERAL_RULE", "0") == "1"
+
+
+def partial_rules_for(e: CellMatrix, transform: int, psc: float, stats: Optional[torch.Tensor] = None, cells: Optional[int] = None,
+                      literal: bool = False) -> int:
     """The rules value the callers of the *partial kernels pass for the reference's partial rule on this matrix:
     RULES_PARTIAL_NOPSC (A = sign(t) sqrt|t|, three instructions per gene instead of five) for the sqrt transform on an f32
-    matrix when the pseudocount cannot be told from zero at the matrix's scale - psc <= 1e-9, mean |e| >= 1e-4 and no non-zero
-    entry below 1e-20 (sampled rows; one device->host sync, so callers decide once per matrix, not per launch) - else
-    RULES_PARTIAL, the literal rule.
-    In f32 `|t| + psc` equals `|t|` for |t| >= 2^24 psc; below that the forms differ by at most psc / (2 sqrt|t|) per gene,
-    which at these scales moves a correlation by less than the f32 rounding of its moment sums (tests/test_gpu_ops.py)."""
-    if transform != SQRT or e.dtype != torch.float32 or not (0.0 <= float(psc) <= PSC_NEGLIGIBLE) or e.C == 0:
+    matrix when the pseudocount cannot be told from zero at the matrix's scale, else RULES_PARTIAL, the literal rule.
+
+    The decision is a FACT about the whole matrix, not a sample: vcy_abs_stats reduces every entry (one pass, one device->host
+    sync - callers decide once per matrix, not per launch).  NOPSC needs all of
+      * psc <= 1e-9,
+      * mean |e| >= 1e-4 (below that the pseudocount is a visible part of |t| + psc),
+      * no non-zero |e| below 1e-20: v_rsq_f32 reads a denormal as zero, so t * rsq|t| of a difference below 2^-126 would be
+        inf; differences of entries at or above 1e-20 are multiples of their ulp (> 1e-27) and stay in the normal range.
+    `stats`: a precomputed abs_stats vector - sharded callers all-reduce it (sum, min, sum) so that every rank decides alike
+    (distributed.all_reduce_abs_stats); `cells`: the number of cells the sums cover when it is not e.C.  `literal=True` or
+    VELOCYTO_AMD_LITERAL_RULE=1 keeps the literal rule whatever the data.
+
+    A-priori bound.  The two rules differ per gene by delta_g = sqrt(|t_g| + psc) - sqrt|t_g| <= min(sqrt(psc), psc / (2 sqrt|t_g|)),
+    and not at all in f32 once |t_g| >= 2^24 psc (`|t| + psc` rounds to `|t|`; 1.7e-3 at the default 1e-10).  Pearson's r of the
+    pair moves by |dr| <= 2 ||delta||_2 / ||A - mean A||_2 to first order (Cauchy-Schwarz on the centred, normalised vectors),
+    i.e. <= psc * sqrt(mean_g 1/|t_g|) / sd(A) over the genes with 0 < |t_g| < 2^24 psc: a few 1e-7 on count-scale data
+    (measured 1.5e-7 over all 12.5 M pairs of the bench workload), and below the f32 tolerance of 1e-5 down to matrix scales of
+    1e-4 (tests/test_gpu_ops.py::test_partial_nopsc_rule_bound_on_scaled_matrices)."""
+    if transform != SQRT or e.dtype != torch.float32 or not (0.0 <= float(psc) <= PSC_NEGLIGIBLE) or e.C == 0 or literal or literal_rule_forced():
         return RULES_PARTIAL
-    rows = e.t[:: max(1, e.C // 64), : e.G].abs()
-    # (v_rsq_f32 reads a denormal as zero: differences below 2^-126 would come out infinite.  Differences of values above 1e-20 are
-    #  multiples of their ulp, > 1e-27 - the sampled smallest non-zero entry guards that, with the mean, in the same sync)
-    tiny = torch.where(rows > 0, rows, torch.full_like(rows, float("inf"))).min()
-    mean, tiny = (float(x) for x in torch.stack([rows.mean(), tiny]).cpu())
+    st = abs_stats(e) if stats is None else stats
+    total, tiny, _ = (float(x) for x in st.cpu())
+    mean = total / (float(e.C if cells is None else cells) * e.G)
     return RULES_PARTIAL_NOPSC if (mean >= SCALE_ORDINARY and tiny >= 1e-20) else RULES_PARTIAL
 
 
@@ -742,10 +770,12 @@ def _knn_search_segmented(x64: torch.Tensor, k: int, include_self: bool, q0: int
     kk = k if include_self else k + 1
     qs = x64[q0:q0 + Q]
     ds, ix = [], []
-    for s0 in range(0, C, KNN_SEGMENT):
-        s1 = min(C, s0 + KNN_SEGMENT)
-        if s1 - s0 <= kk:                                   # a short last segment: borrow from the previous one
-            s0 = max(0, s1 - kk - 1)
+    # segment bounds: a last segment too short to hold kk candidates is evened out with the one before it (no overlap, so no
+    # candidate is ever listed twice - an overlap would need a dedup that exact distance ties can defeat)
+    bounds = list(range(0, C, KNN_SEGMENT)) + [C]
+    if len(bounds) > 2 and bounds[-1] - bounds[-2] <= kk:
+        bounds[-2] = (bounds[-3] + bounds[-1]) // 2
+    for s0, s1 in zip(bounds[:-1], bounds[1:]):
         i, d = knn_query(x64[s0:s1], qs, kk, query_block)
         ds.append(d)
         ix.append(i + s0)
@@ -754,10 +784,6 @@ def _knn_search_segmented(x64: torch.Tensor, k: int, include_self: bool, q0: int
     keep = torch.ones_like(i_all, dtype=torch.bool)
     if not include_self:
         keep = i_all != torch.arange(q0, q0 + Q, device=i_all.device, dtype=i_all.dtype)[:, None]
-    # a borrowed overlap lists a candidate twice (adjacent after the sort): keep its first copy
-    dup = torch.zeros_like(keep)
-    dup[:, 1:] = (i_all[:, 1:] == i_all[:, :-1]) & (d_all[:, 1:] == d_all[:, :-1])
-    keep &= ~dup
     pos = torch.cumsum(keep.to(torch.int32), 1)
     sel = keep & (pos <= k)
     rows, cols = torch.nonzero(sel, as_tuple=True)

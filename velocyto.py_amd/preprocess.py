@@ -170,14 +170,21 @@ class DevicePCA:
         gen = torch.Generator(device=dev).manual_seed(int(self.random_state))
         Z = torch.linalg.qr(torch.randn((G, l), generator=gen, device=dev, dtype=torch.float64))[0]
         prev = None
+        self.converged_ = False
         for it in range(int(self.max_iter)):
             W = AtA(Z)
             ritz = torch.linalg.eigvalsh(Z.T @ W).flip(0)[:k]
             Z = torch.linalg.qr(W)[0]
             if prev is not None and float(((ritz - prev).abs() / ritz.abs().clamp(min=1e-300)).max()) < self.tol:
+                self.converged_ = True
                 break
             prev = ritz
         self.n_iter_ = it + 1
+        if not self.converged_:
+            import warnings
+            warnings.warn(f"DevicePCA: subspace iteration stopped at max_iter={self.max_iter} before the leading {k} Ritz values settled to "
+                          f"rel tol {self.tol:g} (clustered spectrum?); components_ may be unconverged - raise max_iter or use the exact route "
+                          "(svd_solver='full')", RuntimeWarning, stacklevel=2)
         W = AtA(Z)
         w, V = torch.linalg.eigh(Z.T @ W)
         w, V = w.flip(0).clamp_(min=0.0), V.flip(1)
