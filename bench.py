@@ -22,10 +22,12 @@ the halo rows of Sx their neighbour lists reference and all-gather the compact c
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_cdc_partial_grouped): it is VALU-issue-bound, so
 `achieved` is its VALU wave-instruction rate (instructions per launch from the rocprofv3 SQ_INSTS_VALU pass named in
 `roofline.counters_from`, scaled by the exact pair-chunk count of this run; time from HIP events of this run) against the
-issue peak of the chip; the HBM-side figures ride along (`hbm_frac_measured`, `vs_noreuse_model`).  `stages` holds the
-per-stage rooflines, `extra` the reference-precision (f64), uint16-layer and randomised-control lines of the same workload.
-`cpu_baseline` times the oracle restatement (oracle/libvelocyto_oracle.so + oracle.py) on a bounded closed sub-problem
-on the host cores.
+issue peak of the chip; the HBM-side figures ride along (`hbm_frac_measured`, `vs_noreuse_model`).  `value` is the production
+mode (f32); `f64` is the same pass in the reference's own arithmetic (f64 storage and moments, literal branch rule) with its
+own roofline, and `precision_modes` puts the three modes (f32 production / f32 literal rule / f64) side by side.  `stages`
+holds the per-stage rooflines, `extra` the uint16-layer and randomised-control lines of the same workload.  `cpu_baseline`
+times the oracle restatement (oracle/libvelocyto_oracle.so + oracle.py) on a bounded closed sub-problem on the host cores
+and reports, as `parity`, how far the HIP path is from it on that same sub-problem in all three modes.
 """
 import argparse
 import json
@@ -53,7 +55,13 @@ VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
 #   2 pseudocount dropped (VCY_RULES_PARTIAL_NOPSC, f32): v_sub, v_rsq_f32, v_mul_legacy_f32, v_add, two v_fmac -
 #     "cdc no-psc element" 3.89 clocks x 6 instructions (the parts alone sum to 19.8: a transcendental between plain ops costs more)
 MIX_CLK_PER_ELEMENT = {1: 27.7, 2: 23.3}
-COUNTERS_FILE = os.path.join(ROOT, "profiles", "r02_cdc_counters.json")     # written by tools/summarize_profiles.py from the rocprofv3 passes
+# f64 (the reference's arithmetic): literal element = v_add_f64 (sub), v_add_f64 (|t| + psc), v_cvt_f32_f64, v_rsq_f32, v_mul_f32, 2 x v_cvt_f64_f32,
+# v_mul_f64, 4 x v_fma_f64 (square root), v_cmp_lt_f64 + v_cndmask / v_bfi (zero rule, sign), v_add_f64 + 2 x v_fma_f64 (moments): measured as a
+# mix by tools/ubench/valu_issue_f64.hip (profiles/r03_valu_issue_f64.txt: "f64 element, f32 seed + 1 step + 1 correction", wall-clock column)
+MIX_CLK_PER_ELEMENT_F64 = 83.8
+F64_ISSUE_CLK = 4.1               # clocks per wave64 v_add_f64 / v_mul_f64 / v_fma_f64 per SIMD (same file): the f64 issue peak is 1 instruction / 4 clocks
+COUNTERS_FILE = os.path.join(ROOT, "profiles", "r03_cdc_counters.json")     # written by tools/summarize_profiles.py from the rocprofv3 passes
+COUNTERS_FALLBACK = os.path.join(ROOT, "profiles", "r02_cdc_counters.json")
 
 
 def parse():
@@ -264,9 +272,9 @@ class Pipeline:
         conn = (dist_ > 0).to(self.dtype)                                      # (knn > 0): zero-distance neighbours drop out
         wrow = torch.cat([torch.ones((nloc, 1), device=self.dev, dtype=self.dtype), conn], 1)     # diag = 1
         wrow = wrow / wrow.sum(1, keepdim=True)
-        indices = torch.cat([torch.arange(c0, c1, device=self.dev, dtype=torch.int32)[:, None], idx], 1).contiguous()
+        indices = torch.cat([torch.arange(c0, c1, device=self.dev, dtype=torch.int32)[:, None], idx], 1)
         indptr = torch.arange(0, (nloc + 1) * (k + 1), k + 1, device=self.dev, dtype=torch.int64)
-        wrow = wrow.contiguous()
+        indices, wrow = ops.canonical_graph_rows(indices, wrow)                 # rows by cell number: scipy's order in the reference
         ev[10].record()
         ops.knn_pool_counts(self.cS, self.cU, self.fS, self.fU, indptr, indices, wrow, dtype=self.dtype, cell0=c0, C_out=nloc,
                             out=self.Sx_loc, out2=self.Ux_loc, validate=False, order=self.pool_order, slab_genes=self.a.slab)
@@ -284,8 +292,10 @@ class Pipeline:
             dmat = ops.velocity_chain(self.Sx_loc, self.Ux_loc, gamma, None, want=("dmat",), transform=ops.SQRT, psc=1e-10)["dmat"]
         ev[3].record()
         # ---- D: colDeltaCorSqrtpartial; sharded: every rank needs the rows of e = Sx_sz its neighbour lists reference
-        if self.rules is None:                   # decided once, on the first pooled matrix (one host sync; see ops.partial_rules_for)
-            self.rules = ops.RULES_PARTIAL if a.literal_rule else ops.partial_rules_for(self.Sx_loc, ops.SQRT, 1e-10)
+        if self.rules is None:                   # decided once, on the first pooled matrix, from whole-matrix reductions all-reduced over the
+            #                                      ranks (one host sync; every rank takes the same decision; see ops.partial_rules_for)
+            self.rules = ops.RULES_PARTIAL if a.literal_rule else ops.partial_rules_for(
+                self.Sx_loc, ops.SQRT, 1e-10, stats=self.D.all_reduce_abs_stats(ops.abs_stats(self.Sx_loc)), cells=C)
         rules = self.rules
 
         def stage_d(order):
@@ -374,11 +384,35 @@ class Pipeline:
         return out
 
 
+def hip_subproblem(pipe, args, Cs, ixs, dtype, rules):
+    """The HIP path on the closed sub-problem the CPU baseline runs (first `Cs` cells, all genes): kNN graph among those cells,
+    pooling from the count layers, fit_slope, velocity chain folded into the stage-D launch.  Returns (Sx, gamma, corr)."""
+    ops = pipe.ops
+    dev, G, k = pipe.dev, args.genes, min(args.k, Cs - 1)
+    cS = ops.CountMatrix(pipe.cS.t[:Cs].contiguous(), G)
+    cU = ops.CountMatrix(pipe.cU.t[:Cs].contiguous(), G)
+    fS, fU = pipe.fS[:Cs].contiguous(), pipe.fU[:Cs].contiguous()
+    idx, dist_ = ops.knn_search(pipe.space[:Cs].contiguous(), k, include_self=False)
+    conn = (dist_ > 0).to(dtype)
+    wrow = torch.cat([torch.ones((Cs, 1), device=dev, dtype=dtype), conn], 1)
+    wrow = wrow / wrow.sum(1, keepdim=True)
+    indices = torch.cat([torch.arange(Cs, device=dev, dtype=torch.int32)[:, None], idx], 1)
+    indptr = torch.arange(0, (Cs + 1) * (k + 1), k + 1, device=dev, dtype=torch.int64)
+    indices, wrow = ops.canonical_graph_rows(indices, wrow)
+    Sx, Ux = ops.knn_pool_counts(cS, cU, fS, fU, indptr, indices, wrow, dtype=dtype, validate=False)
+    gamma = ops.fit_slope_from_moments(ops.fit_slope_moments(Ux, Sx))
+    gamma[~torch.isfinite(gamma)] = 0.0
+    corr = ops.coldeltacor_partial_fused(Sx, Ux, gamma, None, torch.from_numpy(ixs.astype(np.int32)).to(dev), ops.SQRT, rules, 1e-10, validate=False)
+    return Sx, gamma, corr
+
+
 def cpu_baseline(pipe, args):
     """The oracle restatement (oracle/velocyto_oracle.c with OpenMP + oracle/oracle.py; pinned against the reference's own
     outputs in tests/test_oracle_golden.py) for all four stages on a closed sub-problem of `cpu_cells` cells (all genes, same
-    k / nrndm).  Nothing built from the reference runs on the GPU box."""
+    k / nrndm).  Nothing built from the reference runs on the GPU box.  The oracle's numbers are not thrown away: the HIP path
+    runs the SAME sub-problem in its three arithmetic modes and `parity` reports how far each is from the fp64 restatement."""
     import oracle
+    ops = pipe.ops
     Cs = min(args.cpu_cells, args.cells)
     G = args.genes
     cores = os.cpu_count() or 1
@@ -396,29 +430,114 @@ def cpu_baseline(pipe, args):
     gam = oracle.fit_slope(Ux, Sx)
     tB = time.perf_counter() - t0
     t0 = time.perf_counter()
-    _, _, dS, _ = oracle.velocity_chain(Sx, Ux, gam, None)
+    gam0 = np.where(np.isfinite(gam), gam, 0.0)                          # fit_gammas' policy (analysis.py:1260), as in the timed path
+    _, _, dS, _ = oracle.velocity_chain(Sx, Ux, gam0, None)
     dmat = oracle.delta_transform(Sx, Sx + dS, "sqrt", 1e-10)
     tC = time.perf_counter() - t0
     t0 = time.perf_counter()
-    oracle.coldeltacor_partial_compact(Sx, dmat, ixs, "sqrt", 1e-10, threads=cores)
+    corr = oracle.coldeltacor_partial_compact(Sx, dmat, ixs, "sqrt", 1e-10, threads=cores)
     tD = time.perf_counter() - t0
     total = tA + tB + tC + tD
+    # ---- parity of the HIP path against these numbers, same inputs, three arithmetic modes
+    parity = {"pairs": int(Cs * nr), "genes": G, "against": "the fp64 oracle restatement on the same closed sub-problem (all four stages)"}
+    ok = np.isfinite(corr)
+    for name, dtype, rules in (("f32_nopsc", torch.float32, None), ("f32_literal", torch.float32, ops.RULES_PARTIAL), ("f64", torch.float64, ops.RULES_PARTIAL)):
+        rl = rules
+        hSx, hg, hc = hip_subproblem(pipe, args, Cs, ixs, dtype, ops.RULES_PARTIAL)          # first call: Sx for the rule decision
+        if rl is None:
+            rl = ops.partial_rules_for(hSx, ops.SQRT, 1e-10)
+            hSx, hg, hc = hip_subproblem(pipe, args, Cs, ixs, dtype, rl)
+        hc = hc.double().cpu().numpy()
+        hg = hg.double().cpu().numpy()
+        sx = hSx.t[:, :G].double().cpu().numpy().T
+        pos = gam0 > 0
+        parity[name] = {"rule": ops.RULE_NAMES.get(rl, str(rl)),
+                        "max_abs_dcorr": float(np.abs(hc[ok] - corr[ok]).max()),
+                        "nan_pattern_equal": bool(np.array_equal(np.isnan(hc), ~ok)),
+                        "max_rel_dgamma": float((np.abs(hg[pos] - gam0[pos]) / gam0[pos]).max()),
+                        "max_rel_dSx": float((np.abs(sx - Sx) / np.maximum(np.abs(Sx), 1e-30))[Sx != 0].max())}
+        del hSx, hg, hc, sx
     return {"value": Cs / total, "unit": "cells/s", "cores": cores, "kind": "port",
             "sample": f"closed sub-problem of {Cs} cells x {G} genes, k={min(args.k, Cs - 1)}, nrndm={nr}, all four stages by the oracle "
                       f"restatement (C + OpenMP on {cores} threads for pooling and stage D, NumPy/SciPy for the rest): A {tA:.2f} s, B {tB:.2f} s, "
                       f"C {tC:.2f} s, D {tD:.2f} s; the per-cell cost of D does not depend on the number of cells, the O(C^2) kNN is cheaper at this "
                       "size (favours the CPU)",
-            "stage_s": {"A": tA, "B": tB, "C": tC, "D": tD}}
+            "stage_s": {"A": tA, "B": tB, "C": tC, "D": tD}, "parity": parity}
 
 
-def load_counters():
-    """Per-launch counters of the dominant kernel from the rocprofv3 --pmc passes committed under profiles/ (file named in
-    the bench line).  Returns {} when the file is missing."""
-    try:
-        with open(COUNTERS_FILE) as f:
-            return json.load(f)
-    except Exception:
-        return {}
+def load_counters(dtype="f32"):
+    """Per-launch counters of the dominant kernel in `dtype` from the rocprofv3 --pmc passes committed under profiles/ (file named
+    in the bench line).  Returns ({}, None) when nothing is there."""
+    for path in (COUNTERS_FILE, COUNTERS_FALLBACK):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+        except Exception:
+            continue
+        if "f32" in rec or "f64" in rec:              # round-3 layout: one record per arithmetic type
+            if rec.get(dtype):
+                return rec[dtype], path
+        elif dtype == "f32":                          # round-2 layout: the f32 kernel only
+            return rec, path
+    return {}, None
+
+
+def dominant_roofline(a, pipe, d_ms, dtype):
+    """VALU-issue roofline of the stage-D launch of `pipe` (k_cdc_partial_grouped in f32 or f64) from this run's HIP-event time and the
+    committed per-pair-chunk instruction count of the same kernel."""
+    C, G, nr = a.cells, a.genes, pipe.nrndm
+    nloc = pipe.c1 - pipe.c0
+    s = 8 if dtype == "f64" else 4
+    pair_genes = float(nloc) * nr * G
+    chunk = (6 if s == 4 else 8) * 64 * (16 // s)               # genes per chunk: f32 8 cells x 6 vectors, f64 6 cells x 8 vectors
+    pair_chunks = float(nloc) * nr * ((G + chunk - 1) // chunk)
+    alg_bytes = nloc * ((nr + 2) * G * s + nr * (4 + s))            # SURVEY.md 8(d): (nrndm+2)*G*s + nrndm*(idx+out) per cell, no reuse credited
+    cnt, cnt_path = load_counters(dtype)
+    if cnt.get("rules") != pipe.rules:                               # the committed counters are of the other branch rule
+        cnt = {}
+    instr = cnt.get("valu_insts_per_pair_chunk", None)
+    default_wl = (C, G, nr, a.k, pipe.world, a.order, a.fuse, a.curve, a.counts) == (50000, 30000, 250, 30, 1, "embedding", True, "hilbert", "auto")
+    traffic = a.traffic_bytes if (a.traffic_bytes is not None and dtype == a.dtype) else (cnt.get("hbm_bytes_per_launch") if default_wl else None)
+    rule_name = pipe.ops.RULE_NAMES.get(pipe.rules, str(pipe.rules))
+    shape = "8 cells, 6 vectors" if s == 4 else "6 cells, 8 vectors"
+    roof = {"bound": "valu", "kernel": f"k_cdc_partial_grouped<{'float' if s == 4 else 'double'}, SQRT, rules {pipe.rules}, {shape}> (velocity chain folded in)",
+            "branch_rule": rule_name, "dtype": dtype,
+            "unit": "Ginstr/s", "peak": VALU_ISSUE_PEAK / 1e9, "avg_launch_ms": d_ms,
+            "peak_is": "VALU issue: 1024 SIMD-32 x 2.4 GHz / 2 clocks per wave64 instruction (MI355X_MICROARCH.md); f32 plain ops measure 2.25 clocks" +
+                       (f", f64 add / mul / fma {F64_ISSUE_CLK} (profiles/r03_valu_issue_f64.txt) - see frac_of_f64_issue_peak" if s == 8 else "")}
+    if instr is not None:
+        achieved = instr * pair_chunks / (d_ms * 1e-3)
+        roof.update({"achieved": achieved / 1e9, "frac": achieved / VALU_ISSUE_PEAK,
+                     "valu_insts_per_launch": instr * pair_chunks, "counters_from": os.path.relpath(cnt_path, ROOT),
+                     "wave_time": cnt.get("wave_time")})
+        if s == 8:
+            roof["frac_of_f64_issue_peak"] = achieved / (VALU_ISSUE_PEAK * 2.0 / F64_ISSUE_CLK)
+        ghz = cnt.get("effective_clock_ghz")
+        if ghz:
+            # the chip clocks to its power budget (MI355X_MICROARCH.md, DVFS): GRBM_GUI_ACTIVE / launch time of the profiled launch
+            roof.update({"effective_clock_ghz": ghz, "frac_at_effective_clock": achieved / (VALU_ISSUE_PEAK * ghz / 2.4)})
+    else:
+        roof.update({"achieved": None, "frac": None, "counters_from": None})
+    mix = MIX_CLK_PER_ELEMENT.get(pipe.rules) if s == 4 else (MIX_CLK_PER_ELEMENT_F64 if pipe.rules == 1 else None)
+    if mix:
+        mix_floor_ms = pair_genes * mix / 64.0 / (1024 * 2.4e9) * 1e3
+        roof.update({"mix_clk_per_element": mix, "mix_floor_ms": mix_floor_ms, "frac_of_mix_floor": mix_floor_ms / d_ms})
+        ghz = cnt.get("effective_clock_ghz")
+        if ghz:
+            roof["frac_of_mix_floor_at_effective_clock"] = mix_floor_ms * 2.4 / ghz / d_ms
+    roof.update({"traffic": traffic, "hbm_frac_measured": (traffic / (d_ms * 1e-3) / HBM_PEAK) if traffic else None,
+                 "algorithmic_bytes_per_launch": alg_bytes, "vs_noreuse_model": alg_bytes / (d_ms * 1e-3) / HBM_PEAK,
+                 "note": "VALU-issue-bound: `achieved` = SQ_INSTS_VALU of this kernel (rocprofv3 pass in counters_from, per pair-chunk, scaled "
+                         "by this run's exact pair-chunk count) / HIP-event launch time; `frac` is against the issue peak of one plain "
+                         "instruction per 2 clocks per SIMD at 2.4 GHz.  Two things keep a correct kernel away from that peak and are reported beside it: "
+                         "(1) the mix the arithmetic needs is slower than plain instructions (v_rsq_f32 8 clocks, f64 add / mul / fma 4, v_rsq_f64 12.5): "
+                         "`mix_floor_ms` is the issue time of that mix alone at the measured rates (tools/ubench/valu_issue*.hip), `frac_of_mix_floor` = "
+                         "mix_floor_ms / launch time; (2) the chip does not hold 2.4 GHz under this load: `effective_clock_ghz` = GRBM_GUI_ACTIVE / "
+                         "duration of the profiled launch, `*_at_effective_clock` are the same fractions at that clock.  HBM is not the limit: "
+                         "`traffic` (2*FETCH_SIZE + WRITE_SIZE of the PMC passes) is `hbm_frac_measured` of 8 TB/s; `vs_noreuse_model` "
+                         "is SURVEY 8(d)'s no-reuse byte model over launch time over 8 TB/s (above 1: neighbour rows are shared by the "
+                         "cells of a group out of LDS and by adjacent groups out of L2)."})
+    return roof
 
 
 def run(a, rank, local_rank, world):
@@ -479,43 +598,8 @@ def run(a, rank, local_rank, world):
         s = 8 if a.dtype == "f64" else 4
         d_ms = float(np.mean(pipe.d_ms))
         stage = pipe.stage_ms / a.steps
-        # ---- dominant kernel.  Work of one launch: pair-genes, and pair-chunks of 1536 (f32) / 1024 (f64) genes
-        pair_genes = float(nloc) * nr * G
-        chunk = (6 if s == 4 else 8) * 64 * (16 // s)               # genes per chunk: f32 8 cells x 6 vectors, f64 6 cells x 8 vectors
-        pair_chunks = float(nloc) * nr * ((G + chunk - 1) // chunk)
-        alg_bytes = nloc * ((nr + 2) * G * s + nr * (4 + s))            # (nrndm+2)*G*s + nrndm*(idx+out) per cell, no reuse credited
-        cnt = load_counters() if a.dtype == "f32" else {}
-        if cnt.get("rules") != pipe.rules:                               # the committed counters are of the other branch rule
-            cnt = {}
-        instr = cnt.get("valu_insts_per_pair_chunk", None)
-        default_wl = (C, G, nr, a.k, world, a.order, a.fuse, a.curve, a.dtype, a.counts) == (50000, 30000, 250, 30, 1, "embedding", True, "hilbert", "f32", "auto")
-        traffic = a.traffic_bytes if a.traffic_bytes is not None else (cnt.get("hbm_bytes_per_launch") if default_wl else None)
+        roof = dominant_roofline(a, pipe, d_ms, a.dtype)
         rule_name = pipe.ops.RULE_NAMES.get(pipe.rules, str(pipe.rules))
-        shape = "8 cells, 6 vectors" if s == 4 else "6 cells, 8 vectors"
-        roof = {"bound": "valu", "kernel": f"k_cdc_partial_grouped<{'float' if s == 4 else 'double'}, SQRT, rules {pipe.rules}, {shape}> (velocity chain folded in)",
-                "branch_rule": rule_name,
-                "unit": "Ginstr/s", "peak": VALU_ISSUE_PEAK / 1e9, "avg_launch_ms": d_ms,
-                "peak_is": "VALU issue: 1024 SIMD-32 x 2.4 GHz / 2 clocks per wave64 instruction (MI355X_MICROARCH.md); f32 plain ops measure 2.25 clocks"}
-        if instr is not None:
-            achieved = instr * pair_chunks / (d_ms * 1e-3)
-            roof.update({"achieved": achieved / 1e9, "frac": achieved / VALU_ISSUE_PEAK,
-                         "valu_insts_per_launch": instr * pair_chunks, "counters_from": os.path.relpath(COUNTERS_FILE, ROOT),
-                         "wave_time": cnt.get("wave_time")})
-        else:
-            roof.update({"achieved": None, "frac": None, "counters_from": None})
-        if s == 4 and pipe.rules in MIX_CLK_PER_ELEMENT:
-            mix_floor_ms = pair_genes * MIX_CLK_PER_ELEMENT[pipe.rules] / 64.0 / (1024 * 2.4e9) * 1e3
-            roof.update({"mix_clk_per_element": MIX_CLK_PER_ELEMENT[pipe.rules], "mix_floor_ms": mix_floor_ms, "frac_of_mix_floor": mix_floor_ms / d_ms})
-        roof.update({"traffic": traffic, "hbm_frac_measured": (traffic / (d_ms * 1e-3) / HBM_PEAK) if traffic else None,
-                     "algorithmic_bytes_per_launch": alg_bytes, "vs_noreuse_model": alg_bytes / (d_ms * 1e-3) / HBM_PEAK,
-                     "note": "VALU-issue-bound: `achieved` = SQ_INSTS_VALU of this kernel (rocprofv3 pass in counters_from, per pair-chunk, scaled "
-                             "by this run's exact pair-chunk count) / HIP-event launch time; `frac` is against the issue peak of one plain "
-                             "instruction per 2 clocks per SIMD.  The mix the arithmetic needs is slower than that (v_rsq_f32 / v_sqrt_f32 8 clocks, "
-                             "v_bfi / SGPR-operand VOP3 4): `mix_floor_ms` is the issue time of that mix alone at the measured rates "
-                             "(tools/ubench/valu_issue.hip), `frac_of_mix_floor` = mix_floor_ms / launch time.  HBM is not the limit: "
-                             "`traffic` (2*FETCH_SIZE + WRITE_SIZE of the PMC passes) is `hbm_frac_measured` of 8 TB/s; `vs_noreuse_model` "
-                             "is SURVEY 8(d)'s no-reuse byte model over launch time over 8 TB/s (above 1: neighbour rows are shared by the "
-                             "8 cells of a group out of LDS and by adjacent groups out of L2)."})
         cbytes = 1 if pipe.cS.t.dtype == torch.uint8 else 2
         pool_bytes = nloc * 2 * (G * cbytes + G * s)
         stages = {
@@ -553,11 +637,28 @@ def run(a, rank, local_rank, world):
         }
         if world == 1 and not a.no_extra and a.dtype == "f32" and a.counts == "auto":
             res["extra"] = extra_lines(a, dev, pipe)
+            # ---- the same pass in its three arithmetic modes, in one place.  `value` is the production mode (f32 storage, the
+            #      no-pseudocount form of the partial-sqrt rule where ops.partial_rules_for admits it); the reference itself is fp64
+            #      with the literal rule (speedboosted.pyx:352-443): that run is the top-level `f64` object, with its own roofline.
+            modes = {"f32_production": {"cells_per_s": res["value"], "ms_per_step": ms_per_step, "D_ms": d_ms, "stage_D_rule": rule_name,
+                                        "is": "`value`: the K timed steps of this run"}}
             lit = res["extra"].get("randomised_control", {}).get("literal_rule")
             if lit:                                  # the whole pass with the literal rule in stage D: this run's other stages + the literal launch
                 ms_lit = ms_per_step - d_ms + lit["D_single_ms"]
                 lit["whole_pass_ms"] = ms_lit
                 lit["whole_pass_cells_per_s"] = C / (ms_lit * 1e-3)
+                modes["f32_literal_rule"] = {"cells_per_s": C / (ms_lit * 1e-3), "ms_per_step": ms_lit, "D_ms": lit["D_single_ms"],
+                                             "stage_D_rule": pipe.ops.RULE_NAMES[pipe.ops.RULES_PARTIAL],
+                                             "max_abs_dcorr_vs_production_all_pairs": lit["max_abs_dcorr_all_pairs"],
+                                             "is": "this run's stages A-C + one stage-D launch with VCY_RULES_PARTIAL"}
+            f64 = res["extra"].pop("f64", None)
+            if f64:
+                res["f64"] = f64
+                modes["f64_reference_arithmetic"] = {"cells_per_s": f64["value"], "ms_per_step": f64["ms_per_step"], "D_ms": f64["stage_ms"]["D_coldeltacor"],
+                                                     "stage_D_rule": pipe.ops.RULE_NAMES[pipe.ops.RULES_PARTIAL],
+                                                     "max_abs_dcorr_vs_production_all_pairs": f64["f32_vs_f64"]["max_abs_dcorr_all_pairs"],
+                                                     "is": "top-level `f64`: f64 storage and moments, literal rule, timed steps of a second pipeline on the same inputs"}
+            res["precision_modes"] = modes
         if not a.no_cpu_baseline and world == 1:     # reported on rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(pipe, a)
     finish(res, rank)
@@ -591,17 +692,21 @@ def extra_lines(a, dev, pipe):
     pipe.Sx_loc = pipe.e_rows = pipe.Ux_loc = None     # make room: the f64 pipeline holds 2 x 12 GB at 50k x 30k
     torch.cuda.empty_cache()
     p64 = Pipeline(a, dev, 0, 1, dtype=torch.float64, data=data)
-    ms = short(p64, 1)
-    st = p64.stage_ms
+    n64 = 2
+    ms = short(p64, n64)
+    st = p64.stage_ms / n64
     ok = torch.isfinite(p64.corr_loc) & torch.isfinite(corr32)
     dcorr = float((p64.corr_loc[ok] - corr32[ok].double()).abs().max())
     g64, g32 = p64.last_gamma.double(), gamma32.double()
     dgam = float(((g64 - g32).abs() / g64.abs().clamp(min=1e-30))[g64 > 0].max())
-    out["f64"] = {"dtype": "f64", "ms_per_step": ms, "cells_per_s": a.cells / (ms * 1e-3),
-                  "stage_ms": {"A_knn_imputation": st[0], "B_fit_slope": st[1], "D_coldeltacor": st[4]},
+    out["f64"] = {"dtype": "f64", "value": a.cells / (ms * 1e-3), "unit": "cells/s", "ms_per_step": ms, "steps": n64, "warmup": 1,
+                  "stage_ms": {"A_knn_imputation": st[0], "B_fit_slope": st[1], "C_velocity_chain": st[2], "D_coldeltacor": st[4]},
+                  "stage_D_rule": p64.ops.RULE_NAMES.get(p64.rules, str(p64.rules)),
+                  "roofline": dominant_roofline(a, p64, float(np.mean(p64.d_ms)), "f64"),
                   "f32_vs_f64": {"max_abs_dcorr_all_pairs": dcorr, "pairs_compared": int(ok.sum()), "nan_pattern_equal": bool(torch.equal(torch.isnan(p64.corr_loc), torch.isnan(corr32))),
                                  "max_rel_dgamma": dgam},
-                  "note": "the reference's arithmetic (speedboosted.pyx:13-538 is fp64 throughout): f64 storage of Sx/Ux, f64 moments, same kernels"}
+                  "note": "the reference's arithmetic (speedboosted.pyx:13-538 is fp64 throughout): f64 storage of Sx/Ux, f64 moments, literal branch rule, "
+                          "same kernels and the same inputs as the timed f32 run"}
     return out
 
 

@@ -105,8 +105,9 @@ def _dense_reference(ops, atlas, cS, cU, fS, fU, pcs, emb, k, n_neighbors, frac)
     idx, dist = ops.knn_search(pcs, k, include_self=False)
     conn = (dist > 0).float()
     w = torch.cat([torch.ones((C, 1), device=idx.device), conn], 1)
-    w = (w / w.sum(1, keepdim=True)).contiguous()
-    ind = torch.cat([torch.arange(C, device=idx.device, dtype=torch.int32)[:, None], idx], 1).contiguous()
+    w = w / w.sum(1, keepdim=True)
+    ind = torch.cat([torch.arange(C, device=idx.device, dtype=torch.int32)[:, None], idx], 1)
+    ind, w = ops.canonical_graph_rows(ind, w)                # rows by cell number: the order every device-built graph pools in
     ptr = torch.arange(0, (C + 1) * (k + 1), k + 1, device=idx.device, dtype=torch.int64)
     Sx, Ux = ops.knn_pool_counts(cS.to_dense(), cU.to_dense(), fS, fU, ptr, ind, w, dtype=torch.float32, validate=False)
     gamma = ops.fit_slope_from_moments(ops.fit_slope_moments(Ux, Sx))

@@ -243,6 +243,56 @@ def test_knn_pool_golden(ops, golden, dtype):
     np.testing.assert_array_equal(part, mx[:, 50:120])
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_pooling_in_canonical_row_order_keeps_equal_neighbourhoods_equal(ops, oracle, dtype):
+    """Two cells with the SAME closed neighbourhood (mutual neighbours in a tight cluster) pool the same cells.  The reference
+    pools through scipy with column-sorted rows (analysis.py:1006-1013), so their pooled vectors are bitwise equal, every
+    difference is exactly zero, the zero rule of speedboosted.pyx:372 applies and the pair's correlation is NaN (mapped to 1 at
+    analysis.py:1605).  ops.canonical_graph_rows puts device-built graph rows in that order: same NaN pattern and the same
+    values as the oracle for the whole path; nearest-first rows leave +-1e-16 relative noise that the partial-sqrt transform
+    lifts to +-sqrt(psc) per gene - a finite correlation where the reference has none."""
+    rng = np.random.default_rng(42)
+    C, G, k, P = 120, 1500, 5, 4
+    space = rng.normal(size=(C, P)) * 10.0
+    space[:6] = 100.0 + rng.normal(size=(6, P)) * 1e-3             # a cluster of k + 1 cells far from the rest: one closed neighbourhood
+    S = rng.poisson(rng.gamma(0.5, 2.0, (G, 1)) * np.ones((1, C))).astype(np.float64)
+    U = rng.poisson(0.3 * rng.gamma(0.5, 2.0, (G, 1)) * np.ones((1, C))).astype(np.float64)
+    fS = S.sum(0).mean() / S.sum(0)
+    S_sz, U_sz = S * fS[None, :], U * fS[None, :]
+    _, w, Sx_o, Ux_o = oracle.knn_imputation(S_sz, U_sz, space, k=k)
+    assert np.array_equal(Sx_o[:, 0], Sx_o[:, 3])                   # the reference's order: bitwise equal pooled vectors
+    gam = oracle.fit_slope(Ux_o, Sx_o)
+    gam = np.where(np.isfinite(gam), gam, 0.0)
+    _, _, dS, _ = oracle.velocity_chain(Sx_o, Ux_o, gam, None)
+    d_o = oracle.delta_transform(Sx_o, Sx_o + dS, "sqrt", 1e-10)
+    ixs = np.stack([rng.choice(C, 16, replace=False) for _ in range(C)])
+    ixs[0, :5] = [1, 2, 3, 4, 5]
+    want = oracle.coldeltacor_partial_compact(Sx_o, d_o, ixs, "sqrt", 1e-10)
+    assert np.isnan(want[0, :5]).all()
+    # the device path with device-built rows [self | nearest first] -> canonical order
+    dev = ops.require_gpu()
+    tdt = torch.float64 if dtype == "float64" else torch.float32
+    idx, dist = ops.knn_search(space, k)
+    wrow = torch.cat([torch.ones((C, 1), device=dev, dtype=tdt), (dist > 0).to(tdt)], 1)
+    wrow = wrow / wrow.sum(1, keepdim=True)
+    rows = torch.cat([torch.arange(C, device=dev, dtype=torch.int32)[:, None], idx], 1)
+    indptr = torch.arange(0, (C + 1) * (k + 1), k + 1, device=dev, dtype=torch.int64)
+    cS, cU = ops.CountMatrix.from_genes_major(S.astype(np.uint16)), ops.CountMatrix.from_genes_major(U.astype(np.uint16))
+
+    def path(ind, ww):
+        Sx, Ux = ops.knn_pool_counts(cS, cU, fS, fS, indptr, ind.contiguous(), ww.contiguous(), dtype=dtype)
+        g = ops.fit_slope(Ux, Sx)
+        g[~torch.isfinite(g)] = 0.0
+        return Sx, ops.coldeltacor_partial_fused(Sx, Ux, g, None, ixs, ops.SQRT, ops.RULES_PARTIAL, 1e-10).cpu().numpy()
+    Sx, got = path(*ops.canonical_graph_rows(rows, wrow))
+    assert torch.equal(Sx.t[0], Sx.t[3])
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = np.isfinite(want)
+    np.testing.assert_allclose(got[ok], want[ok], atol=CORR_ATOL[dtype])
+    _, raw = path(rows, wrow)                                       # nearest-first rows: the same pairs come out finite
+    assert np.isfinite(raw[0, :5]).any()
+
+
 @pytest.mark.parametrize("narrow", [True, False])
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_knn_pool_counts(ops, oracle, golden, dtype, narrow):

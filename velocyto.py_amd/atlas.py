@@ -104,7 +104,8 @@ class AtlasPath:
         conn = (dist_ > 0).to(self.dtype)
         wrow = torch.cat([torch.ones((self.nloc, 1), device=dev, dtype=self.dtype), conn], 1)
         wrow = (wrow / wrow.sum(1, keepdim=True)).contiguous()
-        grow = torch.cat([torch.arange(self.c0, self.c1, device=dev, dtype=torch.int32)[:, None], idx], 1).contiguous()   # global cell numbers
+        grow = torch.cat([torch.arange(self.c0, self.c1, device=dev, dtype=torch.int32)[:, None], idx], 1)               # global cell numbers
+        grow, wrow = ops.canonical_graph_rows(grow, wrow)       # pooled in ascending GLOBAL cell number: scipy's order, and independent of the sharding
         # ---- sampled embedding neighbours of the own cells (global numbers)
         self.neigh = sample_neighbors(emb_full, self.c0, self.c1, n_neighbors, sampled_fraction, sampling_probs, seed)
         self.nrndm = int(self.neigh.shape[1])

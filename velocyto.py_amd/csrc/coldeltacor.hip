@@ -18,6 +18,9 @@
 // VALU/transcendental-bound instead.
 #include <stdlib.h>
 #include "common.h"
+#ifndef VCY_EXP
+#define VCY_EXP 0
+#endif
 #include <type_traits>
 
 namespace vcy {
@@ -64,20 +67,23 @@ template <> __device__ __forceinline__ float xform<float, VCY_SQRT, VCY_RULES_PA
     return copysignf(fast_sqrt<float>(fmaf(psc, c, fabsf(t))), t);
 }
 
-// f64 hot variant (partial sqrt; the parity / reference-precision build).  sqrt(double) expands to v_rsq_f64 + two Goldschmidt steps +
-// two residual corrections, wrapped in a range scaling (inputs below 2^-767) and a 0 / inf fix-up: 7 of its ~17 instructions.
-// Here the argument is |t| + psc with |t| >= 1e-16 whenever the result is used, so the bare iteration - the same operations in the
-// same order, hence the same bits (checked: a 400-cell x 5000-gene launch is bitwise equal to the library-sqrt build) - is enough.
+// f64 hot variant (partial sqrt; the reference-precision build).  sqrt(double) expands to v_rsq_f64 (12.5 clocks per wave64, measured:
+// profiles/r03_valu_issue_f64.txt) + a coupled Goldschmidt step + two residual corrections, wrapped in a range scaling (inputs below
+// 2^-767) and a 0 / inf fix-up: ~17 f64 instructions, 130 clocks per element with the moments.  The argument here is |t| + psc with
+// |t| >= 1e-16 whenever the result is used, far inside the f32 exponent range, so the seed can come from the f32 unit instead:
+// v_cvt_f32_f64, v_rsq_f32 (8 clocks, 2^-23), 0.5 y in f32, two v_cvt_f64_f32, then one coupled Goldschmidt step (2^-45) and ONE
+// residual correction in f64: 84 clocks per element (the bare v_rsq_f64 iteration with both corrections: 94.5).  Faithfully rounded:
+// largest relative error against sqrt() over 2^26 arguments in [2^-60, 2^60] 2.2e-16 = 2 ulp (same file), against 1e-10 of tolerance
+// on a correlation.  Domain: |t| + psc in [1e-38, 3e38] (a count-derived matrix never leaves it; below 1e-16 the zero rule discards
+// the value).
 __device__ __forceinline__ double sqrt_normal_f64(double x)
 {
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = 0.5 * y;
+    const float yf = __builtin_amdgcn_rsqf((float)x);
+    const double y = (double)yf, h = (double)(0.5f * yf);
+    double g = x * y;
     const double r = fma(-h, g, 0.5);
     g = fma(g, r, g);
-    h = fma(h, r, h);
-    double d = fma(-g, g, x);
-    g = fma(d, h, g);
-    d = fma(-g, g, x);
+    const double d = fma(-g, g, x);
     return fma(d, h, g);
 }
 template <> __device__ __forceinline__ double xform<double, VCY_SQRT, VCY_RULES_PARTIAL>(double t, double psc)
@@ -260,9 +266,11 @@ __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, c
                     const T *bp = reinterpret_cast<const T *>(&dcv);
 #pragma unroll
                     for (int k = 0; k < N; ++k) {
-                        T a = xform_s<T, TR, RULES>(xp[k] - ep[k], psc, K);
+                        const T tt = xp[k] - ep[k];
+                        T a = xform_s<T, TR, RULES>(tt, psc, K);
                         sA[k] += a;
-                        sAA[k] = fma(a, a, sAA[k]);
+                        if (RULES == VCY_RULES_PARTIAL_NOPSC) sAA[k] += fabs(tt);      // A^2 = |t| exactly (as in the grouped kernel)
+                        else sAA[k] = fma(a, a, sAA[k]);
                         sAb[k] = fma(a, bp[k], sAb[k]);
                     }
                 }
@@ -276,18 +284,22 @@ __global__ __launch_bounds__(1024) void k_cdc_partial(const T *__restrict__ e, c
                 const T *bp = reinterpret_cast<const T *>(&dcv);
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
-                    T a = xform_s<T, TR, RULES>(xp[k] - ep[k], psc, K);
+                    const T tt = xp[k] - ep[k];
+                    T a = xform_s<T, TR, RULES>(tt, psc, K);
                     sA[k] += a;
-                    sAA[k] = fma(a, a, sAA[k]);
+                    if (RULES == VCY_RULES_PARTIAL_NOPSC) sAA[k] += fabs(tt);
+                    else sAA[k] = fma(a, a, sAA[k]);
                     sAb[k] = fma(a, bp[k], sAb[k]);
                 }
             }
             {
                 const int g = nvec * N + lane;
                 if (g < gl) {
-                    T a = xform_s<T, TR, RULES>(row[g] - ec[g], psc, K);
+                    const T tt = row[g] - ec[g];
+                    T a = xform_s<T, TR, RULES>(tt, psc, K);
                     sA[0] += a;
-                    sAA[0] = fma(a, a, sAA[0]);
+                    if (RULES == VCY_RULES_PARTIAL_NOPSC) sAA[0] += fabs(tt);
+                    else sAA[0] = fma(a, a, sAA[0]);
                     sAb[0] = fma(a, dc[g], sAb[0]);
                 }
             }
@@ -549,18 +561,29 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
                 const int mn = mask ? __builtin_ctz(mask) : m;
                 T sA[2], sAA[2], sAb[2], sAb2[2];          // two partial sums per moment and lane: elements (0, 1) and (2, 3) of a vector fold into the SAME
                                                             // accumulator pair (6 registers for three moments; four partials each cost 12)
-#pragma unroll
-                for (int k = 0; k < 2; ++k) { sA[k] = T(0); sAA[k] = T(0); sAb[k] = T(0); sAb2[k] = T(0); }
-                auto fold = [&](const V &xv, const V &ev, const V &bv, const V &b2v) {
+                // (no zeroing: the first two elements of a pair initialise the partial sums - six v_mov and four adds to zero less per
+                //  pair-chunk; sum A^2 of the no-pseudocount rule is sum |t| - A^2 = |t| exactly for A = sign(t) sqrt|t|, one v_add with
+                //  the |.| modifier that does not wait for the v_rsq_f32 - together 77.1 -> 74.6 ms at 50k x 30k)
+                auto fold = [&](const V &xv, const V &ev, const V &bv, const V &b2v, bool first) {
                     const T *xp = reinterpret_cast<const T *>(&xv);
                     const T *ep = reinterpret_cast<const T *>(&ev);
                     const T *bp = reinterpret_cast<const T *>(&bv);
                     const T *bp2 = reinterpret_cast<const T *>(&b2v);
+                    constexpr bool ABS2 = RULES == VCY_RULES_PARTIAL_NOPSC;     // sum A^2 taken as sum |t|
 #pragma unroll
                     for (int k = 0; k < N; ++k) {
-                        T a = xform_s<T, TR, RULES>(xp[k] - ep[k], psc, K);
+                        const T tt = xp[k] - ep[k];
+                        const T a = xform_s<T, TR, RULES>(tt, psc, K);
+                        if (first && k < 2) {
+                            sA[k] = a;
+                            sAA[k] = ABS2 ? fabs(tt) : a * a;
+                            sAb[k] = a * bp[k];
+                            if (DUAL) sAb2[k] = a * bp2[k];
+                            continue;
+                        }
                         sA[k & 1] += a;
-                        sAA[k & 1] = fma(a, a, sAA[k & 1]);
+                        if (ABS2) sAA[k & 1] += fabs(tt);
+                        else sAA[k & 1] = fma(a, a, sAA[k & 1]);
                         sAb[k & 1] = fma(a, bp[k], sAb[k & 1]);
                         if (DUAL) sAb2[k & 1] = fma(a, bp2[k], sAb2[k & 1]);
                     }
@@ -572,13 +595,13 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
                     if (un < NV) rd(eR[un % RD], bR[un % RD], b2R[un % RD], m, un);
                     else rd(eR[un % RD], bR[un % RD], b2R[un % RD], mn, un - NV);
                     VCY_FENCE();
-                    fold(x[u], eR[u % RD], bR[u % RD], b2R[u % RD]);
+                    fold(x[u], eR[u % RD], bR[u % RD], b2R[u % RD], u == 0);
                     VCY_FENCE();
                 }
                 // the three (dual: four) wave totals in one transposing reduction: row r of `tot` holds moment r; lane 16 r
                 // adds it to acc[AS p + r] (the single-control kernel feeds a fourth value nobody reads, so that both
                 // variants sum in the same order)
-                const T tot = wave_sum_rows(sA[0] + sA[1], sAA[0] + sAA[1], sAb[0] + sAb[1], sAb2[0] + sAb2[1]);
+                const T tot = wave_sum_rows(sA[0] + sA[1], sAA[0] + sAA[1], sAb[0] + sAb[1], DUAL ? sAb2[0] + sAb2[1] : T(0));
                 // ds_add_f32 without return: the wave that owns the pair is the only writer of acc[p][.], so the order of the
                 // additions is its program order (deterministic) and nothing waits for the old value
                 if ((lane & 15) == 0 && (lane >> 4) < AS)

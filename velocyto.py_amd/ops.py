@@ -634,6 +634,19 @@ def scatter_rows(vals: torch.Tensor, ixs, ncols: int, rm: Optional[torch.Tensor]
 
 
 # --------------------------------------------------------------------------- stage A
+def canonical_graph_rows(indices: torch.Tensor, weights: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Fixed-width graph rows (C, k + 1) with every row sorted by cell number (weights permuted alike).  The pooling kernels add
+    a row's terms in list order, so the pooled vector depends on that order in its last bits.  The reference pools through
+    scipy with column-sorted rows (`(knn > 0)` / `setdiag`, analysis.py:1006-1008, sort the CSR in place): two cells with the
+    SAME closed neighbourhood - mutual neighbours inside a tight cluster - get bitwise equal vectors there, their difference is
+    exactly zero on every gene and the zero rule of speedboosted.pyx:372 turns the pair into the NaN the facade then maps to 1
+    (analysis.py:1605-1606).  Lists kept nearest-first instead give such a pair rounding noise of 1e-16 relative, which the
+    partial-sqrt transform lifts to +-sqrt(psc) on every gene: a finite, meaningless correlation.  Device-built graphs (bench.py,
+    atlas.py) therefore pool in this canonical order; the facade hands scipy's own (sorted) CSR through."""
+    srt, perm = torch.sort(indices, dim=1)
+    return srt.contiguous(), weights.gather(1, perm).contiguous()
+
+
 def knn_pool(data: CellMatrix, indptr, indices, weights, maximum: bool = False, cell0: int = 0,
              C_out: Optional[int] = None, slab_genes: int = 0, out: Optional[CellMatrix] = None,
              validate: bool = True, order: Optional[torch.Tensor] = None) -> CellMatrix:
