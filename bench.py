@@ -242,7 +242,10 @@ class Pipeline:
                 # interior cells (all sampled neighbours rank-local) need no remote row: their stage D runs while the halo moves
                 base = self.order.long() if self.order is not None else torch.arange(nloc, device=dev)
                 inter = ((self.neigh_loc >= self.c0) & (self.neigh_loc < self.c1)).all(1)
-                self.sched = (base[inter[base]].to(torch.int32).contiguous(), base[~inter[base]].to(torch.int32).contiguous())
+                # the first launch takes whole rounds of the device only (distributed.overlap_schedules): two launches, ONE tail
+                per_round = torch.cuda.get_device_properties(dev).multi_processor_count * (8 if dtype == torch.float32 else 6)
+                self.sched = distributed.overlap_schedules(base, inter, per_round)
+                self.n_interior = int(inter.sum())
             self.e_cell0 = 0
         elif self.collect:
             # all-gather exchange: the full-height buffer, own rows written in place by the pooling
@@ -532,7 +535,7 @@ def dominant_roofline(a, pipe, d_ms, dtype):
                          "instruction per 2 clocks per SIMD at 2.4 GHz.  Two things keep a correct kernel away from that peak and are reported beside it: "
                          "(1) the mix the arithmetic needs is slower than plain instructions (v_rsq_f32 8 clocks, f64 add / mul / fma 4, v_rsq_f64 12.5): "
                          "`mix_floor_ms` is the issue time of that mix alone at the measured rates (tools/ubench/valu_issue*.hip), `frac_of_mix_floor` = "
-                         "mix_floor_ms / launch time; (2) the chip does not hold 2.4 GHz under this load: `effective_clock_ghz` = GRBM_GUI_ACTIVE / "
+                         "mix_floor_ms / launch time; (2) the chip does not hold 2.4 GHz under this load: `effective_clock_ghz` = GRBM_GUI_ACTIVE per XCD / "
                          "duration of the profiled launch, `*_at_effective_clock` are the same fractions at that clock.  HBM is not the limit: "
                          "`traffic` (2*FETCH_SIZE + WRITE_SIZE of the PMC passes) is `hbm_frac_measured` of 8 TB/s; `vs_noreuse_model` "
                          "is SURVEY 8(d)'s no-reuse byte model over launch time over 8 TB/s (above 1: neighbour rows are shared by the "
@@ -547,7 +550,8 @@ def run(a, rank, local_rank, world):
     dev = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("VCY_FORCE_COLLECTIVES", "0") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
+        if "MASTER_PORT" not in os.environ:                      # (world 1 with forced collectives; launchers always set it)
+            os.environ["MASTER_PORT"] = str(_free_port())
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
         backend = os.environ.get("VCY_DIST_BACKEND", "nccl")   # "nccl" = RCCL over xGMI; "gloo" only for the one-GPU logic test
@@ -555,6 +559,7 @@ def run(a, rank, local_rank, world):
             dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == world and dist.get_rank() == rank, "process group does not match the launcher's ranks"
     import velocyto_amd  # noqa: F401
     from velocyto_amd import _lib
     _lib.lib()   # fail loudly if the HIP library is missing
@@ -584,6 +589,20 @@ def run(a, rank, local_rank, world):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / a.steps * 1e3
+    # every rank's own view of the pass (stage times, shard and halo sizes) -> rank 0, for config.parallelism_detail
+    per_rank = None
+    if dist.is_initialized() and pipe.collect:
+        mine = torch.tensor([*(pipe.stage_ms / a.steps), float(pipe.c1 - pipe.c0), float(pipe.plan.n_recv if pipe.plan is not None else 0),
+                             float(pipe.plan.n_send if pipe.plan is not None else 0),
+                             float(pipe.sched[0].numel() if pipe.sched is not None else 0), float(getattr(pipe, "n_interior", 0))], dtype=torch.float64)
+        if dist.get_backend() == "gloo":
+            rows = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(rows, mine)
+            per_rank = torch.stack(rows).numpy()
+        else:
+            rows = torch.zeros((dist.get_world_size(), mine.numel()), dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(rows, mine.to(dev))
+            per_rank = rows.cpu().numpy()
 
     if rank == 0 and a.dump:
         # in a sharded run the cells were relabelled (curve order of the embedding): report in the original labels
@@ -611,12 +630,15 @@ def run(a, rank, local_rank, world):
             "B_fit_slope": {"ms": stage[1], "bound": "hbm", "algorithmic_bytes": nloc * 2 * G * s, "achieved_GBs": nloc * 2 * G * s / (stage[1] * 1e-3) / 1e9,
                             "frac": nloc * 2 * G * s / (stage[1] * 1e-3) / HBM_PEAK},
         }
+        rccl_ranks = dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0
+        if world > 1 and os.environ.get("VCY_DIST_BACKEND", "nccl") == "nccl":
+            assert rccl_ranks == a.gpus, f"--gpus {a.gpus} but RCCL runs {rccl_ranks} ranks"       # never print a multi-GPU line RCCL did not carry
         res = {
             "metric": "cells/sec through knn_imputation->fit_slope->colDeltaCor, 50k cells x 30k genes",
             "value": C / (ms_per_step * 1e-3), "unit": "cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
-            "rccl_ranks": dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0,
+            "rccl_ranks": rccl_ranks,
             "config": {"workload": f"synthetic {C} cells x {G} genes (BASELINE.json configs[2]): knn_imputation(k={a.k}, "
                                    f"{a.pca_dims} PCs) -> fit_slope -> velocity chain -> colDeltaCorSqrtpartial(nrndm={nr}, "
                                    f"n_neighbors={a.n_neighbors}, sampled_fraction={a.sampled_fraction}, psc=1e-10)",
@@ -625,11 +647,12 @@ def run(a, rank, local_rank, world):
                                  "(S_sz = factor*counts), pcs, sampled neighbours",
                        "parallelism": "single GPU" if world == 1 else f"cells sharded over {world} GPUs in embedding ({a.curve} curve) order; RCCL "
                                       "all-reduce of fit moments, " + (f"halo exchange of Sx rows into a compact own+halo buffer (all_to_all, {pipe.plan.n_recv} "
-                                      f"of {C} rows received by rank 0" + (f"; overlapped with stage D of the {int(pipe.sched[0].numel())} interior cells of {nloc})"
+                                      f"of {C} rows received by rank 0" + (f"; overlapped with stage D of {int(pipe.sched[0].numel())} of the {pipe.n_interior} interior cells of {nloc}: whole device rounds)"
                                                               if pipe.sched is not None else ")") if pipe.plan is not None else "all-gather of Sx shards") +
                                       ", all-gather of correlation rows",
                        "stage_ms": {"A_knn_imputation": stage[0], "B_fit_slope": stage[1], "C_velocity_chain": stage[2],
                                     "D_exchange": stage[3], "D_coldeltacor": stage[4]},
+                       **({"parallelism_detail": parallelism_detail(a, pipe, per_rank, s)} if per_rank is not None else {}),
                        "stage_D_rule": rule_name,
                        "velocity_chain": "folded into the staging of d[c] in the stage-D kernel" if a.fuse else "k_velocity_chain (dmat materialised)",
                        "cell_order_D": a.order + (f" ({a.curve} curve)" if a.order == "embedding" else "")},
@@ -662,6 +685,35 @@ def run(a, rank, local_rank, world):
         if not a.no_cpu_baseline and world == 1:     # reported on rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(pipe, a)
     finish(res, rank)
+
+
+def parallelism_detail(a, pipe, per_rank, s):
+    """What every rank did and what every collective moved (one pass), from the ranks' own HIP-event times and plan sizes."""
+    C, G, nr = a.cells, a.genes, pipe.nrndm
+    ld = pipe.ops.padded_ld(G)
+    names = ("A_knn_imputation", "B_fit_slope", "C_velocity_chain", "D_exchange", "D_coldeltacor", "A_knn_search", "A_pooling")
+    ranks = []
+    for r, v in enumerate(per_rank):
+        ranks.append({"rank": r, "cells": int(v[7]), "halo_rows_received": int(v[8]), "halo_rows_sent": int(v[9]), "interior_cells": int(v[11]),
+                      "cells_run_while_the_halo_moves": int(v[10]),
+                      "stage_ms": {n: float(v[i]) for i, n in enumerate(names)}})
+    return {"per_rank": ranks,
+            "bytes_per_collective": {
+                "B_all_reduce_fit_moments": 3 * G * 8,
+                "D_halo_all_to_all_received_per_rank": [int(v[8]) * ld * s for v in per_rank] if a.exchange == "halo" else None,
+                "D_all_gather_Sx_total": None if a.exchange == "halo" else C * ld * s,
+                "D_all_gather_correlation_rows_total": C * nr * s},
+            "note": "stage_ms are each rank's own HIP-event times; D_exchange is the time the rank's stream spent waiting for the halo rows "
+                    "(0 when the transfer finished under the interior cells' stage D) plus the all-gather of the correlation rows"}
+
+
+def _free_port():
+    """A TCP port nobody listens on right now (self-launched ranks and forced-collective runs without a launcher): successive
+    runs on one box never meet a predecessor's socket in TIME_WAIT."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
 
 def extra_lines(a, dev, pipe):
@@ -740,7 +792,8 @@ def main():
         run(a, rank, local_rank, world)
     elif a.gpus > 1:                                 # self-launch: one process per GPU
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(_free_port())
         import torch.multiprocessing as mp
         mp.spawn(_spawned, args=(a,), nprocs=a.gpus, join=True)
     else:

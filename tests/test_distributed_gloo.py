@@ -186,3 +186,23 @@ def test_ragged_count_row_halo(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert done == list(range(world))
+
+
+def test_overlap_schedules_round_alignment():
+    """distributed.overlap_schedules: the first launch holds whole rounds of interior cells in schedule order, the second everything
+    else in schedule order; together they are a permutation of the rank's cells."""
+    import torch
+    from velocyto_amd import distributed as D
+    g = torch.Generator().manual_seed(3)
+    n = 6250
+    base = torch.randperm(n, generator=g)
+    interior = torch.rand(n, generator=g) < 0.6
+    first, second = D.overlap_schedules(base, interior, 2048)
+    assert first.numel() == (int(interior.sum()) // 2048) * 2048 and first.numel() + second.numel() == n
+    assert bool(interior[first.long()].all())
+    assert torch.equal(torch.sort(torch.cat([first, second]).long()).values, torch.arange(n))
+    pos = torch.empty(n, dtype=torch.long); pos[base] = torch.arange(n)
+    assert bool((pos[first.long()][1:] > pos[first.long()][:-1]).all()) and bool((pos[second.long()][1:] > pos[second.long()][:-1]).all())
+    # fewer interior cells than one round: nothing runs before the halo has landed
+    first, second = D.overlap_schedules(base, torch.zeros(n, dtype=torch.bool).index_fill_(0, base[:100], True), 2048)
+    assert first.numel() == 0 and torch.equal(second.long(), base)

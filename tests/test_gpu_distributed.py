@@ -73,7 +73,10 @@ def test_rccl_collectives_on_one_gpu(tmp_path):
         np.testing.assert_array_equal(got["gamma"], ref["gamma"])
         fin = np.isfinite(ref["corr"])
         assert np.array_equal(np.isfinite(got["corr"]), fin)
-        np.testing.assert_array_equal(got["corr"][fin], ref["corr"][fin])
+        if got is rccl:                      # same schedules, same launches: the transport must not change a bit
+            np.testing.assert_array_equal(got["corr"][fin], ref["corr"][fin])
+        else:                                # the all-gather exchange runs stage D as ONE launch, the halo exchange as whole rounds + the rest
+            np.testing.assert_allclose(got["corr"][fin], ref["corr"][fin], atol=2e-6)     # (other tiles / kernels for the last cells)
 
 
 def test_bench_self_launch_equals_torchrun(tmp_path):
@@ -87,3 +90,50 @@ def test_bench_self_launch_equals_torchrun(tmp_path):
     assert np.array_equal(a["neigh"], b["neigh"]) and np.array_equal(a["gamma"], b["gamma"])
     fin = np.isfinite(a["corr"])
     assert np.array_equal(np.isfinite(b["corr"]), fin) and np.array_equal(b["corr"][fin], a["corr"][fin])
+
+
+def test_eight_ranks_at_full_size_on_one_device(tmp_path):
+    """BASELINE.json configs[3] rehearsed on one device: the 50 000 x 30 000 problem of the headline cut into EIGHT shards of 6 250
+    cells, one process per shard, every process on cuda:0 with the collectives host-staged through gloo - everything of the
+    8-GPU run except the transport: relabelling along the Hilbert curve, shard-sized kNN queries and pooling, the all-reduce of
+    the fit moments, the halo plan with sharded e (compact own + halo buffers, renumbered lists, zero-length splits between
+    ranks that share no row), stage D split into interior cells and cells with remote neighbours, the all-gather of the
+    correlation rows, the whole-matrix decision on the branch rule.  Labels, neighbour samples, gamma and ALL 12.5 M
+    correlation rows must equal the one-rank run; the JSON line must carry every rank's own account of the pass."""
+    import json
+    from velocyto_amd import ops
+    ops.require_gpu()
+    if torch.cuda.mem_get_info()[1] < 200e9:
+        pytest.skip("needs the memory of one MI355X for eight co-resident ranks")
+    full = ["--no-cpu-baseline", "--no-extra", "--steps", "1", "--warmup", "1"]
+
+    def go(world, dump, port):
+        env = dict(os.environ, VCY_SINGLE_DEVICE="1", VCY_DIST_BACKEND="gloo", VCY_FORCE_COLLECTIVES="1", MASTER_PORT=str(port),
+                   MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, "bench.py", "--gpus", str(world), *full, "--dump", dump], cwd=ROOT, env=env, capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return dict(np.load(dump)), json.loads([l for l in r.stdout.strip().splitlines() if l.strip()][-1])
+    one, j1 = go(1, str(tmp_path / "one.npz"), 29801)
+    many, j8 = go(8, str(tmp_path / "eight.npz"), 29808)
+    assert j8["n_gpus"] == 8 and j8["config"]["cells"] == 50000 and j8["config"]["genes"] == 30000 and j8["config"]["nrndm"] == 250
+    assert np.array_equal(one["perm"], many["perm"]) and np.array_equal(one["neigh"], many["neigh"])
+    np.testing.assert_allclose(many["gamma"], one["gamma"], rtol=2e-6, atol=1e-9)
+    assert one["corr"].shape == (50000, 250)
+    fin = np.isfinite(one["corr"])
+    assert np.array_equal(np.isfinite(many["corr"]), fin) and fin.mean() > 0.999
+    assert np.abs(many["corr"][fin] - one["corr"][fin]).max() <= 2e-6
+    det = j8["config"]["parallelism_detail"]
+    ranks = det["per_rank"]
+    assert len(ranks) == 8 and sum(r["cells"] for r in ranks) == 50000 and all(r["cells"] == 6250 for r in ranks)
+    assert all(0 < r["halo_rows_received"] < 50000 - 6250 for r in ranks)             # a halo, not the whole matrix
+    assert sum(r["halo_rows_received"] for r in ranks) == sum(r["halo_rows_sent"] for r in ranks)
+    assert all(0 < r["interior_cells"] < 6250 for r in ranks) and all(r["stage_ms"]["D_coldeltacor"] > 0 for r in ranks)
+    # the launch that overlaps the transfer holds whole device rounds of interior cells (distributed.overlap_schedules)
+    assert all(r["cells_run_while_the_halo_moves"] % 2048 == 0 and r["cells_run_while_the_halo_moves"] <= r["interior_cells"] for r in ranks)
+    b = det["bytes_per_collective"]
+    assert b["B_all_reduce_fit_moments"] == 3 * 30000 * 8 and b["D_all_gather_correlation_rows_total"] == 50000 * 250 * 4
+    assert b["D_halo_all_to_all_received_per_rank"] == [r["halo_rows_received"] * 30016 * 4 for r in ranks]
+    assert j8["config"]["stage_D_rule"] == j1["config"]["stage_D_rule"]

@@ -70,7 +70,8 @@ for sfx, dname, ctype, chunk in (("", "f32", "float", 1536), ("_f64", "f64", "do
     kname = next(kn for (cn, kn) in acc if tagk in kn and cn == "SQ_INSTS_VALU")
     rule = {"1": "partial (literal)", "2": "partial, pseudocount dropped (VCY_RULES_PARTIAL_NOPSC)", "0": "full"}.get(kname.split("<")[1].split(",")[2].strip(), "?")
     wc = cdc.get("SQ_WAVE_CYCLES")
-    ghz = cdc["GRBM_GUI_ACTIVE"] / dur["GRBM_GUI_ACTIVE"] if "GRBM_GUI_ACTIVE" in cdc else None      # cycles per ns
+    # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (each has its own GRBM; a single-XCD reading would be 18 "GHz"): cycles per ns per XCD
+    ghz = cdc["GRBM_GUI_ACTIVE"] / dur["GRBM_GUI_ACTIVE"] / 8.0 if "GRBM_GUI_ACTIVE" in cdc else None
     counters[dname] = {
         "profile": f"profiles/{tag}_bench_50kx30k_pmc.csv", "kernel": kname.split("(")[0].replace("void vcy::", ""), "rules": int(kname.split("<")[1].split(",")[2]),
         "rule": rule,
@@ -86,8 +87,8 @@ for sfx, dname, ctype, chunk in (("", "f32", "float", 1536), ("_f64", "f64", "do
         "wave_time": {k: (cdc[c] / wc if wc and c in cdc else None) for k, c in
                       (("parked_at_waitcnt_or_barrier", "SQ_WAIT_ANY"), ("waiting_to_issue", "SQ_WAIT_INST_ANY"), ("issuing", "SQ_ACTIVE_INST_ANY"))},
         "note": "counters of ONE launch under rocprofv3 --pmc (separate passes for FETCH_SIZE, WRITE_SIZE, the SQ set and GRBM_GUI_ACTIVE); HBM-side read "
-                "bytes = 2 x FETCH_SIZE x 1024 on gfx950 (MI355X_MICROARCH.md, HBM); effective_clock_ghz = GRBM_GUI_ACTIVE / duration of that launch "
-                "(the chip clocks to its power budget: MI355X_MICROARCH.md, DVFS)"}
+                "bytes = 2 x FETCH_SIZE x 1024 on gfx950 (MI355X_MICROARCH.md, HBM); effective_clock_ghz = GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / duration "
+                "of that launch (the chip clocks to its power budget: MI355X_MICROARCH.md, DVFS)"}
 
 with open(os.path.join(OUT, f"{tag}_bench_50kx30k_kernel_stats.csv"), "w", newline="") as f:
     w = csv.writer(f)

@@ -799,7 +799,7 @@ static int launch_grouped(const void *e, const void *d, const void *d2, const in
     // 3.05 rounds -> 4).  The groups beyond the last full round therefore run as the last blocks of the launch with their
     // neighbour lists cut into narrower tiles, as many (group, tile) blocks as there are CUs.
     const int64_t groups = (C_out + GC - 1) / GC, W = dev.cus > 0 ? dev.cus : 256;
-    const int64_t full = groups >= 2 * W ? groups / W * W : 0;
+    const int64_t full = groups >= W ? groups / W * W : 0;       // (from one round on: a 270-group launch is one round + a tiled tail, not two rounds)
     const int64_t c_main = full * GC, c_tail = C_out - c_main;
     int64_t tw = tile;
     if (c_tail > 0) {

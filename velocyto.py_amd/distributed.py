@@ -306,3 +306,25 @@ class HaloPlan:
         elif out is not None and recv.data_ptr() != out[row0:row0 + self.n_recv].data_ptr():
             out[row0:row0 + self.n_recv].copy_(recv)
         return out
+
+
+def overlap_schedules(base: torch.Tensor, interior: torch.Tensor, cells_per_round: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Two stage-D schedules for the halo overlap: (cells that run WHILE the halo rows move, cells that run after).
+
+    `base`: the rank's cells in schedule order (int64 local cell numbers); `interior`: bool per local cell, True when every
+    sampled neighbour is rank-local.  Only interior cells may run before the halo has landed, but not all of them have to:
+    the grouped stage-D kernel keeps one workgroup per CU, every group of 8 cells costs the same, so a launch costs whole
+    ROUNDS of `cells_per_round` (= CUs x cells per group) cells plus one tiled tail - and two launches pay two tails.  The
+    first launch therefore takes the largest whole number of rounds the interior cells fill (at least one round covers the
+    transfer of a halo: ~3 ms of work against ~2 ms of xGMI time at 8 ranks), everything else - the remaining interior cells
+    and the cells with remote neighbours, in schedule order - goes to the second launch, which then holds the only tail.
+    Measured on 6 250-cell shards (tools/shard_model.py): interior + remote as they fall 12.4 ms, round-aligned 9.5 ms, one
+    launch 9.8 ms.  With less than one round of interior cells there is nothing to overlap: ([], all)."""
+    inter_sched = base[interior[base]]
+    n1 = (int(inter_sched.numel()) // cells_per_round) * cells_per_round
+    if n1 == 0:
+        return base[:0].to(torch.int32).contiguous(), base.to(torch.int32).contiguous()
+    first = inter_sched[:n1]
+    taken = torch.zeros(interior.numel(), dtype=torch.bool, device=base.device)
+    taken[first] = True
+    return first.to(torch.int32).contiguous(), base[~taken[base]].to(torch.int32).contiguous()
