@@ -217,6 +217,13 @@ int vcy_balance_knn_host(const int64_t *dsi_host, const double *dist_host, const
                          const int64_t *groups_host, int64_t n, int64_t K, int64_t maxl, int64_t k,
                          int return_distance, double *dist_new_host, int64_t *dsi_new_host, int64_t *l_host);
 
+/* The same selection on int32 sight lists (the type vcy_knn_search returns) without distances on the host: pos_new_host (n, k+1)
+ * receives the position of every selected neighbour in its cell's sight list (-1: column 0 and padded slots), so that the caller
+ * gathers the distances where they live.  For the reference's default sight = whole dataset (analysis.py:985-988) this keeps the
+ * host side at n * K * 4 bytes instead of n * K * 16.                                                                          */
+int vcy_balance_knn_host32(const int32_t *dsi_host, const int64_t *lsi_host, const int64_t *groups_host, int64_t n, int64_t K,
+                           int64_t maxl, int64_t k, int32_t *pos_new_host, int64_t *dsi_new_host, int64_t *l_host);
+
 /* ---------------------------------------------------------------- stage B: gamma fits
  * estimation.fit_slope + _fit1_slope (estimation.py:173-188, 267-279): per gene
  *     gamma = max(0, sum_c x*y / sum_c x*x), NaN if x == 0 everywhere, 0 if y == 0 everywhere;

@@ -178,35 +178,50 @@ def test_atlas_sharded_ranks_equal_one_rank(tmp_path, world, extra):
     np.testing.assert_allclose(many["corr"][fin], one["corr"][fin], atol=2e-6)
 
 
-def test_atlas_fullsize_200k_cells_30k_genes(ops, oracle):
-    """BASELINE.json configs[4] at the size ONE GPU walks: 200 000 cells x 30 000 genes, CSR layers at ~8 % density,
-    streamed in four blocks (dense Sx/Ux of the whole dataset would be 48 GB; a block holds ~15 GB).
+@pytest.mark.parametrize("C,block_cells,nblocks", [(200_000, 50_000, 4), (1_000_000, "auto", 3)])
+def test_atlas_fullsize_cells_30k_genes(ops, oracle, C, block_cells, nblocks):
+    """BASELINE.json configs[4]: 30 000 genes, CSR layers at ~8 % density, streamed over cell blocks - at 200 000 cells in four
+    blocks of 50 000 (dense Sx/Ux of the whole dataset would be 48 GB; a block holds ~15 GB) and at the STATED size, 1 000 000
+    cells, on one MI355X in the default blocks (three of 366 350 cells on 288 GB; the dense f32 layers alone would be 240 GB).
       * pooling from CSR == pooling from the densified layers, bit for bit, on cell blocks from both ends of the dataset;
+      * the exact kNN graph (projection-pruned from 100 000 cells on) == brute force on sampled queries;
       * gamma against fp64 column sums of the pooled blocks; correlations of sampled cells against the fp64 oracle on the
         rows they touch (f32 tolerance 5e-5); size-independent properties of the whole result."""
     from velocyto_amd import atlas
     dev = ops.require_gpu()
-    C, G, k = 200_000, 30_000, 30
+    if C > 500_000 and torch.cuda.mem_get_info()[1] < 250e9:
+        pytest.skip("the 1M-cell pass with its default blocks needs the memory of one MI355X")
+    G, k = 30_000, 30
     cS, cU, totS, totU, pcs, emb = atlas.synth_atlas(C, G, 30, dev, density=0.08)
     dens = cS.nnz / (C * G)
     assert 0.07 < dens < 0.09, dens
     fS, fU = atlas.size_factors(totS, totU, C)
-    path = atlas.AtlasPath(cS, cU, fS, fU, pcs, emb, k=k, n_neighbors=500, sampled_fraction=0.5, block_cells=50_000)
-    assert path.nrndm == 250 and len(path.blocks()) == 4
+    if block_cells == "auto":                                         # what `bench.py --workload cfg5` picks from the free HBM
+        block_cells = atlas.auto_block_cells(C, C, G, dev)
+    path = atlas.AtlasPath(cS, cU, fS, fU, pcs, emb, k=k, n_neighbors=500, sampled_fraction=0.5, block_cells=block_cells)
+    assert path.nrndm == 250 and (len(path.blocks()) == nblocks if C <= 500_000 else 2 <= len(path.blocks()) <= 6), path.blocks()
     corr = path.run()
-    # ---- A: CSR pooling against the dense kernel on the densified layer (6 GB of uint8 per layer), three blocks of 4096 cells
-    dS, dU = cS.to_dense(), cU.to_dense()
-    for b0 in (0, 101_000, C - 4096):
+    assert corr.shape == (C, 250)
+    # ---- A: the graph the pass pooled with (pruned search from 100 000 cells on) against brute force on 2048 spread queries
+    q = (torch.arange(2048, device=dev) * (C / 2048)).long()
+    bi, bd = ops.knn_query(pcs, pcs[q], k + 1)                         # the query itself comes back in column 0 (distance 0)
+    assert bool((bd[:, 0] == 0).all())
+    assert torch.equal(torch.sort(bi.long(), 1).values, torch.sort(path.g_idx[q].long(), 1).values), "pruned kNN graph differs from brute force"
+    # ---- A: CSR pooling against the dense kernel on the densified count rows the block touches, three blocks of 4096 cells
+    for b0 in (0, C // 2 + 1000, C - 4096):
         rows = slice(b0, b0 + 4096)
         gi, gw = path.g_idx[rows], path.g_w[rows]
+        sel = torch.unique(gi.reshape(-1).long())                       # count rows the block gathers (ascending); densify only those
+        loc = torch.searchsorted(sel, gi.reshape(-1).long()).to(torch.int32)
+        dS, dU = path.cS.rows(sel).to_dense(), path.cU.rows(sel).to_dense()
         ptr = torch.arange(0, 4097 * (k + 1), k + 1, device=dev, dtype=torch.int64)
-        ref_S, ref_U = ops.knn_pool_counts(dS, dU, path.fS, path.fU, ptr, gi.reshape(-1), gw.reshape(-1), dtype=torch.float32, C_out=4096, validate=False)
+        ref_S, ref_U = ops.knn_pool_counts(dS, dU, path.fS[sel], path.fU[sel], ptr, loc, gw.reshape(-1), dtype=torch.float32, C_out=4096, validate=False)
         got_S = ops.CellMatrix.empty(4096, G, torch.float32)
         got_U = ops.CellMatrix.empty(4096, G, torch.float32)
         path._pool(path.cS, path.fS, rows, got_S)
         path._pool(path.cU, path.fU, rows, got_U)
         assert torch.equal(got_S.t, ref_S.t) and torch.equal(got_U.t, ref_U.t), f"block at {b0}: CSR pooling differs from dense pooling"
-    del dS, dU, ref_S, ref_U
+        del dS, dU, ref_S, ref_U, got_S, got_U
     # ---- B: gamma = max(0, <Sx,Ux>/<Sx,Sx>) over ALL cells, re-derived in fp64 from freshly pooled blocks
     sxx = torch.zeros(G, dtype=torch.float64, device=dev)
     sxy = torch.zeros(G, dtype=torch.float64, device=dev)
@@ -226,7 +241,7 @@ def test_atlas_fullsize_200k_cells_30k_genes(ops, oracle):
     assert bool((path.neigh[:, 1:] > path.neigh[:, :-1]).all()) and int(path.neigh.max()) < C
     # ---- D: sampled cells against the fp64 oracle (first / last block, block boundaries)
     g64 = path.gamma.double().cpu().numpy()
-    for c in (17, 49_999, 50_000, 123_456, C - 3):
+    for c in (17, 49_999, 50_000, 123_456, C // 2 + 1, path.blocks()[1][0] - 1, path.blocks()[1][0], C - 3):     # incl. both sides of a block boundary
         nb = path.neigh[c].long()
         rows = torch.cat([torch.tensor([c], device=dev), nb])
         eS = ops.CellMatrix.empty(rows.numel(), G, torch.float32)

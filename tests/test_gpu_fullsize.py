@@ -144,6 +144,53 @@ def test_fullsize_pipeline_properties_and_spot_checks(world, oracle):
         np.testing.assert_allclose(got[okc], ref[okc], atol=5e-5)
 
 
+def test_fullsize_stage_d_256_cells_against_the_oracle(world, oracle):
+    """Stage D at the headline size against the fp64 oracle on 256 whole cells = 64 000 pairs x 30 000 genes: 192 cells spread
+    over the dataset + 64 from the groups beyond the last full round of the launch (they run as narrower column tiles: every
+    tile of such a cell is covered, all 250 columns are compared).  f32 production rule and the literal rule, fused launch."""
+    w, ops = world, world["ops"]
+    dev = w["dev"]
+    rng = np.random.default_rng(23)
+    S, U, pcs, neigh = w["S"], w["U"], w["pcs"], w["neigh"]
+    idx, dist, indptr, indices, wrow = _pool_inputs(w, ops)
+    indices, wrow = ops.canonical_graph_rows(indices.reshape(C, K + 1), wrow)
+    Sx = ops.knn_pool(S, indptr, indices, wrow, validate=False)
+    Ux = ops.knn_pool(U, indptr, indices, wrow, validate=False)
+    gam = ops.fit_slope(Ux, Sx)
+    gam[~torch.isfinite(gam)] = 0.0
+    g64 = gam.double().cpu().numpy()
+    tail0 = (C // 8 // 256) * 256 * 8                      # first cell of the tiled tail part (natural schedule, 8-cell groups, 256 CUs)
+    assert 0 < C - tail0 < 2048
+    cells = np.concatenate([rng.choice(tail0, 192, replace=False), rng.choice(np.arange(tail0, C), 64, replace=False)])
+    got = {}
+    for name, rules in (("production", ops.partial_rules_for(Sx, ops.SQRT, 1e-10)), ("literal", ops.RULES_PARTIAL)):
+        got[name] = ops.coldeltacor_partial_fused(Sx, Ux, gam, None, neigh, ops.SQRT, rules, 1e-10, validate=False)[torch.as_tensor(cells, device=dev)].cpu().numpy()
+    worst = {"production": 0.0, "literal": 0.0}
+    B = 64                                                 # cells per oracle call (its OpenMP loop runs over cells): <= 16 064 rows of e on the host
+    for b in range(0, len(cells), B):
+        cs = cells[b:b + B]
+        nb = neigh[torch.as_tensor(cs, device=dev)].long().cpu().numpy()
+        others = np.setdiff1d(np.unique(nb.ravel()), cs)
+        rows = np.concatenate([cs, others])                 # the batch's cells first: columns 0 .. B-1 of the sub-problem
+        col = np.full(C, -1, dtype=np.int64)
+        col[rows] = np.arange(len(rows))
+        e_sub = Sx.t[torch.as_tensor(rows, device=dev), :G].double().cpu().numpy().T.copy()    # (G, rows), the oracle's layout
+        s, u = e_sub[:, :len(cs)], Ux.t[torch.as_tensor(cs, device=dev), :G].double().cpu().numpy().T
+        Dv = (s + (u - g64[:, None] * s)) - s
+        d_sub = np.zeros_like(e_sub)
+        d_sub[:, :len(cs)] = np.sign(Dv) * np.sqrt(np.abs(Dv) + 1e-10)
+        ixs = np.zeros((len(rows), nb.shape[1]), dtype=np.int64)
+        ixs[:len(cs)] = col[nb]
+        ref = oracle.coldeltacor_partial_compact(e_sub, d_sub, ixs, "sqrt", 1e-10, c0=0, c1=len(cs))[:len(cs)]
+        ok = np.isfinite(ref)
+        for name in got:
+            g_ = got[name][b:b + B]
+            assert np.array_equal(np.isnan(g_), ~ok)
+            worst[name] = max(worst[name], float(np.abs(g_[ok] - ref[ok]).max()))
+        del e_sub, d_sub
+    assert worst["production"] <= 5e-5 and worst["literal"] <= 5e-5, worst
+
+
 def test_fullsize_markov_chain_factored_vs_dense(world):
     """prepare_markov / run_markov at 50 000 cells: the factored chain (no (n, n) matrix) against the dense matrix it stands for
     (10 GB in f32, streamed by k_vecmat_dense_vec), plus what must hold at any size: every iterate is a probability vector
@@ -311,3 +358,41 @@ def test_cfg2_size_balanced_knn_imputation_and_fit_slope(oracle):
         ref = np.maximum(0, (X * Y).sum(0) / (X * X).sum(0))
         ok = np.isfinite(ref)
         np.testing.assert_allclose(vlm.gammas[genes][ok], ref[ok], rtol=2e-5, atol=1e-7)
+        # ---- the same step by the ORACLE on the whole 10 000 x 20 000 problem (fp64 restatement of analysis.py:982-1023):
+        #      the graph bit for bit, every pooled value and every gamma at the f32 tolerances
+        S_sz, U_sz = np.asarray(vlm.S_sz, dtype=np.float64), np.asarray(vlm.U_sz, dtype=np.float64)
+        o_knn, o_w, o_Sx, o_Ux = oracle.knn_imputation(S_sz, U_sz, P, k=k, balanced=balanced, b_sight=240, b_maxl=120)
+        if balanced:
+            _, o_dist, o_dsi, o_l = oracle.balanced_knn_graph(P, k, 240, 120)
+            bk = velocyto_amd.neighbors.BalancedKNN(k=k, sight_k=240, maxl=120, n_jobs=4).fit(P)
+            d_new, dsi_new, l_new = bk.kneighbors()
+            assert np.array_equal(dsi_new, o_dsi) and np.array_equal(l_new, o_l), "balanced graph differs from the oracle's"
+            np.testing.assert_allclose(d_new, o_dist, rtol=1e-12, atol=1e-12)
+            assert bk.dsi.shape == (Cc, 241) and bk.dist.shape == (Cc, 241)     # the sight lists stayed on the device until somebody asked
+        o_csr = o_knn.tocsr(); o_csr.sort_indices()
+        k_csr = knn.copy(); k_csr.sort_indices()
+        assert np.array_equal(k_csr.indptr, o_csr.indptr) and np.array_equal(k_csr.indices, o_csr.indices), "kNN graph differs from the oracle's"
+        np.testing.assert_allclose(k_csr.data, o_csr.data, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(np.asarray(vlm.Sx), o_Sx, rtol=3e-6, atol=1e-6)
+        np.testing.assert_allclose(np.asarray(vlm.Ux), o_Ux, rtol=3e-6, atol=1e-6)
+        o_g = oracle.fit_slope(o_Ux, o_Sx)
+        okg = np.isfinite(o_g)
+        np.testing.assert_allclose(vlm.gammas[okg], o_g[okg], rtol=2e-5, atol=1e-7)
+        del S_sz, U_sz, o_Sx, o_Ux
+    # ---- the reference's DEFAULT sight (analysis.py:985-988: b_sight = max(8k, N - 1) = the whole dataset, b_maxl = max(4k, N - 1)):
+    #      (C, C) sight lists, kept on the device; graph against the oracle's, bit for bit
+    vlm.knn_imputation(k=k, n_pca_dims=30, balanced=True, n_jobs=4)
+    _, o_dist, o_dsi, o_l = oracle.balanced_knn_graph(P, k, Cc - 1, Cc - 1)
+    got = vlm.knn.tocsr(); got.sort_indices()
+    want = sparse_from_lists(o_dsi, o_dist, Cc)
+    assert np.array_equal(got.indices, want.indices) and np.allclose(got.data, want.data, rtol=1e-12, atol=1e-12)
+    bk = velocyto_amd.neighbors.BalancedKNN(k=k, sight_k=Cc - 1, maxl=Cc - 1, n_jobs=4).fit(P)
+    d_new, dsi_new, l_new = bk.kneighbors()
+    assert np.array_equal(dsi_new, o_dsi) and np.array_equal(l_new, o_l)
+
+
+def sparse_from_lists(dsi, dist, n):
+    from scipy import sparse
+    m = sparse.csr_matrix((dist.ravel(), dsi.ravel(), np.arange(0, dsi.size + 1, dsi.shape[1])), shape=(n, n))
+    m.sort_indices()
+    return m

@@ -364,6 +364,14 @@ def size_factors(totS: torch.Tensor, totU: torch.Tensor, C: int) -> Tuple[torch.
     return (sums[0] / C) / totS.clamp(min=1.0), (sums[1] / C) / totU.clamp(min=1.0)
 
 
+def auto_block_cells(nloc: int, C: int, G: int, dev) -> int:
+    """Cells per streamed block chosen from the free HBM: as many as fit beside the CSR layers - a block holds ~2.6 dense f32
+    rows per cell (Sx + the e rows it reads outside itself, Ux); the kNN workspace of 8192 queries x C distances and 6 GB of
+    headroom stay free.  On 288 GB: 1M cells x 30k genes walk in three blocks of ~366 000 cells."""
+    free = torch.cuda.mem_get_info(dev)[0] - 8192 * C * 4 - (6 << 30)
+    return int(max(4096, min(nloc, free * 0.6 // (2.6 * ops.padded_ld(G) * 4))))
+
+
 def bench_main(a, dev, rank: int, world: int) -> Optional[dict]:
     """bench.py --workload cfg5: the streamed path on synthetic CSR layers; returns the JSON record on rank 0."""
     C, G = a.cells, a.genes
@@ -372,11 +380,7 @@ def bench_main(a, dev, rank: int, world: int) -> Optional[dict]:
     cS, cU, totS, totU, pcs, emb = synth_atlas(C, G, a.pca_dims, dev, density=a.density, c0=c0, c1=c1)
     fS, fU = size_factors(totS, totU, C)
     nloc = c1 - c0
-    block = a.block_cells
-    if block <= 0:
-        # as many cells per block as fit beside the CSR layers: a block holds ~2.6 dense rows per cell (Sx + outside rows, Ux)
-        free = torch.cuda.mem_get_info(dev)[0] - 8192 * C * 4 - (6 << 30)
-        block = int(max(4096, min(nloc, free * 0.6 // (2.6 * ops.padded_ld(G) * 4))))
+    block = a.block_cells if a.block_cells > 0 else auto_block_cells(nloc, C, G, dev)
     path = AtlasPath(cS, cU, fS, fU, pcs, emb, c0=c0, C_total=C, k=a.k, n_neighbors=a.n_neighbors, sampled_fraction=a.sampled_fraction,
                      block_cells=block, dtype=torch.float32, knn=getattr(a, "knn", "auto"))
     torch.cuda.synchronize()

@@ -495,3 +495,40 @@ extern "C" int vcy_balance_knn_host(const int64_t *dsi, const double *dist, cons
         for (int64_t t = 0; t < n * w; ++t) dist_new[t] = 1.0;
     return VCY_OK;
 }
+
+// The same loop on the sight lists AS THE DEVICE SEARCH RETURNS THEM: int32 neighbour numbers (a quarter of the host memory of
+// the int64 + fp64 pair the reference holds - its default sight is the whole dataset, analysis.py:985-988: (C, C) lists, 40 GB of
+// host arrays at 50 000 cells against 10 GB here), no distances on the host at all.  Instead of distances it returns the POSITION
+// j of every selected neighbour in its cell's sight list (pos_new, -1 for column 0 and for padded slots), from which the caller
+// gathers dist[el, j] where the distances live (the device).  Selection identical to vcy_balance_knn_host.
+extern "C" int vcy_balance_knn_host32(const int32_t *dsi, const int64_t *lsi, const int64_t *groups, int64_t n, int64_t K, int64_t maxl,
+                                      int64_t k, int32_t *pos_new, int64_t *dsi_new, int64_t *l)
+{
+    VCY_REQUIRE(dsi && lsi && pos_new && dsi_new && l, "balance_knn32: null pointer");
+    VCY_REQUIRE(n > 0 && K >= k && k > 0 && K < (1LL << 31), "balance_knn32: sight needs to be bigger than k");
+    const int64_t w = k + 1;
+    for (int64_t t = 0; t < n * w; ++t) { dsi_new[t] = -1; pos_new[t] = -1; }
+    for (int64_t t = 0; t < n; ++t) l[t] = 0;
+    for (int64_t it = 0; it < n; ++it) {
+        const int64_t el = lsi[it];
+        if (el < 0 || el >= n) return fail(VCY_ERR_INVALID, "%s: lsi entry out of range", "balance_knn32");
+        const int32_t *sight = dsi + el * K;
+        int64_t taken = 0, j = 0;
+        for (; j < K && taken < k; ++j) {
+            const int64_t m = sight[j];
+            if (m == el) { dsi_new[el * w] = el; continue; }
+            if (m < 0 || m >= n) return fail(VCY_ERR_INVALID, "%s: dsi entry out of range", "balance_knn32");
+            if (groups && groups[m] != groups[el]) continue;
+            if (l[m] >= maxl) continue;
+            ++taken;
+            dsi_new[el * w + taken] = m;
+            pos_new[el * w + taken] = (int32_t)j;
+            ++l[m];
+        }
+        for (; taken < k;) {   // sight exhausted: padded with el itself (distance dist[el, 0], neighbors.py:65-69) - pos stays -1
+            ++taken;
+            dsi_new[el * w + taken] = el;
+        }
+    }
+    return VCY_OK;
+}

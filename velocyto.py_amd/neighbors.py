@@ -90,6 +90,16 @@ class BalancedKNN:
     def n_samples(self) -> int:
         return self.data.shape[0]
 
+    def __getattr__(self, name):
+        # `dsi` / `dist`: the reference keeps the full sight lists as host arrays (neighbors.py:282-283); here they stay on the
+        # device and become numpy arrays only if somebody reads them
+        if name in ("dsi", "dist") and "_lists_dev" in self.__dict__:
+            idx, dist = self.__dict__["_lists_dev"]
+            val = idx.cpu().numpy().astype(np.int64) if name == "dsi" else dist.cpu().numpy()
+            self.__dict__[name] = val
+            return val
+        raise AttributeError(name)
+
     def fit(self, data: np.ndarray, sight_k: int = None) -> Any:
         """neighbors.py:226-244 (the search itself runs in kneighbors; there is no index to build)."""
         self.data = data
@@ -116,7 +126,23 @@ class BalancedKNN:
             if corr:
                 self.dist = self.dist * self.dist / 2.0
         else:
-            self.dist, self.dsi = _kneighbors(self.fitdata, sight, self.metric, include_self=True)
+            # the fitted points are their own queries (the path knn_imputation takes; its default sight is the WHOLE dataset,
+            # analysis.py:985-988): the (C, sight) lists stay on the device, the greedy loop reads an int32 host copy of the
+            # indices only, the distances of the selected entries are gathered on the device (ops.balance_knn_device_lists) -
+            # 10 GB of host memory at 50 000 cells where int64 + fp64 host lists would take 40 GB
+            Xs, corr = _search_space(self.fitdata, self.metric)
+            idx, dist = ops.knn_search(Xs, sight, include_self=True)
+            if corr:
+                dist = dist * dist / 2.0
+            self._lists_dev = (idx, dist)
+            self.__dict__.pop("dsi", None); self.__dict__.pop("dist", None)
+            logging.debug(f"Using the initialization network to find a {self.k}-NN graph with maximum connectivity of {self.maxl}")
+            groups = None if self.constraint is None else np.asarray(self.constraint).astype("int64")
+            self.dist_new, self.dsi_new, self.l = ops.balance_knn_device_lists(idx, dist, self.maxl, self.k, groups)
+            if mode == "connectivity":
+                self.dist = np.ones((idx.shape[0], idx.shape[1]), dtype=np.int64)
+                self.dist[:, 0] = 0
+            return self.dist_new, self.dsi_new, self.l
         logging.debug(f"Using the initialization network to find a {self.k}-NN graph with maximum connectivity of {self.maxl}")
         self.dist_new, self.dsi_new, self.l = knn_balance(self.dsi, self.dist, maxl=self.maxl, k=self.k, constraint=self.constraint)
         if mode == "connectivity":

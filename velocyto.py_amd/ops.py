@@ -990,6 +990,35 @@ def balance_knn_host(dsi: np.ndarray, dist: Optional[np.ndarray], lsi: np.ndarra
     return dist_new, dsi_new, l
 
 
+def balance_knn_device_lists(idx: torch.Tensor, dist: torch.Tensor, maxl: int, k: int, groups: Optional[np.ndarray] = None
+                             ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """knn_balance (neighbors.py:143-183) on sight lists that STAY where the search left them: `idx` (C, K) int32 and `dist`
+    (C, K) fp64 device tensors.  The in-degree count and the processing order are device reductions, the sequential loop reads
+    an int32 host copy of `idx` only (vcy_balance_knn_host32) and the distances of the k + 1 selected entries are gathered on
+    the device: host memory C * K * 4 bytes instead of the reference's C * K * 16 (its default sight is the whole dataset).
+    Returns (dist_new, dsi_new, l) exactly as balance_knn_host does."""
+    C, K = idx.shape
+    if K < k:
+        raise AssertionError("sight needs to be bigger than k")
+    l0 = torch.bincount(idx.reshape(-1).long(), minlength=C)
+    # np.argsort(l, kind="mergesort")[::-1]: stable ascending, reversed (ties come out by DEscending cell number)
+    lsi = torch.flip(torch.sort(l0, stable=True).indices, [0]).cpu().numpy().astype(np.int64)
+    host = idx.cpu().numpy()                                   # int32, the only big host array
+    g = None if groups is None else np.ascontiguousarray(groups, dtype=np.int64)
+    pos = np.empty((C, k + 1), dtype=np.int32)
+    dsi_new = np.empty((C, k + 1), dtype=np.int64)
+    l = np.empty(C, dtype=np.int64)
+    _lib.check(_lib.lib().vcy_balance_knn_host32(host.ctypes.data, lsi.ctypes.data, None if g is None else g.ctypes.data, C, K, int(maxl), int(k),
+                                                 pos.ctypes.data, dsi_new.ctypes.data, l.ctypes.data), "balance_knn32")
+    del host
+    pd = torch.from_numpy(pos).to(idx.device).long()
+    got = torch.gather(dist, 1, pd.clamp(min=0))
+    pad = torch.from_numpy(dsi_new == np.arange(C)[:, None]).to(idx.device) & (pd < 0)     # padded slots carry dist[el, 0] (neighbors.py:65-69)
+    got = torch.where(pd >= 0, got, torch.where(pad, dist[:, :1].expand_as(got), torch.zeros_like(got)))
+    got[:, 0] = 0.0                                            # column 0 is never written by the loop (stays at its initial 0)
+    return got.cpu().numpy(), dsi_new, l
+
+
 def choice_stream_host(n: int, size: int, p: np.ndarray, cells: int, block: int = 4096, pool_factor: float = 1.5) -> np.ndarray:
     """``np.stack([np.random.choice(n, size=size, replace=False, p=p) for _ in range(cells)])`` - the neighbour sampling of
     estimate_transition_prob (analysis.py:1561-1564) - with the same draws from numpy's global legacy RNG and the same RNG
