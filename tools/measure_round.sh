@@ -1,0 +1,19 @@
+#!/bin/bash
+# On the GPU box: everything the round's documents quote besides the rocprofv3 passes (tools/profile_round.sh <tag> runs first):
+# the 8-rank rehearsal on one device, the cfg5 lines, stage D on shard shapes / wide lists / with the randomised control, the shard model.
+# Usage: tools/measure_round.sh <tag>   -> gpurun_out/<tag>_*
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+T=$1
+cd $R
+VCY_SINGLE_DEVICE=1 VCY_DIST_BACKEND=gloo python bench.py --gpus 8 --no-cpu-baseline --no-extra --steps 2 --warmup 1 2> gpurun_out/${T}_8ranks.err | tail -1 > gpurun_out/${T}_bench_8ranks_one_device_line.json
+python bench.py --workload cfg5 --cells 200000 --no-cpu-baseline --steps 2 --warmup 1 2> gpurun_out/${T}_cfg5_200k.err | tail -1 > gpurun_out/${T}_bench_cfg5_200k_line.json
+python bench.py --workload cfg5 --cells 1000000 --no-cpu-baseline --steps 2 --warmup 1 2> gpurun_out/${T}_cfg5_1M.err | tail -1 > gpurun_out/${T}_bench_cfg5_1M_line.json
+python tools/bench_shapes.py > gpurun_out/${T}_stage_d_shapes.txt 2>&1
+python tools/bench_dual.py > gpurun_out/${T}_stage_d_dual.txt 2>&1
+LITERAL=1 python tools/bench_dual.py >> gpurun_out/${T}_stage_d_dual.txt 2>&1
+python tools/shard_model.py > gpurun_out/${T}_shard_model.json 2> gpurun_out/${T}_shard_model.err
+C=50000 G=30000 PRE=0 python tools/run_facade.py > gpurun_out/${T}_facade_50k.txt 2>&1
+for f in gpurun_out/${T}_bench_8ranks_one_device_line.json gpurun_out/${T}_bench_cfg5_200k_line.json gpurun_out/${T}_bench_cfg5_1M_line.json; do cut -c1-250 $f; echo; done
+cat gpurun_out/${T}_stage_d_shapes.txt gpurun_out/${T}_stage_d_dual.txt | grep -v amdgpu.ids
+tail -25 gpurun_out/${T}_facade_50k.txt
