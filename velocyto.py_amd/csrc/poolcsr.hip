@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64 * CSR_WAVES) void k_knn_pool_csr(const int64_t *
                                                                   const double *__restrict__ scale, T *__restrict__ out,
                                                                   const int64_t *__restrict__ g_indptr, const int32_t *__restrict__ g_indices,
                                                                   const T *__restrict__ w, const int32_t *__restrict__ order, int G, int64_t ld_out,
-                                                                  int64_t cell0, int C_out, int nslab, int nsplit, int maximum)
+                                                                  int64_t cell0, int C_out, int nslab, int nsplit, int maximum, int64_t C_rows)
 {
     using V = typename Vec<T>::type;
     constexpr int N = Vec<T>::N;
@@ -73,6 +73,7 @@ __global__ __launch_bounds__(64 * CSR_WAVES) void k_knn_pool_csr(const int64_t *
     const int sper = (nslab + nsplit - 1) / nsplit, s0 = split * sper, s1 = min(nslab, s0 + sper);
     const int64_t p0 = g_indptr[cl], p1 = g_indptr[cl + 1];
     const int64_t own = cell0 + cl;
+    const int64_t nnz_total = indptr[C_rows];                  // (the 16-byte loads below never read past it)
 
     for (int64_t pb = p0; pb < p1 || pb == p0; pb += 64) {     // batches of 64 graph entries (one batch for any kNN graph)
         const bool first = pb == p0, last = pb + 64 >= p1;
@@ -112,33 +113,60 @@ __global__ __launch_bounds__(64 * CSR_WAVES) void k_knn_pool_csr(const int64_t *
                     if (v < nv) reinterpret_cast<V *>(slab)[v] = reinterpret_cast<const V *>(orow)[v];
                 }
             }
+            // The non-zeros of CSR_ROWS rows are requested together and applied row by row.  Lane t takes the FOUR CONSECUTIVE
+            // non-zeros 4 t .. 4 t + 3 of a row's segment: ONE 16-byte load of the gene numbers and one load of the counts per row
+            // and lane (8 -> 2 vector-memory instructions per row).  The request phase is nothing but loads - no arithmetic on what
+            // they return, no branch on it - so that the compiler waits for none of them before the last has been issued (a
+            // conditional element-wise tail path made it wait per row: one round trip per row, whatever CSR_ROWS was).  The quad
+            // that would run past the end of a segment is shifted back to END with the segment (and, at the very end of the
+            // arrays, inside them); the merge phase applies only the elements 4 t <= e < n it owns.
+            static_assert(CSR_NZ == 4, "a lane owns one quad of consecutive non-zeros");
+            constexpr int XW = (int)sizeof(CT);                  // dwords holding a lane's four counts (uint8: 1, uint16: 2)
             for (int u0 = 0; u0 < cnt; u0 += CSR_ROWS) {
-                int g[CSR_ROWS][CSR_NZ];
-                CT x[CSR_ROWS][CSR_NZ];
+                int gq[CSR_ROWS][4];
+                unsigned xw[CSR_ROWS][XW];
                 T ws[CSR_ROWS];
                 int64_t a[CSR_ROWS];
-                int n[CSR_ROWS];
+                int n[CSR_ROWS], sh[CSR_ROWS];
+                const int t4 = 4 * lane;
 #pragma unroll
                 for (int r = 0; r < CSR_ROWS; ++r) {
                     const int u = min(u0 + r, cnt - 1);
                     a[r] = ((int64_t)__builtin_amdgcn_readlane((int)(a_l >> 32), u) << 32) | (unsigned)__builtin_amdgcn_readlane((int)a_l, u);
                     n[r] = (u0 + r < cnt) ? __builtin_amdgcn_readlane(n_l, u) : 0;
                     ws[r] = readlane_t(ws_l, u);
-#pragma unroll
-                    for (int q = 0; q < CSR_NZ; ++q) {
-                        const int t = lane + 64 * q;
-                        g[r][q] = -1;
-                        if (t < n[r]) { g[r][q] = indices[a[r] + t] - g0; x[r][q] = data[a[r] + t]; }
+                    // first element of the lane's quad, relative to a[r]: 4 t, pulled back so that the quad ends inside the arrays
+                    int s4 = min(t4, max(n[r] - 4, 0));
+                    s4 = (int)min((int64_t)s4, nnz_total - 4 - a[r]);
+                    sh[r] = s4;
+                    if (t4 < n[r]) {
+                        __builtin_memcpy(gq[r], indices + a[r] + s4, 16);
+                        __builtin_memcpy(xw[r], data + a[r] + s4, 4 * sizeof(CT));
                     }
                 }
 #pragma unroll
                 for (int r = 0; r < CSR_ROWS; ++r) {
+                    // the four non-zeros of a lane (and of all lanes) of ONE row are distinct genes: their read-modify-writes do not
+                    // alias, so the four reads go out together, then the four updates (LDS executes a wave's operations in order: the
+                    // next row's reads see these writes)
+                    bool ok[4];
+                    int gg[4];
+                    T cur[4];
 #pragma unroll
-                    for (int q = 0; q < CSR_NZ; ++q)
-                        if (g[r][q] >= 0) slab[g[r][q]] = fma(ws[r], (T)x[r][q], slab[g[r][q]]);
+                    for (int q = 0; q < 4; ++q) {
+                        const int el = sh[r] + q;                // element of the segment this quad position holds
+                        ok[q] = t4 < n[r] && el >= t4 && el < n[r];
+                        gg[q] = ok[q] ? gq[r][q] - g0 : 0;
+                        cur[q] = slab[gg[q]];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned cv = sizeof(CT) == 1 ? (xw[r][0] >> (8 * q)) & 0xffu : (xw[r][q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                        if (ok[q]) slab[gg[q]] = fma(ws[r], (T)cv, cur[q]);
+                    }
                     for (int t = 64 * CSR_NZ + lane; t < n[r]; t += 64) {       // segments longer than 256 non-zeros (dense rows)
-                        const int gg = indices[a[r] + t] - g0;
-                        slab[gg] = fma(ws[r], (T)data[a[r] + t], slab[gg]);
+                        const int g2 = indices[a[r] + t] - g0;
+                        slab[g2] = fma(ws[r], (T)data[a[r] + t], slab[g2]);
                     }
                 }
             }
@@ -202,7 +230,7 @@ extern "C" int vcy_knn_pool_csr(const int64_t *indptr, const int32_t *indices, c
     hipStream_t st = as_stream(stream);
 #define VCY_POOLCSR(T, CT)                                                                                                                          \
     hipLaunchKernelGGL((k_knn_pool_csr<T, CT>), dim3((unsigned)blocks), dim3(64 * CSR_WAVES), 0, st, indptr, indices, (const CT *)data, slabptr, scale, \
-                       (T *)out, g_indptr, g_indices, (const T *)w, order, (int)G, ld_out, cell0, (int)C_out, (int)nslab, (int)nsplit, maximum)
+                       (T *)out, g_indptr, g_indices, (const T *)w, order, (int)G, ld_out, cell0, (int)C_out, (int)nslab, (int)nsplit, maximum, C)
     if (dtype == VCY_F32) { if (count_dtype == VCY_U16) VCY_POOLCSR(float, uint16_t); else VCY_POOLCSR(float, uint8_t); }
     else { if (count_dtype == VCY_U16) VCY_POOLCSR(double, uint16_t); else VCY_POOLCSR(double, uint8_t); }
 #undef VCY_POOLCSR
