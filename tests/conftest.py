@@ -33,3 +33,16 @@ def oracle():
     import oracle as _oracle  # oracle/oracle.py - the CPU checker (test infrastructure)
     _oracle.build()
     return _oracle
+
+
+@pytest.fixture(autouse=True)
+def _release_device_memory():
+    """After every test: drop what the caching allocator still holds.  The suite runs in ONE process and some tests need most of the
+    device (cfg5 at 1M cells peaks at 136 GB, the 8-rank rehearsal starts eight more processes on the same GPU): memory cached by an
+    earlier test must not starve a later one or the subprocesses it launches."""
+    yield
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available():
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
