@@ -191,6 +191,24 @@ def test_fullsize_stage_d_256_cells_against_the_oracle(world, oracle):
     assert worst["production"] <= 5e-5 and worst["literal"] <= 5e-5, worst
 
 
+def test_default_sight_balanced_knn_at_50k_cells(world):
+    """knn_imputation(balanced=True) with the reference's DEFAULT sight at the headline size (analysis.py:985-988: b_sight = b_maxl =
+    N - 1, i.e. (50 000 x 50 000) sight lists): the lists stay on the device (10 GB int32 + 20 GB fp64), the greedy loop reads an
+    int32 host copy (vcy_balance_knn_host32), 4 s in all - int64 + fp64 host lists would be 40 GB.  With maxl = N - 1 the in-degree cap
+    can never bind, so the balanced graph must BE the plain 30-NN graph (a size-independent property), self in column 0."""
+    import velocyto_amd
+    w, ops = world, world["ops"]
+    P = w["pcs"].cpu().numpy()
+    bk = velocyto_amd.neighbors.BalancedKNN(k=K, sight_k=C - 1, maxl=C - 1, n_jobs=4).fit(P)
+    d_new, dsi_new, l = bk.kneighbors()
+    idx, dist = ops.knn_search(P, K)
+    assert dsi_new.shape == (C, K + 1) and np.array_equal(dsi_new[:, 0], np.arange(C))
+    assert np.array_equal(dsi_new[:, 1:], idx.cpu().numpy())
+    np.testing.assert_array_equal(d_new[:, 1:], dist.cpu().numpy())
+    assert np.array_equal(l, np.bincount(idx.cpu().numpy().ravel(), minlength=C)) and l.max() < C - 1
+    del bk
+
+
 def test_fullsize_markov_chain_factored_vs_dense(world):
     """prepare_markov / run_markov at 50 000 cells: the factored chain (no (n, n) matrix) against the dense matrix it stands for
     (10 GB in f32, streamed by k_vecmat_dense_vec), plus what must hold at any size: every iterate is a probability vector
