@@ -438,6 +438,36 @@ def test_gene_quantiles(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_gene_quantiles_every_register_variant(ops, dtype):
+    """The selection with the gene's keys in registers (fit.hip k_gene_quantiles_reg, one instantiation per band of cell counts) and
+    the row-re-reading kernel above 65 536 (f32) / 32 768 (f64) cells: exact order statistics with numpy's interpolation, plain and
+    restricted to the cells above / at-or-below a per-gene threshold of a second matrix."""
+    rng = np.random.default_rng(91)
+    G = 5
+    for C in (1025, 8192, 9000, 20000, 24577, 33000, 49153, 50000, 57345, 65536, 70001):
+        a = rng.gamma(1.0, 2.0, (G, C)) * (rng.random((G, C)) < 0.6)
+        a[1] = -a[1]
+        a[2] = np.round(a[2])                                              # heavy ties
+        m = ops.CellMatrix.from_genes_major(a, dtype)
+        stored = m.to_genes_major()
+        qs = [0, 2, 37.5, 98, 99.99, 100]
+        got = ops.gene_quantiles(m, qs).cpu().numpy()
+        np.testing.assert_allclose(got, np.percentile(stored, qs, axis=1), rtol=1e-14, atol=0)
+        src = rng.random((G, C))
+        thr = np.array([0.5, 0.9, 0.001, 2.0, -1.0])                       # gene 3: no cell above; gene 4: every cell above
+        msrc = ops.CellMatrix.from_genes_major(src, dtype)
+        sst = msrc.to_genes_major()
+        for mode in (1, 2):
+            got = ops.gene_quantiles(m, [2, 98], mask_src=msrc, mask_thr=torch.from_numpy(thr).cuda(), mask_mode=mode).cpu().numpy()
+            for g in range(G):
+                sel = sst[g] > thr[g] if mode == 1 else sst[g] <= thr[g]
+                if sel.any():
+                    np.testing.assert_allclose(got[:, g], np.percentile(stored[g][sel], [2, 98]), rtol=1e-14, atol=0)
+                else:
+                    assert np.isnan(got[:, g]).all()
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_fit_weighted_vs_oracle_exact(ops, oracle, golden, dtype):
     g = golden("fits")
     rt = 1e-9 if dtype == "float64" else 2e-5

@@ -276,6 +276,30 @@ template <> struct Key<double> {
     static __device__ __forceinline__ double dec(U u) { u = (u >> 63) ? (u & 0x7fffffffffffffffull) : ~u; return __longlong_as_double((long long)u); }
 };
 
+// One histogram increment per matching lane.  Expression rows are mostly exact zeros and a row's values share a few exponents, so the
+// lanes of a wave mostly ask for the SAME bin - and LDS atomics on one address serialise, 64 deep when a whole wave holds zeros (the 2nd
+// percentile of a 60 %-zero matrix cost twice the 98th).  The lanes that share the first matching lane's digit are therefore folded
+// into one atomic carrying their count (VCY_QPEEL rounds of it); only the lanes left over add one each.
+#ifndef VCY_QPEEL
+#define VCY_QPEEL 1
+#endif
+__device__ __forceinline__ void hist_add(unsigned *hist, unsigned bin, bool match)
+{
+    const int lane = (int)(threadIdx.x & 63);
+#pragma unroll
+    for (int round = 0; round < VCY_QPEEL; ++round) {
+        const unsigned long long m = __ballot(match);
+        if (m == 0) return;
+        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+        const unsigned lead_bin = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
+        const bool same = match && bin == lead_bin;
+        const unsigned long long ms = __ballot(same);
+        if (lane == leader) atomicAdd(&hist[lead_bin], (unsigned)__popcll(ms));
+        match = match && !same;
+    }
+    if (match) atomicAdd(&hist[bin], 1u);
+}
+
 // Step 2: one workgroup per gene: MSB-first 8-bit radix select of rank `r` over the gene's C keys
 // (sizeof(key) passes, 256-bin LDS histogram; the row is L2-resident after the first pass), then one
 // more pass for the next order statistic (count <= v, min > v).  numpy.percentile's default
@@ -320,7 +344,7 @@ __global__ __launch_bounds__(256) void k_gene_quantiles(const T *__restrict__ Z,
             for (int c = tid; c < C; c += 256) {
                 const U k = Key<T>::enc(row[c]);
                 const bool match = (pass == 0) || ((k >> ((shift + 8) & (8 * PASSES - 1))) == (prefix >> ((shift + 8) & (8 * PASSES - 1))));
-                if (match) atomicAdd(&hist[(unsigned)((k >> shift) & 0xff)], 1u);
+                hist_add(hist, (unsigned)((k >> shift) & 0xff), match);
             }
             __syncthreads();
             if (tid < 64) {   // one wave scans the 256 bins: 4 bins per lane
@@ -355,6 +379,150 @@ __global__ __launch_bounds__(256) void k_gene_quantiles(const T *__restrict__ Z,
         unsigned long long mg = ~0ull;
         for (int c = tid; c < C; c += 256) {
             const U k = Key<T>::enc(row[c]);
+            if (k <= prefix) ++cnt;
+            else if ((unsigned long long)k < mg) mg = (unsigned long long)k;
+        }
+        cnt = wave_sum(cnt);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(mg, off, 64);
+            mg = o < mg ? o : mg;
+        }
+        if ((tid & 63) == 0) { atomicAdd(&s_cnt_le, cnt); atomicMin(&s_min_gt, mg); }
+        __syncthreads();
+        if (tid == 0) {
+#pragma clang fp contract(off)   // hipcc would fuse the mul/add below even through the *_rn intrinsics
+            T vhi = vlo;
+            if (lo + 1 < nvalid && s_cnt_le < (unsigned)(lo + 2)) vhi = Key<T>::dec((U)s_min_gt);
+            // numpy _lerp, without fma contraction so the rounding matches numpy's mul-then-add
+            const double a = (double)vlo, b = (double)vhi, diff = __dsub_rn(b, a);
+            double r = __dadd_rn(a, __dmul_rn(diff, t));
+            if (t >= 0.5) r = __dsub_rn(b, __dmul_rn(diff, __dsub_rn(1.0, t)));
+            if (t == 0.0) r = a;
+            out[(int64_t)qi * G + g] = r;
+        }
+        __syncthreads();
+    }
+}
+
+// Step 2, register-resident (round 3): the same selection with the gene's C keys held in the REGISTERS of a 1024-thread workgroup
+// (NPT keys per thread, C <= 1024 NPT).  k_gene_quantiles re-reads the 200 KB row of a gene from memory on every radix pass - ten
+// passes for two percentiles, and 2048 co-resident rows are 400 MB, far beyond L2: 60 GB of re-reads for a 6 GB matrix, 17 ms at
+// 50 000 x 30 000.  Here the row is read ONCE (coalesced: thread t takes elements t, t + 1024, ...), every pass walks registers;
+// histograms, scans and the interpolation are the ones of k_gene_quantiles, so the results are the same to the bit.
+template <typename T, int NPT>
+__global__ __launch_bounds__(1024) void k_gene_quantiles_reg(const T *__restrict__ Z, QArgs qa, int nq,
+                                                              double *__restrict__ out, int C, int G, int masked)
+{
+    using U = typename Key<T>::U;
+    constexpr int PASSES = sizeof(U);
+    constexpr U KMAX = ~(U)0;                                // padding key: sorts last, never reaches a rank < nvalid
+    constexpr int COPIES = 32, CSTRIDE = 257;                // lane l counts in copy l % 32; copy c starts at bank c, so equal digits of
+    __shared__ unsigned hcopy[COPIES * CSTRIDE];             // different lanes fall in different banks (two lanes per word at worst)
+    __shared__ unsigned hist[256];                           // the copies folded
+    __shared__ unsigned hist0[256];                          // ... of the first digit: the same for every percentile
+    __shared__ U s_prefix;
+    __shared__ unsigned s_rank;
+    __shared__ unsigned s_cnt_le;
+    __shared__ unsigned long long s_min_gt;
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const T *row = Z + (int64_t)g * C;
+    U key[NPT];
+    unsigned nfin = 0;
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        // branch-free (a load inside a branch makes hipcc wait for it inside the branch: NPT serialised round trips)
+        const int c = tid + 1024 * i;
+        const T v = row[c < C ? c : C - 1];
+        key[i] = c < C ? Key<T>::enc(v) : KMAX;
+        nfin += (c < C && v < (T)INFINITY) ? 1u : 0u;
+    }
+    for (int i = tid; i < COPIES * CSTRIDE; i += 1024) hcopy[i] = 0;
+    if (tid < 256) hist[tid] = 0;
+    if (tid == 0) s_cnt_le = 0;
+    __syncthreads();
+    int nvalid = C;
+    if (masked) {   // entries removed by the mask were stored as +inf
+        const unsigned cnt = wave_sum(nfin);
+        if ((tid & 63) == 0) atomicAdd(&s_cnt_le, cnt);
+        __syncthreads();
+        nvalid = (int)s_cnt_le;
+        __syncthreads();
+    }
+    unsigned *mine = hcopy + (tid & (COPIES - 1)) * CSTRIDE;
+    for (int qi = 0; qi < nq; ++qi) {
+        if (nvalid == 0) { if (tid == 0) out[(int64_t)qi * G + g] = NAN; continue; }
+        const double h = __dmul_rn((double)(nvalid - 1), qa.q[qi] / 100.0);   // numpy: (n-1) * (q/100)
+        const int lo = (int)floor(h);
+        const double t = h - lo;
+        U prefix = 0;
+        unsigned rank = (unsigned)lo;
+        // (the pass loop stays rolled: unrolled, hipcc hoists every key's digit of every pass out of the percentile loop -
+        // PASSES x NPT more live registers, kilobytes of scratch)
+#pragma unroll 1
+        for (int pass = 0; pass < PASSES; ++pass) {
+            const int shift = 8 * (PASSES - 1 - pass);
+            const bool counted = pass == 0 && qi > 0;      // the first digit's histogram is kept from the first percentile
+            if (!counted) {
+#pragma unroll
+                for (int i = 0; i < NPT; ++i) {
+                    // (padding keys are counted too: they sit above every real key, and the rank looked for is below the real count)
+                    const U k = key[i];
+                    const bool match = (pass == 0) || ((k >> ((shift + 8) & (8 * PASSES - 1))) == (prefix >> ((shift + 8) & (8 * PASSES - 1))));
+                    if (match) atomicAdd(&mine[(unsigned)((k >> shift) & 0xff)], 1u);
+                }
+                __syncthreads();
+                {   // fold the copies (and leave them zero for the next pass): thread = (bin, quarter of the copies)
+                    const int bin = tid & 255, part = tid >> 8;
+                    unsigned sum = 0;
+#pragma unroll
+                    for (int c = 0; c < COPIES / 4; ++c) {
+                        unsigned *w = hcopy + (part * (COPIES / 4) + c) * CSTRIDE + bin;
+                        sum += *w;
+                        *w = 0;
+                    }
+                    if (sum) atomicAdd(&hist[bin], sum);
+                }
+                __syncthreads();
+            }
+            if (tid < 64) {   // one wave scans the 256 bins: 4 bins per lane
+                const unsigned *hsrc = counted ? hist0 : hist;
+                unsigned h0 = hsrc[tid * 4], h1 = hsrc[tid * 4 + 1], h2 = hsrc[tid * 4 + 2], h3 = hsrc[tid * 4 + 3];
+                if (!counted) {
+                    if (pass == 0) { hist0[tid * 4] = h0; hist0[tid * 4 + 1] = h1; hist0[tid * 4 + 2] = h2; hist0[tid * 4 + 3] = h3; }
+                    hist[tid * 4] = 0; hist[tid * 4 + 1] = 0; hist[tid * 4 + 2] = 0; hist[tid * 4 + 3] = 0;
+                }
+                unsigned tot = h0 + h1 + h2 + h3, incl = tot;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    unsigned o = __shfl_up(incl, off, 64);
+                    if (tid >= off) incl += o;
+                }
+                const unsigned excl = incl - tot;
+                if (rank >= excl && rank < incl) {   // exactly one lane
+                    unsigned r = rank - excl;
+                    int d;
+                    if (r < h0) d = 0;
+                    else if ((r -= h0) < h1) d = 1;
+                    else if ((r -= h1) < h2) d = 2;
+                    else { r -= h2; d = 3; }
+                    s_prefix = prefix | ((U)(tid * 4 + d) << shift);
+                    s_rank = r;
+                }
+            }
+            __syncthreads();
+            prefix = s_prefix;
+            rank = s_rank;
+        }
+        const T vlo = Key<T>::dec(prefix);
+        // next order statistic
+        if (tid == 0) { s_cnt_le = 0; s_min_gt = ~0ull; }
+        __syncthreads();
+        unsigned cnt = 0;
+        unsigned long long mg = ~0ull;
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const U k = key[i];   // a padding key can only be counted when the answer is NaN anyway, or be the minimum when it is not used
             if (k <= prefix) ++cnt;
             else if ((unsigned long long)k < mg) mg = (unsigned long long)k;
         }
@@ -508,11 +676,24 @@ extern "C" int vcy_gene_quantiles(const void *M, const void *M2, const double *s
     if (dtype == VCY_F32) {
         hipLaunchKernelGGL(k_build_z<float>, gridz, dim3(256), 0, st, (const float *)M, (const float *)M2, scale_a, scale_b, (const float *)mask_src, mask_thr, mask_mode, (float *)Z, (int)C, (int)G, ld);
         VCY_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_gene_quantiles<float>, dim3((unsigned)G), dim3(256), 0, st, (const float *)Z, qs_dev, nq, out, (int)C, (int)G, mask_mode != 0);
+        // the gene's keys in the registers of 1024 threads when they fit (C <= 65 536 in f32), else the row is re-read per pass
+        const bool reg = env_int("VCY_QUANTILES_REG", 1) == 1;
+#define VCY_QREG(TT, NPT) hipLaunchKernelGGL((k_gene_quantiles_reg<TT, NPT>), dim3((unsigned)G), dim3(1024), 0, st, (const TT *)Z, qs_dev, nq, out, (int)C, (int)G, mask_mode != 0)
+        if (reg && C <= 1024 * 16) VCY_QREG(float, 16);
+        else if (reg && C <= 1024 * 32) VCY_QREG(float, 32);
+        else if (reg && C <= 1024 * 48) VCY_QREG(float, 48);
+        else if (reg && C <= 1024 * 56) VCY_QREG(float, 56);
+        else if (reg && C <= 1024 * 64) VCY_QREG(float, 64);
+        else hipLaunchKernelGGL(k_gene_quantiles<float>, dim3((unsigned)G), dim3(256), 0, st, (const float *)Z, qs_dev, nq, out, (int)C, (int)G, mask_mode != 0);
     } else {
         hipLaunchKernelGGL(k_build_z<double>, gridz, dim3(256), 0, st, (const double *)M, (const double *)M2, scale_a, scale_b, (const double *)mask_src, mask_thr, mask_mode, (double *)Z, (int)C, (int)G, ld);
         VCY_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_gene_quantiles<double>, dim3((unsigned)G), dim3(256), 0, st, (const double *)Z, qs_dev, nq, out, (int)C, (int)G, mask_mode != 0);
+        const bool reg = env_int("VCY_QUANTILES_REG", 1) == 1;          // f64 keys take two registers each: up to 32 768 cells
+        if (reg && C <= 1024 * 8) VCY_QREG(double, 8);
+        else if (reg && C <= 1024 * 16) VCY_QREG(double, 16);
+        else if (reg && C <= 1024 * 24) VCY_QREG(double, 24);
+        else if (reg && C <= 1024 * 32) VCY_QREG(double, 32);
+        else hipLaunchKernelGGL(k_gene_quantiles<double>, dim3((unsigned)G), dim3(256), 0, st, (const double *)Z, qs_dev, nq, out, (int)C, (int)G, mask_mode != 0);
     }
     VCY_LAUNCH_CHECK();
     return VCY_OK;
