@@ -347,6 +347,11 @@ int vcy_scale_log(const void *M, const double *factor, void *out_sz, void *out_n
  * 3 logratio: e_out = log2(hi_dim + psc), dmat = log2(|hi_dim_t| + psc) - e_out.          */
 int vcy_delta_transform(const void *hi_dim, const void *delta_S, void *dmat, void *e_out, int64_t C, int64_t G, int64_t ld,
                         double used_dt, int mode, double psc, int dtype, vcy_stream stream);
+/* permute_rows_nsign (analysis.py:2407-2420, called at :1540-1541 for the randomised control): out[c, g] = +- in[pi_g(c), g] with
+ * an independent pseudo-random permutation pi_g of the cells and independent random signs per gene, both functions of (seed, g).
+ * The reference draws them from numba's RNG stream: statistical parity, not the same numbers.  in != out; padding columns of out
+ * are zeroed.                                                                                  */
+int vcy_permute_rows_nsign(const void *in, void *out, int64_t C, int64_t G, int64_t ld, uint64_t seed, int dtype, vcy_stream stream);
 /* np.fill_diagonal(corrcoef, 0) and corrcoef[isnan] = nan_to (analysis.py:1604-1612, 1666-1668) on
  * the compact (C_out, nrndm) form; nan_count (device int, may be NULL) counts the NaNs seen.  */
 int vcy_corr_fixup(void *vals, const int32_t *ixs, int64_t cell0, int64_t C_out, int64_t nrndm, int zero_self, int fix_nan,

@@ -438,6 +438,48 @@ def test_gene_quantiles(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_permute_rows_nsign_is_a_uniform_independent_shuffle_per_gene(ops, dtype):
+    """analysis.py:2407-2420 (numba: np.random.shuffle of every gene's row, then random signs).  The device version evaluates a
+    keyed permutation per gene: every gene's output is a permutation of its input up to signs; permutations are reproducible from
+    the seed, differ between genes and seeds, and behave like uniform draws (where a cell lands, fixed points, no memory of the
+    source position, balanced signs independent of the shuffle)."""
+    rng = np.random.default_rng(4)
+    for C, G in ((1, 3), (2, 70), (17, 70), (1000, 300), (5000, 70)):
+        a = np.stack([rng.permutation(C) + 1.0 for _ in range(G)])          # distinct positive values per gene: the value names its source cell
+        m = ops.CellMatrix.from_genes_major(a, dtype)
+        out = ops.permute_rows_nsign(m, 15071990)
+        assert torch.all(out.t[:, G:] == 0)                                 # padding columns of the layout
+        o = out.to_genes_major()
+        np.testing.assert_array_equal(np.sort(np.abs(o), 1), np.sort(a, 1))
+        np.testing.assert_array_equal(ops.permute_rows_nsign(m, 15071990).to_genes_major(), o)
+        if C >= 17:
+            o2 = ops.permute_rows_nsign(m, 15071991).to_genes_major()
+            assert (np.abs(o2) != np.abs(o)).mean() > 0.8
+            src = np.abs(o) - 1                                             # rank of the value that landed in each cell
+            inv = np.argsort(a, 1)                                          # ... back to its source cell
+            pi = np.take_along_axis(inv, src.astype(np.int64), 1)
+            assert (pi[0] != pi[1]).mean() > 0.8                            # genes are shuffled independently
+            assert (pi == np.arange(C)[None, :]).sum(1).mean() < 3.0        # ~1 fixed point per permutation
+            if C >= 1000:
+                r = np.array([np.corrcoef(pi[g], np.arange(C))[0, 1] for g in range(G)])
+                assert np.abs(r).max() < 6 / np.sqrt(C) and abs(r.mean()) < 4 / np.sqrt(C * G)
+                d = (pi - np.arange(C)[None, :]) % C                        # displacement: uniform over [0, C)
+                h = np.bincount((d.ravel() * 20 // C).astype(np.int64), minlength=20)
+                e = d.size / 20
+                assert ((h - e) ** 2 / e).sum() < 60                        # chi-square, 19 degrees of freedom
+            sg = np.sign(o)
+            assert abs(sg.mean()) < 5 / np.sqrt(sg.size)
+            assert abs(np.corrcoef(sg.ravel()[:-1], sg.ravel()[1:])[0, 1]) < 5 / np.sqrt(sg.size)
+    # where cell 0 comes from, over many genes: uniform over a small population
+    C, G = 50, 20000
+    a = np.tile(np.arange(1.0, C + 1), (G, 1))
+    o = np.abs(ops.permute_rows_nsign(ops.CellMatrix.from_genes_major(a, dtype), 7).to_genes_major())
+    for cell in (0, 49):
+        h = np.bincount(o[:, cell].astype(np.int64) - 1, minlength=C)
+        assert ((h - G / C) ** 2 / (G / C)).sum() < 120                    # chi-square, 49 degrees of freedom
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_gene_quantiles_every_register_variant(ops, dtype):
     """The selection with the gene's keys in registers (fit.hip k_gene_quantiles_reg, one instantiation per band of cell counts) and
     the row-re-reading kernel above 65 536 (f32) / 32 768 (f64) cells: exact order statistics with numpy's interpolation, plain and

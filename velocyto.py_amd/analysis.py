@@ -823,19 +823,9 @@ def _fill_diagonal_zero(m: torch.Tensor) -> None:
 
 
 def _permute_rows_nsign(dS: CellMatrix, seed: int) -> CellMatrix:
-    """analysis.py:2407-2420: per gene, shuffle the values across cells and flip signs at random.
-    RNG plumbing (torch device generator; the reference uses numba's) - statistical parity only."""
-    dev = dS.t.device
-    gen = torch.Generator(device=dev).manual_seed(int(seed))
-    out = torch.zeros_like(dS.t)
-    C, G = dS.C, dS.G
-    blk = max(1, int(2e8 // max(C, 1)))
-    for g0 in range(0, G, blk):
-        g1 = min(G, g0 + blk)
-        perm = torch.argsort(torch.rand((C, g1 - g0), generator=gen, device=dev), dim=0)
-        sign = torch.randint(0, 2, (C, g1 - g0), generator=gen, device=dev, dtype=torch.int8).to(dS.dtype) * 2 - 1
-        out[:, g0:g1] = torch.gather(dS.t[:, g0:g1], 0, perm) * sign
-    return CellMatrix(out, G)
+    """analysis.py:2407-2420: per gene, shuffle the values across cells and flip signs at random (the reference uses numba's RNG
+    stream: statistical parity only).  One gather on the device, ops.permute_rows_nsign."""
+    return ops.permute_rows_nsign(dS, seed)
 
 
 def gaussian_kernel(X: np.ndarray, mu: float = 0, sigma: float = 1) -> np.ndarray:

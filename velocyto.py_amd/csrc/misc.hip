@@ -86,6 +86,55 @@ __global__ __launch_bounds__(256) void k_delta_transform(const T *__restrict__ h
     }
 }
 
+// ---------------------------------------------------------------- randomised control: permute_rows_nsign (analysis.py:2407-2420)
+// Per gene, the values shuffled across the cells and multiplied by random signs.  The reference draws both from numba's private
+// Mersenne twister, gene after gene; here every gene gets its own pseudo-random PERMUTATION of [0, C) as a function that is evaluated
+// where it is needed - a 5-round Feistel network over the 2 * hb >= log2(C) bits of the cell number, keyed by (seed, gene), walked
+// until it lands below C (a permutation of [0, 4^hb) restricted to the cycle-walk over a subset is a permutation of the subset) - so
+// the shuffle is one gather, out[c, g] = +- in[pi_g(c), g], with no sort, no keys in memory and no gene-major copy.  Statistical
+// parity with the reference (uniform, independent per gene), not the same random numbers.
+__device__ __forceinline__ uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+template <typename T, int CPT>
+__global__ __launch_bounds__(256) void k_permute_rows_nsign(const T *__restrict__ in, T *__restrict__ out, int C, int G, int64_t ld,
+                                                             uint32_t seed_lo, uint32_t seed_hi, int hb)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;            // lanes = consecutive genes: coalesced stores, one sector per gathered value
+    if (g >= ld) return;
+    const int c0 = blockIdx.y * CPT;
+    if (g >= G) {                                             // padding columns of the cell-major layout stay zero
+        for (int c = c0; c < min(C, c0 + CPT); ++c) out[(int64_t)c * ld + g] = T(0);
+        return;
+    }
+    const uint32_t key = mix32(seed_lo ^ mix32((uint32_t)g * 0x9e3779b9u + seed_hi));
+    const uint32_t mask = (1u << hb) - 1u;
+    T v[CPT];
+    uint32_t sg[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = min(c0 + i, C - 1);
+        uint32_t x = (uint32_t)c;
+        do {
+            uint32_t L = x >> hb, R = x & mask;
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const uint32_t t = L ^ (mix32(R + key + (uint32_t)r * 0x85ebca6bu) & mask);
+                L = R;
+                R = t;
+            }
+            x = (L << hb) | R;
+        } while (x >= (uint32_t)C);
+        v[i] = in[(int64_t)x * ld + g];
+        sg[i] = mix32(key ^ ((uint32_t)c * 0xc2b2ae35u + 0x27d4eb2fu)) >> 31;
+    }
+#pragma unroll
+    for (int i = 0; i < CPT; ++i)
+        if (c0 + i < C) out[(int64_t)(c0 + i) * ld + g] = sg[i] ? -v[i] : v[i];
+}
+
 // np.fill_diagonal(corrcoef, 0); corrcoef[isnan] = nan_to   (analysis.py:1604-1606) on the compact form
 template <typename T>
 __global__ void k_corr_fixup(T *__restrict__ vals, const int32_t *__restrict__ ixs, int64_t cell0, int64_t total, int nrndm,
@@ -500,6 +549,21 @@ extern "C" int vcy_delta_transform(const void *hi_dim, const void *delta_S, void
     if (dtype == VCY_F32) hipLaunchKernelGGL(k_delta_transform<float>, dim3(blocks), dim3(256), 0, as_stream(stream), (const float *)hi_dim, (const float *)delta_S, (float *)dmat, (float *)e_out, C, (int)G, ld, (float)used_dt, mode, (float)psc);
     else if (dtype == VCY_F64) hipLaunchKernelGGL(k_delta_transform<double>, dim3(blocks), dim3(256), 0, as_stream(stream), (const double *)hi_dim, (const double *)delta_S, (double *)dmat, (double *)e_out, C, (int)G, ld, used_dt, mode, psc);
     else return fail(VCY_ERR_INVALID, "%s: bad dtype", "delta_transform");
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}
+
+extern "C" int vcy_permute_rows_nsign(const void *in, void *out, int64_t C, int64_t G, int64_t ld, uint64_t seed, int dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(in && out && in != out && C > 0 && G > 0 && ld >= G && C < (1ll << 30), "permute_rows_nsign: bad arguments");
+    int hb = 1;
+    while ((1ll << (2 * hb)) < C) ++hb;                      // 4^hb >= C: at most 4 walks per cell on average, 1.3 at 50 000
+    constexpr int CPT = 8;
+    const dim3 grid((unsigned)((ld + 255) / 256), (unsigned)((C + CPT - 1) / CPT));
+    const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+    if (dtype == VCY_F32) hipLaunchKernelGGL((k_permute_rows_nsign<float, CPT>), grid, dim3(256), 0, as_stream(stream), (const float *)in, (float *)out, (int)C, (int)G, ld, lo, hi, hb);
+    else if (dtype == VCY_F64) hipLaunchKernelGGL((k_permute_rows_nsign<double, CPT>), grid, dim3(256), 0, as_stream(stream), (const double *)in, (double *)out, (int)C, (int)G, ld, lo, hi, hb);
+    else return fail(VCY_ERR_INVALID, "%s: bad dtype", "permute_rows_nsign");
     VCY_LAUNCH_CHECK();
     return VCY_OK;
 }

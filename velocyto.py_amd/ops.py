@@ -1271,6 +1271,16 @@ def delta_transform(hi_dim: CellMatrix, delta_S: CellMatrix, used_dt: float, mod
     return dm, eo
 
 
+def permute_rows_nsign(delta_S: CellMatrix, seed: int) -> CellMatrix:
+    """The randomised control's delta_S (analysis.py:2407-2420): per gene, the values shuffled across the cells by an independent
+    pseudo-random permutation and multiplied by independent random signs (vcy_permute_rows_nsign; a function of (seed, gene, cell),
+    statistical parity with the reference's numba stream)."""
+    out = CellMatrix(torch.empty_like(delta_S.t), delta_S.G)
+    _lib.check(_lib.lib().vcy_permute_rows_nsign(delta_S.t.data_ptr(), out.t.data_ptr(), delta_S.C, delta_S.G, delta_S.ld, int(seed) & (2**64 - 1),
+                                                 delta_S.code, _stream()), "permute_rows_nsign")
+    return out
+
+
 def corr_fixup(vals: torch.Tensor, ixs: torch.Tensor, cell0: int = 0, zero_self: bool = True, fix_nan: bool = True,
                nan_to: float = 1.0) -> int:
     """In place: zero the self pairs, NaN -> nan_to; returns the number of NaNs met (host sync)."""
