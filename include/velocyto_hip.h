@@ -156,6 +156,13 @@ int vcy_knn_pool2(const void *data, void *out, const void *data2, void *out2, co
                   const int32_t *indices, const void *w, const int32_t *order, int64_t C, int64_t G, int64_t ld,
                   int64_t cell0, int64_t C_out, int maximum, int64_t slab_genes, int dtype, vcy_stream stream);
 
+/* ONE matrix pooled with TWO weight sets over the same graph, out = data-rows . w, out2 = data-rows . w2: the two
+ * `hi_dim @ (transition_prob - embedding_knn / n).T` products of calculate_embedding_shift (analysis.py:1716 real, :1728
+ * randomised control) share hi_dim and the neighbour lists, so the rows are gathered once.                      */
+int vcy_knn_pool_w2(const void *data, void *out, void *out2, const int64_t *indptr, const int32_t *indices, const void *w,
+                    const void *w2, const int32_t *order, int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out,
+                    int64_t slab_genes, int dtype, vcy_stream stream);
+
 /* Pooling straight from the loom's uint16 count layers (velocyto/constants.py:11): the size-normalised
  * inputs of knn_imputation are norm_factor[c] * counts[c,:] (analysis.py:546-549, 573-579), so
  *     out[c,:] = sum_p (w[p] * scale[indices[p]]) * counts[indices[p],:]

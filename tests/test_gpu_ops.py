@@ -438,6 +438,29 @@ def test_gene_quantiles(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_pool_two_weight_sets_equals_two_poolings(ops, dtype):
+    """vcy_knn_pool_w2 (calculate_embedding_shift's real + control products in one gather) against two vcy_knn_pool launches:
+    the same fma chain per output, so the same bits; ragged rows, an empty row, a cell block, a schedule."""
+    rng = np.random.default_rng(12)
+    C, G = 300, 1003
+    data = ops.CellMatrix.from_genes_major(rng.gamma(1.0, 1.0, (G, C)), dtype)
+    lens = rng.integers(0, 23, C)
+    lens[5] = 0
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    indices = rng.integers(0, C, indptr[-1]).astype(np.int32)
+    w, w2 = rng.normal(size=indptr[-1]), rng.normal(size=indptr[-1])
+    order = torch.from_numpy(rng.permutation(C).astype(np.int32)).cuda()
+    a, b = ops.knn_pool_w2(data, indptr, indices, w, w2, order=order)
+    ra, rb = ops.knn_pool(data, indptr, indices, w), ops.knn_pool(data, indptr, indices, w2)
+    assert torch.equal(a.t, ra.t) and torch.equal(b.t, rb.t)
+    c0, n = 40, 100                                                       # rows of a block of output cells
+    ip = (indptr[c0:c0 + n + 1] - indptr[c0]).astype(np.int64)
+    sl = slice(indptr[c0], indptr[c0 + n])
+    a, b = ops.knn_pool_w2(data, ip, indices[sl], w[sl], w2[sl], cell0=c0, C_out=n)
+    assert torch.equal(a.t, ra.t[c0:c0 + n]) and torch.equal(b.t, rb.t[c0:c0 + n])
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_permute_rows_nsign_is_a_uniform_independent_shuffle_per_gene(ops, dtype):
     """analysis.py:2407-2420 (numba: np.random.shuffle of every gene's row, then random signs).  The device version evaluates a
     keyed permutation per gene: every gene's output is a permutation of its input up to signs; permutations are reproducible from

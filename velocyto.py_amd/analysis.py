@@ -592,27 +592,35 @@ class VelocytoLoom(PreprocessMixin):
         hi = self.dev(self.which_hidim)
         dev = hi.t.device
 
-        def one(corr, dS_name):
+        order = self.__dict__.get("_embed_order") if self.corr_calc == "knn_random" else None
+        n = neigh.shape[1]
+        names = [("_corr", "delta_S")] + ([("_corr_random", "delta_S_rndm")] if "_corr_random" in self.__dict__ else [])
+        parts = []
+        for corr_name, _ in names:
+            corr = self.__dict__[corr_name]
             c = corr if self.corr_calc == "knn_random" else torch.gather(corr, 1, neigh.long())
-            tp, wd, de = ops.transition_prob(c.contiguous(), neigh, self.embedding, sigma_corr)
-            scaling = None
-            if expression_scaling:
-                n = neigh.shape[1]
-                indptr = torch.arange(0, (neigh.shape[0] + 1) * n, n, dtype=torch.int64, device=dev)
-                estim = ops.knn_pool(hi, indptr, neigh.reshape(-1), wd.reshape(-1), validate=False,      # hi_dim @ (P - knn/n).T   (:1716)
-                                     order=self.__dict__.get("_embed_order") if self.corr_calc == "knn_random" else None)
-                cos_proj = ops.row_cosproj(self.dev(dS_name), estim)                                       # :1717
-                scaling = torch.clamp(cos_proj / scaling_penalty, 0, 1)                                    # NaN stays NaN, like np.clip
-                de = de * scaling[:, None]
-            return tp, de, scaling
+            parts.append(ops.transition_prob(c.contiguous(), neigh, self.embedding, sigma_corr))       # (tp, P - knn/n, delta_embedding)
+        scalings = [None] * len(names)
+        if expression_scaling:
+            # hi_dim @ (P - knn/n).T (:1716, and :1728 for the control): both products gather the same rows of hi_dim
+            indptr = torch.arange(0, (neigh.shape[0] + 1) * n, n, dtype=torch.int64, device=dev)
+            if len(names) == 2:
+                estims = ops.knn_pool_w2(hi, indptr, neigh.reshape(-1), parts[0][1].reshape(-1), parts[1][1].reshape(-1), validate=False, order=order)
+            else:
+                estims = (ops.knn_pool(hi, indptr, neigh.reshape(-1), parts[0][1].reshape(-1), validate=False, order=order),)
+            for i, (_, dS_name) in enumerate(names):
+                cos_proj = ops.row_cosproj(self.dev(dS_name), estims[i])                                 # :1717
+                scalings[i] = torch.clamp(cos_proj / scaling_penalty, 0, 1)                              # NaN stays NaN, like np.clip
+            del estims
+        res = [(tp, de if sc is None else de * sc[:, None], sc) for (tp, _, de), sc in zip(parts, scalings)]
 
-        tp, de, sc = one(self._corr, "delta_S")
+        tp, de, sc = res[0]
         self._tp, self._tp_ixs = tp, neigh
         self.delta_embedding = de.cpu().numpy()
         if sc is not None:
             self.scaling = sc.cpu().numpy()
-        if "_corr_random" in self.__dict__:
-            tp, de, sc = one(self._corr_random, "delta_S_rndm")
+        if len(res) == 2:
+            tp, de, sc = res[1]
             self._tp_random = tp
             self.delta_embedding_random = de.cpu().numpy()
             if sc is not None:

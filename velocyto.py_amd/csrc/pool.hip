@@ -14,13 +14,17 @@
 
 namespace vcy {
 
-template <typename T, bool DUAL>
+// DUAL: a second matrix pooled with the same weights (data2 -> out2).  W2: ONE matrix pooled with two weight sets over the same
+// graph (w -> out, w2 -> out2; calculate_embedding_shift's real and randomised transition probabilities, analysis.py:1716, 1728):
+// the rows are gathered once.
+template <typename T, bool DUAL, bool W2 = false>
 __global__ __launch_bounds__(256) void k_knn_pool(const T *__restrict__ data, T *__restrict__ out, const T *__restrict__ data2,
                                                    T *__restrict__ out2, const int64_t *__restrict__ indptr,
-                                                   const int32_t *__restrict__ indices, const T *__restrict__ w,
+                                                   const int32_t *__restrict__ indices, const T *__restrict__ w, const T *__restrict__ w2,
                                                    const int32_t *__restrict__ order, int G, int64_t ld,
                                                    int64_t cell0, int C_out, int slab, int maximum)
 {
+    static_assert(!(DUAL && W2), "one extension at a time");
     using V = typename Vec<T>::type;
     constexpr int N = Vec<T>::N;
     // slab-major block order; inside a slab the schedule is XCD-aware: workgroup b lands on XCD b % 8
@@ -41,20 +45,25 @@ __global__ __launch_bounds__(256) void k_knn_pool(const T *__restrict__ data, T 
         for (int k = 0; k < N; ++k) { acc[k] = T(0); acc2[k] = T(0); }
         int64_t p = p0;
         for (; p + 3 < p1; p += 4) {                       // 4 (DUAL: 8) gathers in flight
-            V x[4], y[4]; T ww[4];
+            V x[4], y[4]; T ww[4], wv2[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t ro = (int64_t)indices[p + u] * ld + g0;
                 x[u] = reinterpret_cast<const V *>(data + ro)[v];
                 if (DUAL) y[u] = reinterpret_cast<const V *>(data2 + ro)[v];
                 ww[u] = w[p + u];
+                if (W2) wv2[u] = w2[p + u];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const T *xp = reinterpret_cast<const T *>(&x[u]);
                 const T *yp = reinterpret_cast<const T *>(&y[u]);
 #pragma unroll
-                for (int k = 0; k < N; ++k) { acc[k] = fma(ww[u], xp[k], acc[k]); if (DUAL) acc2[k] = fma(ww[u], yp[k], acc2[k]); }
+                for (int k = 0; k < N; ++k) {
+                    acc[k] = fma(ww[u], xp[k], acc[k]);
+                    if (DUAL) acc2[k] = fma(ww[u], yp[k], acc2[k]);
+                    if (W2) acc2[k] = fma(wv2[u], xp[k], acc2[k]);
+                }
             }
         }
         for (; p < p1; ++p) {
@@ -62,11 +71,15 @@ __global__ __launch_bounds__(256) void k_knn_pool(const T *__restrict__ data, T 
             const V xv = reinterpret_cast<const V *>(data + ro)[v];
             V yv;
             if (DUAL) yv = reinterpret_cast<const V *>(data2 + ro)[v];
-            const T wv = w[p];
+            const T wv = w[p], wq = W2 ? w2[p] : T(0);
             const T *xp = reinterpret_cast<const T *>(&xv);
             const T *yp = reinterpret_cast<const T *>(&yv);
 #pragma unroll
-            for (int k = 0; k < N; ++k) { acc[k] = fma(wv, xp[k], acc[k]); if (DUAL) acc2[k] = fma(wv, yp[k], acc2[k]); }
+            for (int k = 0; k < N; ++k) {
+                acc[k] = fma(wv, xp[k], acc[k]);
+                if (DUAL) acc2[k] = fma(wv, yp[k], acc2[k]);
+                if (W2) acc2[k] = fma(wq, xp[k], acc2[k]);
+            }
         }
         if (maximum) {
             const int64_t ro = (cell0 + cl) * ld + g0;
@@ -86,20 +99,21 @@ __global__ __launch_bounds__(256) void k_knn_pool(const T *__restrict__ data, T 
 #pragma unroll
         for (int k = 0; k < N; ++k) { op[k] = acc[k]; op2[k] = acc2[k]; }
         reinterpret_cast<V *>(out + (int64_t)cl * ld + g0)[v] = o;
-        if (DUAL) reinterpret_cast<V *>(out2 + (int64_t)cl * ld + g0)[v] = o2;
+        if (DUAL || W2) reinterpret_cast<V *>(out2 + (int64_t)cl * ld + g0)[v] = o2;
     }
     for (int g = g0 + nvec * N + threadIdx.x; g < g1; g += blockDim.x) {   // < N tail genes of the last slab
         T a = T(0), a2 = T(0);
         for (int64_t p = p0; p < p1; ++p) {
             a = fma(w[p], data[(int64_t)indices[p] * ld + g], a);
             if (DUAL) a2 = fma(w[p], data2[(int64_t)indices[p] * ld + g], a2);
+            if (W2) a2 = fma(w2[p], data[(int64_t)indices[p] * ld + g], a2);
         }
         if (maximum) {
             const T sv = data[(cell0 + cl) * ld + g]; a = a > sv ? a : sv;
             if (DUAL) { const T tv = data2[(cell0 + cl) * ld + g]; a2 = a2 > tv ? a2 : tv; }
         }
         out[(int64_t)cl * ld + g] = a;
-        if (DUAL) out2[(int64_t)cl * ld + g] = a2;
+        if (DUAL || W2) out2[(int64_t)cl * ld + g] = a2;
     }
 }
 }  // namespace vcy
@@ -208,11 +222,12 @@ __global__ __launch_bounds__(256) void k_knn_pool_counts(const CT *__restrict__ 
 }  // namespace vcy
 
 static int knn_pool_impl(const void *data, void *out, const void *data2, void *out2, const int64_t *indptr, const int32_t *indices,
-                         const void *w, const int32_t *order, int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int maximum,
+                         const void *w, const void *w2, const int32_t *order, int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int maximum,
                          int64_t slab_genes, int dtype, vcy_stream stream)
 {
     VCY_REQUIRE(data && out && indptr && indices && w, "knn_pool: null pointer");
-    VCY_REQUIRE((data2 == nullptr) == (out2 == nullptr), "knn_pool: data2/out2 go together");
+    VCY_REQUIRE(w2 ? (data2 == nullptr && out2 != nullptr) : ((data2 == nullptr) == (out2 == nullptr)), "knn_pool: data2/out2 (or w2/out2) go together");
+    VCY_REQUIRE(!(w2 && maximum), "knn_pool: maximum is not defined for two weight sets");
     VCY_REQUIRE(C > 0 && G > 0 && ld >= G && C_out > 0 && cell0 >= 0 && cell0 + C_out <= C, "knn_pool: bad shape");
     VCY_REQUIRE(dtype == VCY_F32 || dtype == VCY_F64, "knn_pool: bad dtype");
     const int N = dtype == VCY_F32 ? 4 : 2;
@@ -226,11 +241,11 @@ static int knn_pool_impl(const void *data, void *out, const void *data2, void *o
     const int64_t blocks = nslab * ((C_out + 7) / 8 * 8);
     VCY_REQUIRE(blocks < (1LL << 31), "knn_pool: grid too large");
     hipStream_t st = as_stream(stream);
-#define VCY_POOL(T, DUAL)                                                                                                          \
-    hipLaunchKernelGGL((k_knn_pool<T, DUAL>), dim3((unsigned)blocks), dim3(threads), 0, st, (const T *)data, (T *)out, (const T *)data2, \
-                       (T *)out2, indptr, indices, (const T *)w, order, (int)G, ld, cell0, (int)C_out, (int)slab, maximum)
-    if (dtype == VCY_F32) { if (data2) VCY_POOL(float, true); else VCY_POOL(float, false); }
-    else { if (data2) VCY_POOL(double, true); else VCY_POOL(double, false); }
+#define VCY_POOL(T, DUAL, W2)                                                                                                      \
+    hipLaunchKernelGGL((k_knn_pool<T, DUAL, W2>), dim3((unsigned)blocks), dim3(threads), 0, st, (const T *)data, (T *)out, (const T *)data2, \
+                       (T *)out2, indptr, indices, (const T *)w, (const T *)w2, order, (int)G, ld, cell0, (int)C_out, (int)slab, maximum)
+    if (dtype == VCY_F32) { if (w2) VCY_POOL(float, false, true); else if (data2) VCY_POOL(float, true, false); else VCY_POOL(float, false, false); }
+    else { if (w2) VCY_POOL(double, false, true); else if (data2) VCY_POOL(double, true, false); else VCY_POOL(double, false, false); }
 #undef VCY_POOL
     VCY_LAUNCH_CHECK();
     return VCY_OK;
@@ -240,7 +255,7 @@ extern "C" int vcy_knn_pool(const void *data, void *out, const int64_t *indptr, 
                             const int32_t *order, int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out, int maximum,
                             int64_t slab_genes, int dtype, vcy_stream stream)
 {
-    return knn_pool_impl(data, out, nullptr, nullptr, indptr, indices, w, order, C, G, ld, cell0, C_out, maximum, slab_genes, dtype, stream);
+    return knn_pool_impl(data, out, nullptr, nullptr, indptr, indices, w, nullptr, order, C, G, ld, cell0, C_out, maximum, slab_genes, dtype, stream);
 }
 
 extern "C" int vcy_knn_pool2(const void *data, void *out, const void *data2, void *out2, const int64_t *indptr, const int32_t *indices,
@@ -250,9 +265,17 @@ extern "C" int vcy_knn_pool2(const void *data, void *out, const void *data2, voi
     VCY_REQUIRE(data2 && out2, "knn_pool2: null pointer");
     // one launch per matrix: sharing the index / weight reads does not pay for the doubled accumulators (f32, 50k x 30k:
     // 20.4 ms in one launch, 18.5 ms in two; tools/bench_pool.py)
-    const int rc = knn_pool_impl(data, out, nullptr, nullptr, indptr, indices, w, order, C, G, ld, cell0, C_out, maximum, slab_genes, dtype, stream);
+    const int rc = knn_pool_impl(data, out, nullptr, nullptr, indptr, indices, w, nullptr, order, C, G, ld, cell0, C_out, maximum, slab_genes, dtype, stream);
     if (rc) return rc;
-    return knn_pool_impl(data2, out2, nullptr, nullptr, indptr, indices, w, order, C, G, ld, cell0, C_out, maximum, slab_genes, dtype, stream);
+    return knn_pool_impl(data2, out2, nullptr, nullptr, indptr, indices, w, nullptr, order, C, G, ld, cell0, C_out, maximum, slab_genes, dtype, stream);
+}
+
+extern "C" int vcy_knn_pool_w2(const void *data, void *out, void *out2, const int64_t *indptr, const int32_t *indices, const void *w,
+                               const void *w2, const int32_t *order, int64_t C, int64_t G, int64_t ld, int64_t cell0, int64_t C_out,
+                               int64_t slab_genes, int dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(w2 && out2 && out != out2, "knn_pool_w2: null pointer");
+    return knn_pool_impl(data, out, nullptr, out2, indptr, indices, w, w2, order, C, G, ld, cell0, C_out, 0, slab_genes, dtype, stream);
 }
 
 extern "C" int vcy_knn_pool_counts(const void *countsS, const void *countsU, const double *scaleS, const double *scaleU, void *out,

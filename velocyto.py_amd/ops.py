@@ -669,6 +669,29 @@ def knn_pool(data: CellMatrix, indptr, indices, weights, maximum: bool = False, 
     return out
 
 
+def knn_pool_w2(data: CellMatrix, indptr, indices, weights, weights2, cell0: int = 0, C_out: Optional[int] = None, slab_genes: int = 0,
+                validate: bool = True, order: Optional[torch.Tensor] = None) -> Tuple[CellMatrix, CellMatrix]:
+    """One matrix pooled with two weight sets over the same graph (vcy_knn_pool_w2: the rows are gathered once):
+    out[c,:] = sum_p w[p] data[indices[p],:],  out2[c,:] = sum_p w2[p] data[indices[p],:]."""
+    dev = data.t.device
+    C_out = data.C - cell0 if C_out is None else C_out
+    ip = (indptr if isinstance(indptr, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(indptr).astype(np.int64))).to(device=dev, dtype=torch.int64).contiguous()
+    ix = _as_i32(indices, dev)
+    as_w = lambda t: (t if isinstance(t, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(t))).to(device=dev, dtype=data.dtype).contiguous()
+    w, w2 = as_w(weights), as_w(weights2)
+    assert ip.numel() == C_out + 1 and ix.numel() == w.numel() == w2.numel()
+    if validate and ix.numel() and (int(ix.min()) < 0 or int(ix.max()) >= data.C):
+        raise ValueError("neighbour index out of range")
+    out, out2 = CellMatrix.empty(C_out, data.G, data.dtype), CellMatrix.empty(C_out, data.G, data.dtype)
+    if order is not None:
+        order = order.to(device=dev, dtype=torch.int32).contiguous()
+        assert order.numel() == C_out
+    _lib.check(_lib.lib().vcy_knn_pool_w2(data.t.data_ptr(), out.t.data_ptr(), out2.t.data_ptr(), ip.data_ptr(), ix.data_ptr(), w.data_ptr(),
+                                          w2.data_ptr(), _p(order), data.C, data.G, data.ld, cell0, C_out, int(slab_genes), data.code, _stream()),
+               "knn_pool_w2")
+    return out, out2
+
+
 def knn_pool2(data: CellMatrix, data2: CellMatrix, indptr, indices, weights, maximum: bool = False, cell0: int = 0,
               C_out: Optional[int] = None, slab_genes: int = 0, out: Optional[CellMatrix] = None, out2: Optional[CellMatrix] = None,
               validate: bool = True, order: Optional[torch.Tensor] = None) -> Tuple[CellMatrix, CellMatrix]:
