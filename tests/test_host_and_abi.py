@@ -138,14 +138,19 @@ def _rng_state_equal(a, b):
 
 
 @pytest.mark.parametrize("n,size,cells,kind", [(101, 50, 40, "ramp"), (501, 250, 64, "ramp"), (30, 30, 25, "ramp"), (64, 20, 30, "zeros"),
-                                               (17, 1, 50, "uniform"), (200, 199, 12, "steep"), (12, 0, 5, "uniform"), (9, 4, 0, "uniform")])
+                                               (17, 1, 50, "uniform"), (200, 199, 12, "steep"), (12, 0, 5, "uniform"), (9, 4, 0, "uniform"),
+                                               (501, 250, 300, "ramp"), (4000, 40, 30, "plateau"), (4000, 900, 6, "plateau"), (2500, 30, 40, "uniform")])
 def test_choice_stream_host_replays_numpy(lib, n, size, cells, kind):
     """The neighbour sampling of estimate_transition_prob (analysis.py:1561-1564): the block helper must return what the
     reference's per-cell np.random.choice(n, size, replace=False, p=p) calls return, draw for draw, and leave numpy's global
-    RNG in the same state - whatever the block / pool sizes (refill path, cells that do not fit the pool)."""
+    RNG in the same state - whatever the block / pool sizes (refill path, cells that do not fit the pool, the short measuring
+    block followed by full ones) and whichever lookup the library picks: bucket table + fixed scan in the first round (or a
+    binary search when a bucket of the table is wide: "plateau", long runs of zero probability), normalised cdf + binary search
+    in big later rounds, unnormalised sums + exact predicate in small ones."""
     from velocyto_amd import ops
     p = {"ramp": np.linspace(0.5, 0.1, n), "uniform": np.ones(n), "steep": np.geomspace(1.0, 1e-6, n),
-         "zeros": np.where(np.arange(n) % 3 == 0, 0.0, np.linspace(1, 2, n))}[kind]
+         "zeros": np.where(np.arange(n) % 3 == 0, 0.0, np.linspace(1, 2, n)),
+         "plateau": np.where((np.arange(n) > 100) & (np.arange(n) < 2900), 0.0, np.linspace(1, 2, n))}[kind]
     p = p / p.sum()
     np.random.seed(15071990 + n)
     want = np.stack([np.random.choice(n, size=(size,), replace=False, p=p) for _ in range(cells)], 0) if cells else np.empty((0, size), dtype=np.int64)

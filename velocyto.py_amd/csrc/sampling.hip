@@ -35,26 +35,47 @@ extern "C" int vcy_choice_stream_host(const double *pool, int64_t pool_len, cons
         positive += p[i] > 0.0;
     }
     VCY_REQUIRE(positive >= size, "choice_stream: Fewer non-zero entries in p than size");
-    std::vector<double> pw((size_t)n), cdf((size_t)n), cdf0((size_t)n);
-    std::vector<int64_t> stamp((size_t)n, -1);
     constexpr int64_t LUT = 128;                                 // power of two: v * LUT and b / LUT are exact
-    std::vector<int32_t> lut((size_t)LUT), lut0((size_t)LUT);
-    // cdf = cumsum(w) / cumsum(w)[-1] exactly as numpy forms it (sequential fp64 accumulation, elementwise division), plus a
-    // bucket table over [0, 1): table[b] = first index with cdf > b / LUT, a lower bound of searchsorted(cdf, v, "right") for
-    // every v in bucket b = floor(v * LUT); the few remaining steps are a scan.
-    auto build = [&](const double *w, double *cd, int32_t *table) {
+    constexpr int64_t WMAX = 32;                                 // widest bucket the fixed-length scan of round 1 is used for
+    std::vector<double> pw((size_t)n), cs((size_t)n), cdf((size_t)n), cdf0((size_t)(n + WMAX), 2.0);     // cdf0 padded with values no draw reaches
+    std::vector<int64_t> stamp((size_t)n, -1);
+    std::vector<int32_t> lut0((size_t)LUT + 1);
+    // cdf = cumsum(w) / cumsum(w)[-1] exactly as numpy forms it: a sequential fp64 accumulation, then an elementwise division.
+    auto cumsum = [&](const double *w, double *c) {
         double acc = 0.0;
-        for (int64_t i = 0; i < n; ++i) { acc = acc + w[i]; cd[i] = acc; }
-        const double total = cd[n - 1];
-        for (int64_t i = 0; i < n; ++i) cd[i] = cd[i] / total;
+        for (int64_t i = 0; i < n; ++i) { acc = acc + w[i]; c[i] = acc; }
+    };
+    // The first round of every cell sees the untouched p and takes most of the draws: its cdf gets a bucket table over [0, 1),
+    // table[b] = first index with cdf > b / LUT, a lower bound of searchsorted(cdf, v, "right") for every v in bucket
+    // b = floor(v * LUT); the answer lies in [table[b], table[b + 1]], so it is table[b] + the number of entries <= v among the next
+    // W = widest bucket + 1 (entries past the answer are > v: the array is sorted and padded).  No data-dependent branch: what
+    // costs in this loop is not arithmetic but mispredicted exits of a scan.
+    cumsum(p, cdf0.data());
+    int64_t W = 1;
+    {
+        const double total = cdf0[(size_t)n - 1];
+        for (int64_t i = 0; i < n; ++i) cdf0[(size_t)i] = cdf0[(size_t)i] / total;
         int64_t i = 0;
         for (int64_t b = 0; b < LUT; ++b) {
             const double edge = (double)b * (1.0 / LUT);
-            while (cd[i] <= edge && i < n - 1) ++i;
-            table[b] = (int32_t)i;
+            while (cdf0[(size_t)i] <= edge && i < n - 1) ++i;
+            lut0[(size_t)b] = (int32_t)i;
         }
+        lut0[(size_t)LUT] = (int32_t)(n - 1);
+        for (int64_t b = 0; b < LUT; ++b) W = std::max<int64_t>(W, lut0[(size_t)b + 1] - lut0[(size_t)b] + 1);
+        W = (W + 3) / 4 * 4;
+    }
+    // searchsorted(c, v, "right") = number of entries <= v of a non-decreasing array, without data-dependent branches
+    auto upper_bound = [&](const double *c, double v) {
+        int64_t lo = 0, len = n;
+        while (len > 1) {
+            const int64_t half = len >> 1;
+            lo += (c[lo + half - 1] <= v) ? half : 0;
+            len -= half;
+        }
+        return lo + ((c[lo] <= v) ? 1 : 0);
     };
-    build(p, cdf0.data(), lut0.data());                           // the first round of every cell sees the untouched p
+    constexpr int64_t LAZY = 24;                                 // rounds with fewer draws than this do not normalise the whole cdf
     int64_t pos = 0, done = 0, used = 0, round_id = 0;
     for (int64_t c = 0; c < cells; ++c) {
         int64_t *found = out + c * size;
@@ -65,22 +86,52 @@ extern "C" int vcy_choice_stream_host(const double *pool, int64_t pool_len, cons
             if (pos + need > pool_len) { fits = false; break; }
             const double *x = pool + pos;
             pos += need;
-            const double *cd = cdf0.data();
-            const int32_t *table = lut0.data();
-            if (n_uniq > 0) {
-                if (zeroed == 0) for (int64_t i = 0; i < n; ++i) pw[(size_t)i] = p[i];
-                for (; zeroed < n_uniq; ++zeroed) pw[(size_t)found[zeroed]] = 0.0;
-                build(pw.data(), cdf.data(), lut.data());
-                cd = cdf.data();
-                table = lut.data();
-            }
             ++round_id;
             int64_t added = 0;
-            for (int64_t k = 0; k < need; ++k) {
-                const double v = x[k];
-                int64_t lo = table[(int64_t)(v * (double)LUT)];
-                while (lo < n - 1 && cd[lo] <= v) ++lo;              // cdf[n-1] == 1 > v: numpy cannot run past the end either
-                if (stamp[(size_t)lo] != round_id) { stamp[(size_t)lo] = round_id; found[n_uniq + added++] = lo; }
+            auto take = [&](int64_t lo) {                        // first occurrences, in draw order (np.unique(return_index) + sort + take)
+                const int64_t fresh = stamp[(size_t)lo] != round_id;
+                stamp[(size_t)lo] = round_id;
+                found[n_uniq + added] = lo;                      // written either way, kept only if fresh: draw k of a round writes slot
+                added += fresh;                                  // n_uniq + added <= n_uniq + k < size, and a later fresh index overwrites a repeat
+            };
+            if (n_uniq == 0 && W <= WMAX) {
+                const double *cd = cdf0.data();
+                for (int64_t k = 0; k < need; ++k) {
+                    const double v = x[k];
+                    const double *win = cd + lut0[(size_t)(int64_t)(v * (double)LUT)];
+                    int64_t cnt = 0;
+                    for (int64_t j = 0; j < W; ++j) cnt += win[j] <= v;
+                    take((win - cd) + cnt);
+                }
+            } else if (n_uniq == 0) {
+                for (int64_t k = 0; k < need; ++k) {
+                    const int64_t lo = upper_bound(cdf0.data(), x[k]);
+                    take(lo < n - 1 ? lo : n - 1);
+                }
+            } else {
+                if (zeroed == 0) for (int64_t i = 0; i < n; ++i) pw[(size_t)i] = p[i];
+                for (; zeroed < n_uniq; ++zeroed) pw[(size_t)found[zeroed]] = 0.0;
+                cumsum(pw.data(), cs.data());
+                const double total = cs[(size_t)n - 1];
+                if (need >= LAZY) {
+                    for (int64_t i = 0; i < n; ++i) cdf[(size_t)i] = cs[(size_t)i] / total;
+                    for (int64_t k = 0; k < need; ++k) {
+                        const int64_t lo = upper_bound(cdf.data(), x[k]);
+                        take(lo < n - 1 ? lo : n - 1);
+                    }
+                } else {
+                    // a handful of draws: look each one up in the UNNORMALISED sums near v * total, then settle the position with the
+                    // exact predicate cs[i] / total <= v (the quotient is monotone in cs[i], so the normalised cdf is sorted the same
+                    // way and its searchsorted is the first index where the predicate fails)
+                    for (int64_t k = 0; k < need; ++k) {
+                        const double v = x[k];
+                        int64_t lo = upper_bound(cs.data(), v * total);
+                        if (lo > n - 1) lo = n - 1;
+                        while (lo > 0 && !(cs[(size_t)lo - 1] / total <= v)) --lo;
+                        while (lo < n - 1 && cs[(size_t)lo] / total <= v) ++lo;
+                        take(lo);
+                    }
+                }
             }
             n_uniq += added;
         }

@@ -1046,7 +1046,9 @@ def choice_stream_host(n: int, size: int, p: np.ndarray, cells: int, block: int 
     """``np.stack([np.random.choice(n, size=size, replace=False, p=p) for _ in range(cells)])`` - the neighbour sampling of
     estimate_transition_prob (analysis.py:1561-1564) - with the same draws from numpy's global legacy RNG and the same RNG
     state afterwards, without the per-cell trips through RandomState.choice: the uniforms of a block of cells are drawn in one
-    call and vcy_choice_stream_host replays choice's rounds over them."""
+    call and vcy_choice_stream_host replays choice's rounds over them.  The uniforms of the next block are drawn by a second thread
+    while a block is replayed (both release the GIL); how many a cell takes is measured on a short first block."""
+    from concurrent.futures import ThreadPoolExecutor
     p = np.ascontiguousarray(p, dtype=np.float64)
     n, size, cells = int(n), int(size), int(cells)
     if p.shape != (n,):
@@ -1060,17 +1062,35 @@ def choice_stream_host(n: int, size: int, p: np.ndarray, cells: int, block: int 
     cd, used = ctypes.c_int64(0), ctypes.c_int64(0)
     pending = np.empty(0, dtype=np.float64)                  # uniforms drawn but not consumed yet (carried to the next block)
     draws = []                                               # (RNG state before the draw, number drawn), to hand back the unused tail
-    while done_total < cells and size > 0:
-        todo = min(int(block), cells - done_total)
-        want = max(int(todo * size * pool_factor) + size - pending.size, size)
-        draws.append((np.random.get_state(), want))
-        pool = np.concatenate([pending, np.random.random_sample(want)])
-        _lib.check(_lib.lib().vcy_choice_stream_host(pool.ctypes.data, pool.size, p.ctypes.data, n, size, todo, out[done_total:].ctypes.data,
-                                                     ctypes.byref(cd), ctypes.byref(used)), "choice_stream")
-        pending = pool[used.value:]
-        if cd.value == 0:
-            pool_factor *= 2                                 # a cell needed more rounds than the pool held: draw more
-        done_total += cd.value
+    per_cell = float(size) * pool_factor                     # uniforms a cell takes: a guess, then the measured mean
+
+    def draw(want):                                          # only this function touches the global RNG while the loop runs
+        state = np.random.get_state()
+        return state, np.random.random_sample(want)
+
+    def block_cells(cells_left):                             # a short first block measures what a cell takes
+        return min(int(block) if draws else min(int(block), 256), cells_left)
+
+    def want(todo, have):
+        return max(int(todo * per_cell) + size - have, size)
+
+    with ThreadPoolExecutor(1) as ex:
+        fut = ex.submit(draw, want(block_cells(cells), 0)) if cells > 0 and size > 0 else None
+        while fut is not None:
+            state, fresh = fut.result()
+            draws.append((state, fresh.size))
+            pool = np.concatenate([pending, fresh]) if pending.size else fresh
+            todo = block_cells(cells - done_total) if len(draws) > 1 else min(256, int(block), cells)
+            # the uniforms of the block after this one are drawn while this one is replayed
+            after = cells - done_total - todo
+            fut = ex.submit(draw, want(min(int(block), after), max(0, pool.size - int(todo * per_cell)))) if after > 0 else None
+            _lib.check(_lib.lib().vcy_choice_stream_host(pool.ctypes.data, pool.size, p.ctypes.data, n, size, todo, out[done_total:].ctypes.data,
+                                                         ctypes.byref(cd), ctypes.byref(used)), "choice_stream")
+            pending = pool[used.value:]
+            done_total += cd.value
+            per_cell = (used.value / cd.value * 1.02 + 0.5) if cd.value else per_cell * 2       # measured; nothing fitted: draw more
+            if fut is None and done_total < cells:           # the pool fell short on what was planned as the last block
+                fut = ex.submit(draw, want(cells - done_total, pending.size))
     left = pending.size                                      # leave the RNG where the per-cell calls would have left it
     while left > 0:
         state, drawn = draws.pop()
