@@ -783,6 +783,55 @@ def test_markov_factored_matches_dense_chain(ops, oracle, edim, compute):
                 np.testing.assert_allclose((xa if acc else xf).cpu().numpy(), want, rtol=rt)
 
 
+@pytest.mark.parametrize("edim", [1, 2, 3])
+@pytest.mark.parametrize("compute", ["float64", "float32"])
+def test_markov_culled_gauss_transform_equals_the_full_one(ops, oracle, edim, compute):
+    """vcy_diffuse_step_factored_culled (cells sorted along the Hilbert curve, source runs out of the kernel's reach skipped)
+    against vcy_diffuse_step_factored on clustered embeddings much wider than sigma_W - what prepare_markov is usually given - and
+    against the oracle's dense chain on a small one; the dropped terms are below the accumulation's own rounding."""
+    from scipy import sparse
+    rng = np.random.default_rng(77 + edim)
+    n, k = 6000, 12
+    centres = rng.normal(size=(9, edim)) * 40.0
+    lab = np.sort(rng.integers(0, 9, n))
+    emb = centres[lab] + rng.normal(size=(n, edim)) * 2.0
+    first, count = np.searchsorted(lab, lab), np.bincount(lab)[lab]      # transitions go to cells of the same cluster (a row whose
+    ix = first[:, None] + (rng.integers(0, 1 << 30, (n, k)) % count[:, None])   # neighbours are all out of K_D's reach has no chain)
+    ix[:, 0] = np.arange(n)                                              # (repeats allowed; the stored diagonal keeps every row alive)
+    tp = rng.random((n, k)) + 0.01
+    tp /= tp.sum(1, keepdims=True)
+    indptr = np.arange(0, n * k + 1, k)
+    cdt = torch.float64 if compute == "float64" else torch.float32
+    full = ops.prepare_markov_factored(indptr, ix.ravel(), tp.ravel(), emb, 1.0, 0.5, compute_dtype=cdt, cull=False)
+    cul = ops.prepare_markov_factored(indptr, ix.ravel(), tp.ravel(), emb, 1.0, 0.5, compute_dtype=cdt)
+    assert full.cull is None and cul.cull is not None                     # auto: the embedding is ~200 kernel widths across
+    x0 = rng.random(n)
+    x0 /= x0.sum()
+    for steps, acc in ((1, False), (7, True), (40, False)):
+        a, aa = ops.diffuse(x0, full, steps, accumulate=acc)
+        b, bb = ops.diffuse(x0, cul, steps, accumulate=acc)
+        ra, rb = (aa, bb) if acc else (a, b)
+        tol = 1e-12 if compute == "float64" else 2e-6
+        assert float(((ra - rb).abs() / ra.abs().clamp_min(1e-300)).max()) < tol
+        assert abs(float(rb.sum()) - (steps if acc else 1.0)) < (1e-9 if compute == "float64" else 1e-4)
+    # a narrow compact embedding: nothing can be skipped, auto leaves the plain transform on
+    near = ops.prepare_markov_factored(indptr, ix.ravel(), tp.ravel(), rng.normal(size=(n, edim)), 1.0, 2.0, compute_dtype=cdt)
+    assert near.cull is None
+    # and against the oracle's dense chain (forced culling on a small wide problem)
+    m = 500
+    embs = np.concatenate([rng.normal(size=(m // 2, edim)), rng.normal(size=(m - m // 2, edim)) + 30.0])
+    tpd = np.zeros((m, m))
+    np.put_along_axis(tpd, np.stack([rng.choice(m, 9, replace=False) for _ in range(m)]), rng.random((m, 9)) + 0.01, axis=1)
+    tpd /= tpd.sum(1, keepdims=True)
+    ref = oracle.prepare_markov(tpd, embs, 25.0, 0.7, "forward")          # (K_D wide: the random transitions cross between the blobs)
+    P = sparse.csr_matrix(tpd)
+    P.sort_indices()
+    fac = ops.prepare_markov_factored(P.indptr, P.indices, P.data, embs, 25.0, 0.7, compute_dtype=cdt, cull=True)
+    xs = rng.random(m)
+    got, _ = ops.diffuse(xs / xs.sum(), fac, 9, accumulate=False)
+    np.testing.assert_allclose(got.cpu().numpy(), oracle.diffuse(xs, ref, 9, "time_evolution").ravel(), rtol=1e-11 if compute == "float64" else 5e-5)
+
+
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
 @pytest.mark.parametrize("transform,psc", [("sqrt", 1e-10), ("log10", 1e-10), ("linear", 0.0)])
 @pytest.mark.parametrize("C,G,nr", [(200, 3100, 24), (40, 700, 9), (20, 500, 5)])

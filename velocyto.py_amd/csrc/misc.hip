@@ -435,13 +435,13 @@ __global__ void k_markov_scale_coords(const double *__restrict__ emb, CT *__rest
 }
 template <typename CT>
 __global__ void k_markov_scale_x(const double *__restrict__ x, const double *__restrict__ tot, const double *__restrict__ kw, double *__restrict__ v,
-                                 CT *__restrict__ u, int n, double coef)
+                                 CT *__restrict__ u, int n, double coef, const int32_t *__restrict__ rank)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     const double vc = x[c] / tot[c];
     v[c] = vc;
-    u[c] = (CT)(coef * vc / kw[c]);
+    u[rank ? rank[c] : c] = (CT)(coef * vc / kw[c]);          // rank: the cell's position in the spatially sorted order of the culled transform
 }
 
 __device__ __forceinline__ float exp2_neg(float d2) { return __builtin_amdgcn_exp2f(-d2); }
@@ -500,13 +500,129 @@ __global__ __launch_bounds__(256) void k_gauss_transform(const CT *__restrict__ 
     for (int t = 0; t < JPT; ++t)
         if (j0 + t * 256 < n) part[(int64_t)blockIdx.y * n + j0 + t * 256] = acc[t];
 }
+// The same transform for a kernel that is NARROW against the extent of the embedding (prepare_markov is typically called with sigma_W
+// of a grid step): terms below 2^-cut of their weight are left out.  Cells are visited in a spatially sorted order (Hilbert curve of
+// the embedding, made by the caller), so 256 consecutive targets and 32 consecutive sources both fill small boxes; a workgroup
+// skips every chunk of 32 sources whose box is farther than sqrt(cut) from its targets' box.  The box tests of 64 chunks are made at
+// once, one per lane, and the survivors walked through a ballot mask (one test after the other costs a scalar-load round trip each -
+// more than the arithmetic they save).  What is left out per target is below n max(u) 2^-cut: cut = 48 (f32) / 72 (f64) puts it
+// under the rounding of the accumulation itself.
+constexpr int GT_CHUNK = 32;
+template <typename CT, int EDIM>
+__global__ void k_gauss_boxes(const CT *__restrict__ pts, int npts, CT *__restrict__ lo, CT *__restrict__ hi, int nbox)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;     // box b = bounding box of GT_CHUNK consecutive points
+    if (b >= nbox) return;
+    const int p0 = b * GT_CHUNK, p1 = min(npts, p0 + GT_CHUNK);
+#pragma unroll
+    for (int a = 0; a < EDIM; ++a) {
+        CT l = pts[(int64_t)p0 * EDIM + a], h = l;
+        for (int q = p0 + 1; q < p1; ++q) { const CT v = pts[(int64_t)q * EDIM + a]; l = fmin(l, v); h = fmax(h, v); }
+        lo[(int64_t)b * EDIM + a] = l;
+        hi[(int64_t)b * EDIM + a] = h;
+    }
+}
+
+template <typename CT, int EDIM, int JPT>
+__global__ __launch_bounds__(256) void k_gauss_transform_culled(const CT *__restrict__ es, const CT *__restrict__ u, double *__restrict__ part, int n,
+                                                                 const CT *__restrict__ clo, const CT *__restrict__ chi, int nchunk, CT cut)
+{
+    __shared__ CT red[2][EDIM][4];
+    const int j0 = blockIdx.x * 256 * JPT + threadIdx.x;
+    CT ej[JPT][EDIM];
+#pragma unroll
+    for (int t = 0; t < JPT; ++t) {
+        const int j = min(j0 + t * 256, n - 1);
+#pragma unroll
+        for (int a = 0; a < EDIM; ++a) ej[t][a] = es[(int64_t)j * EDIM + a];
+    }
+    CT tlo[EDIM], thi[EDIM];                                   // the box of this workgroup's targets
+#pragma unroll
+    for (int a = 0; a < EDIM; ++a) {
+        CT l = ej[0][a], h = ej[0][a];
+#pragma unroll
+        for (int t = 1; t < JPT; ++t) { l = fmin(l, ej[t][a]); h = fmax(h, ej[t][a]); }
+        l = -wave_max(-l);
+        h = wave_max(h);
+        if ((threadIdx.x & 63) == 0) { red[0][a][threadIdx.x >> 6] = l; red[1][a][threadIdx.x >> 6] = h; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < EDIM; ++a) {
+        tlo[a] = fmin(fmin(red[0][a][0], red[0][a][1]), fmin(red[0][a][2], red[0][a][3]));
+        thi[a] = fmax(fmax(red[1][a][0], red[1][a][1]), fmax(red[1][a][2], red[1][a][3]));
+    }
+    // the sources are split over blockIdx.y by chunks (finely: where the data is dense a few workgroups get all the work of a target
+    // block, and the launch lasts as long as the busiest of them)
+    const int qper = (nchunk + gridDim.y - 1) / gridDim.y;
+    const int qa = blockIdx.y * qper, qb = min(nchunk, qa + qper);
+    const int lane = threadIdx.x & 63;
+    double acc[JPT];
+#pragma unroll
+    for (int t = 0; t < JPT; ++t) acc[t] = 0.0;
+    auto term = [&](int c, CT (&fold)[JPT]) {
+        CT ec[EDIM];
+#pragma unroll
+        for (int a = 0; a < EDIM; ++a) ec[a] = es[(int64_t)c * EDIM + a];
+        const CT uc = u[c];
+#pragma unroll
+        for (int t = 0; t < JPT; ++t) {
+            CT d2 = CT(0);
+#pragma unroll
+            for (int a = 0; a < EDIM; ++a) { const CT df = ej[t][a] - ec[a]; d2 = fma(df, df, d2); }
+            fold[t] = fma(uc, exp2_neg(d2), fold[t]);
+        }
+    };
+    for (int qq = qa; qq < qb; qq += 64) {
+        const int mine = qq + lane;                            // every wave makes the same 64 tests and gets the same mask
+        bool near = false;
+        if (mine < qb) {
+            CT d2 = CT(0);
+#pragma unroll
+            for (int a = 0; a < EDIM; ++a) {
+                const CT gap = fmax(fmax(clo[(int64_t)mine * EDIM + a] - thi[a], tlo[a] - chi[(int64_t)mine * EDIM + a]), CT(0));
+                d2 = fma(gap, gap, d2);
+            }
+            near = !(d2 > cut);
+        }
+        unsigned long long mask = __ballot(near);
+        while (mask) {
+            const int q = qq + __builtin_ctzll(mask);
+            mask &= mask - 1;
+            int c = q * GT_CHUNK;
+            const int c1 = min(n, c + GT_CHUNK);
+            for (; c + 8 <= c1; c += 8) {
+                CT fold[JPT];
+#pragma unroll
+                for (int t = 0; t < JPT; ++t) fold[t] = CT(0);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) term(c + k, fold);
+#pragma unroll
+                for (int t = 0; t < JPT; ++t) acc[t] += (double)fold[t];
+            }
+            if (c < c1) {
+                CT fold[JPT];
+#pragma unroll
+                for (int t = 0; t < JPT; ++t) fold[t] = CT(0);
+                for (; c < c1; ++c) term(c, fold);
+#pragma unroll
+                for (int t = 0; t < JPT; ++t) acc[t] += (double)fold[t];
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < JPT; ++t)
+        if (j0 + t * 256 < n) part[(int64_t)blockIdx.y * n + j0 + t * 256] = acc[t];
+}
 // y[j] += the folded partials (fixed order); path_integral: accum += y
-__global__ void k_gauss_reduce(const double *__restrict__ part, double *__restrict__ y, double *__restrict__ accum, int n, int nparts)
+__global__ void k_gauss_reduce(const double *__restrict__ part, double *__restrict__ y, double *__restrict__ accum, int n, int nparts,
+                               const int32_t *__restrict__ rank)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
+    const int jj = rank ? rank[j] : j;
     double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * n + j];
+    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * n + jj];
     s += y[j];
     y[j] = s;
     if (accum) accum[j] += s;
@@ -691,20 +807,35 @@ extern "C" int vcy_prepare_markov_factored(const int64_t *indptr, const int32_t 
     return VCY_OK;
 }
 
+static inline int64_t gt_chunks(int64_t n) { return (n + GT_CHUNK - 1) / GT_CHUNK; }
+
 template <typename CT>
 static int diffuse_step_factored(const double *x, double *y, double *accum, const int64_t *colptr, const int32_t *rowidx, const double *scsc,
                                  const double *tot, const double *kw, const CT *es, int edim, double sigma_W, void *workspace, int64_t n,
-                                 hipStream_t st)
+                                 hipStream_t st, const int32_t *rank = nullptr, const CT *boxes = nullptr, double cut = 0.0)
 {
     double *v = (double *)workspace;
     CT *u = (CT *)(v + n);
     double *part = v + 2 * n;
     const double coef = 0.2 / sqrt(2.0 * 3.14159265358979323846 * sigma_W * sigma_W);
-    hipLaunchKernelGGL(k_markov_scale_x<CT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, tot, kw, v, u, (int)n, coef);
+    hipLaunchKernelGGL(k_markov_scale_x<CT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, tot, kw, v, u, (int)n, coef, rank);
     VCY_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_vecmat_csc<double>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, colptr, rowidx, scsc, (const double *)v, y, (double *)nullptr, (int)n);
     VCY_LAUNCH_CHECK();
-    const int nparts = gauss_parts(n);
+    int nparts = gauss_parts(n);
+    if (boxes) {
+        const int64_t nc = gt_chunks(n);
+        nparts = nc < 64 ? (int)nc : 64;
+        const CT *clo = boxes, *chi = clo + nc * edim;
+        dim3 gridc((unsigned)((n + 255) / 256), nparts);
+#define VCY_GTC(ED) hipLaunchKernelGGL((k_gauss_transform_culled<CT, ED, 1>), gridc, dim3(256), 0, st, es, (const CT *)u, part, (int)n, clo, chi, (int)nc, (CT)cut)
+        switch (edim) { case 1: VCY_GTC(1); break; case 2: VCY_GTC(2); break; case 3: VCY_GTC(3); break; default: VCY_GTC(4); break; }
+#undef VCY_GTC
+        VCY_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_gauss_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double *)part, y, accum, (int)n, nparts, rank);
+        VCY_LAUNCH_CHECK();
+        return VCY_OK;
+    }
     dim3 grid((unsigned)((n + 511) / 512), nparts);
     switch (edim) {
     case 1: hipLaunchKernelGGL((k_gauss_transform<CT, 1, 2>), grid, dim3(256), 0, st, es, (const CT *)u, part, (int)n); break;
@@ -713,9 +844,47 @@ static int diffuse_step_factored(const double *x, double *y, double *accum, cons
     default: hipLaunchKernelGGL((k_gauss_transform<CT, 4, 2>), grid, dim3(256), 0, st, es, (const CT *)u, part, (int)n); break;
     }
     VCY_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_gauss_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double *)part, y, accum, (int)n, nparts);
+    hipLaunchKernelGGL(k_gauss_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double *)part, y, accum, (int)n, nparts, rank);
     VCY_LAUNCH_CHECK();
     return VCY_OK;
+}
+
+extern "C" size_t vcy_markov_cull_boxes_bytes(int64_t n, int edim, int compute_dtype)
+{
+    if (n <= 0 || edim <= 0) return 0;
+    return (size_t)2 * (size_t)gt_chunks(n) * (size_t)edim * (compute_dtype == VCY_F64 ? 8 : 4);
+}
+
+template <typename CT>
+static int markov_cull_boxes(const CT *es, CT *boxes, int64_t n, int edim, hipStream_t st)
+{
+    const int64_t nc = gt_chunks(n);
+    CT *clo = boxes, *chi = clo + nc * edim;
+#define VCY_GB(ED) hipLaunchKernelGGL((k_gauss_boxes<CT, ED>), dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, es, (int)n, clo, chi, (int)nc)
+    switch (edim) { case 1: VCY_GB(1); break; case 2: VCY_GB(2); break; case 3: VCY_GB(3); break; default: VCY_GB(4); break; }
+#undef VCY_GB
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}
+
+extern "C" int vcy_markov_cull_boxes(const void *es_sorted, void *boxes, int64_t n, int edim, int compute_dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(es_sorted && boxes && n > 0 && n < (1ll << 31) && edim > 0 && edim <= 4, "markov_cull_boxes: bad arguments");
+    if (compute_dtype == VCY_F32) return markov_cull_boxes<float>((const float *)es_sorted, (float *)boxes, n, edim, as_stream(stream));
+    if (compute_dtype == VCY_F64) return markov_cull_boxes<double>((const double *)es_sorted, (double *)boxes, n, edim, as_stream(stream));
+    return fail(VCY_ERR_INVALID, "%s: bad dtype", "markov_cull_boxes");
+}
+
+extern "C" int vcy_diffuse_step_factored_culled(const double *x, double *y, double *accum, const int64_t *colptr, const int32_t *rowidx,
+                                                const double *scsc, const double *tot, const double *kw, const void *es_sorted,
+                                                const int32_t *rank, const void *boxes, int edim, double sigma_W, double cut, void *workspace,
+                                                int64_t n, int compute_dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(x && y && colptr && rowidx && scsc && tot && kw && es_sorted && rank && boxes && workspace && x != y, "diffuse_step_factored_culled: bad arguments");
+    VCY_REQUIRE(n > 0 && n < (1ll << 31) && edim > 0 && edim <= 4 && sigma_W > 0 && cut > 0, "diffuse_step_factored_culled: bad arguments");
+    if (compute_dtype == VCY_F32) return diffuse_step_factored<float>(x, y, accum, colptr, rowidx, scsc, tot, kw, (const float *)es_sorted, edim, sigma_W, workspace, n, as_stream(stream), rank, (const float *)boxes, cut);
+    if (compute_dtype == VCY_F64) return diffuse_step_factored<double>(x, y, accum, colptr, rowidx, scsc, tot, kw, (const double *)es_sorted, edim, sigma_W, workspace, n, as_stream(stream), rank, (const double *)boxes, cut);
+    return fail(VCY_ERR_INVALID, "%s: bad dtype", "diffuse_step_factored_culled");
 }
 
 extern "C" int vcy_diffuse_step_factored(const double *x, double *y, double *accum, const int64_t *colptr, const int32_t *rowidx, const double *scsc,

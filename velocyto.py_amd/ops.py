@@ -1395,6 +1395,13 @@ def diffuse(x0, tr, n_steps: int, accumulate: bool) -> Tuple[torch.Tensor, Optio
         ws = torch.empty(int(L.vcy_markov_factored_workspace_bytes(n)), dtype=torch.uint8, device=dev)
 
         def step(src, dst):
+            if tr.cull is not None:
+                es_sorted, rank, boxes, cut = tr.cull
+                _lib.check(L.vcy_diffuse_step_factored_culled(src.data_ptr(), dst.data_ptr(), _p(acc), tr.colptr.data_ptr(), tr.rowidx.data_ptr(),
+                                                              tr.scsc.data_ptr(), tr.tot.data_ptr(), tr.kw.data_ptr(), es_sorted.data_ptr(), rank.data_ptr(),
+                                                              boxes.data_ptr(), tr.edim, tr.sigma_W, cut, ws.data_ptr(), n, _DT[tr.compute_dtype],
+                                                              _stream()), "diffuse_step_factored_culled")
+                return
             _lib.check(L.vcy_diffuse_step_factored(src.data_ptr(), dst.data_ptr(), _p(acc), tr.colptr.data_ptr(), tr.rowidx.data_ptr(), tr.scsc.data_ptr(),
                                                    tr.tot.data_ptr(), tr.kw.data_ptr(), tr.es.data_ptr(), tr.edim, tr.sigma_W, ws.data_ptr(), n,
                                                    _DT[tr.compute_dtype], _stream()), "diffuse_step_factored")
@@ -1442,14 +1449,38 @@ class MarkovFactors:
         self.colptr, self.rowidx, self.scsc, self.tot, self.kw, self.es, self.compute_dtype = colptr, rowidx, scsc, tot, kw, es, compute_dtype
         self.n, self.edim = int(embedding.shape[0]), int(embedding.shape[1])
         self.shape = (self.n, self.n)
+        self.cull = None                                    # (es_sorted, rank, boxes, cut) of the culled Gauss transform, see enable_culling
+
+    def enable_culling(self, cut: Optional[float] = None) -> "MarkovFactors":
+        """Sort the cells along the Hilbert curve of the embedding and box runs of them, so that the steps skip source runs whose
+        contribution to a block of targets is below 2^-cut of their weight (vcy_diffuse_step_factored_culled).  Pays when sigma_W
+        is small against the extent of the embedding, costs a few per cent when it is not."""
+        dev = self.es.device
+        if cut is None:
+            cut = 48.0 if self.compute_dtype == torch.float32 else 72.0
+        if self.edim >= 2:
+            order = hilbert_order(self.embedding[:, :2].contiguous()).long()
+        else:
+            order = torch.argsort(self.embedding[:, 0])
+        rank = torch.empty(self.n, dtype=torch.int32, device=dev)
+        rank[order] = torch.arange(self.n, dtype=torch.int32, device=dev)
+        es_sorted = self.es.index_select(0, order).contiguous()
+        code = _DT[self.compute_dtype]
+        boxes = torch.empty(int(_lib.lib().vcy_markov_cull_boxes_bytes(self.n, self.edim, code)), dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib().vcy_markov_cull_boxes(es_sorted.data_ptr(), boxes.data_ptr(), self.n, self.edim, code, _stream()), "markov_cull_boxes")
+        self.cull = (es_sorted, rank, boxes, float(cut))
+        return self
 
     def dense(self, dtype=torch.float64) -> torch.Tensor:
         ip, ix, pv = self._csr
         return prepare_markov(ip, ix, pv, self.embedding, self.sigma_D, self.sigma_W, dtype=dtype)
 
 
-def prepare_markov_factored(indptr, indices, pval, embedding, sigma_D: float, sigma_W: float, compute_dtype=torch.float32) -> MarkovFactors:
-    """Factors of the Markov matrix from CSR transition probabilities (vcy_prepare_markov_factored); O(nnz + n) memory."""
+def prepare_markov_factored(indptr, indices, pval, embedding, sigma_D: float, sigma_W: float, compute_dtype=torch.float32,
+                            cull: Optional[bool] = None) -> MarkovFactors:
+    """Factors of the Markov matrix from CSR transition probabilities (vcy_prepare_markov_factored); O(nnz + n) memory.
+    cull: step with the culled Gauss transform (MarkovFactors.enable_culling); None = when the embedding is wider than twice the
+    radius beyond which the kernel is dropped (else every box is in range of every other and the tests only cost)."""
     dev = require_gpu()
     ip = torch.as_tensor(np.ascontiguousarray(indptr, dtype=np.int64)).to(dev) if not isinstance(indptr, torch.Tensor) else indptr.to(dev, torch.int64).contiguous()
     ix = _as_i32(indices, dev)
@@ -1472,8 +1503,15 @@ def prepare_markov_factored(indptr, indices, pval, embedding, sigma_D: float, si
     order = torch.argsort(cols * n + rows)
     colptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     colptr[1:] = torch.cumsum(torch.bincount(cols, minlength=n), 0)
-    return MarkovFactors((ip, ix, pv), emb, sigma_D, sigma_W, colptr, rows[order].to(torch.int32).contiguous(), vals[order].contiguous(),
-                         tot, kw, es, compute_dtype)
+    fac = MarkovFactors((ip, ix, pv), emb, sigma_D, sigma_W, colptr, rows[order].to(torch.int32).contiguous(), vals[order].contiguous(),
+                        tot, kw, es, compute_dtype)
+    if cull is None:
+        cut = 48.0 if compute_dtype == torch.float32 else 72.0
+        extent = float((es.max(0).values - es.min(0).values).max()) if n > 1 else 0.0
+        cull = n >= 4096 and extent > 2.0 * cut ** 0.5
+    if cull:
+        fac.enable_culling()
+    return fac
 
 
 def prepare_markov(indptr, indices, pval, embedding, sigma_D: float, sigma_W: float, dtype=torch.float64) -> torch.Tensor:
