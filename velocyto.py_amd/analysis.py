@@ -523,50 +523,86 @@ class VelocytoLoom(PreprocessMixin):
         self.embedding = embedding
         mode = {"linear": 0, "sqrt": 1, "log": 2, "logratio": 3}[transform]
         kern = {"linear": ops.LINEAR, "sqrt": ops.SQRT, "log": ops.LOG10, "logratio": ops.LINEAR}[transform]
+        # (uploaded before any kernel is queued: a host-to-device copy waits for what is ahead of it in the stream, and the host with it)
+        emb_dev = torch.from_numpy(np.ascontiguousarray(embedding)).to(hi.t.device)
         dmat, e_alt = ops.delta_transform(hi, dS, self.used_delta_t, mode, psc)     # :1538, 1575-1601
         e = e_alt if transform == "logratio" else hi
+        # f32 sqrt with a negligible pseudocount on a matrix of ordinary scale: the three-instruction form (decided from
+        # whole-matrix reductions); `vlm.literal_rule = True` (or VELOCYTO_AMD_LITERAL_RULE=1) keeps the literal rule.
+        # (Decided here - it reads a scalar back - so that nothing below waits for the device before the sampling starts.)
+        rules = ops.partial_rules_for(e, kern, psc, literal=bool(getattr(self, "literal_rule", False))) if knn_random else None
         dmat_r = None
         if calculate_randomized:
             self._set_dev("delta_S_rndm", _permute_rows_nsign(dS, random_seed))     # :1540-1541
             dmat_r, _ = ops.delta_transform(hi, self.dev("delta_S_rndm"), self.used_delta_t, mode, psc)
         # embedding kNN, n_neighbors + 1 nearest (query excluded)                    :1547-1549
-        knn_ix, _ = ops.knn_search(embedding, n_neighbors + 1, include_self=False)
+        knn_ix, _ = ops.knn_search(emb_dev, n_neighbors + 1, include_self=False)
         if knn_random:
             self.corr_calc = "knn_random"
             n_cand = int(knn_ix.shape[1])
             p = np.linspace(sampling_probs[0], sampling_probs[1], n_cand)
             p = p / p.sum()
             size = int(sampled_fraction * (n_neighbors + 1))
-            if device_sampling:
-                # weighted sampling without replacement (Efraimidis-Spirakis keys u^(1/p), top `size`) with torch's device RNG
-                gen = torch.Generator(device=hi.t.device).manual_seed(int(random_seed))
-                keys = torch.log(torch.rand((C, n_cand), generator=gen, device=hi.t.device, dtype=torch.float64)) / \
-                    torch.as_tensor(p, device=hi.t.device)[None, :]
-                picks = torch.topk(keys, size, dim=1).indices
-                sampling_ixs = picks.cpu().numpy()
-            else:
-                # identical numpy legacy-RNG stream to the reference (:1561-1564)
-                sampling_ixs = ops.choice_stream_host(n_cand, size, p, C)
-                picks = torch.from_numpy(sampling_ixs).to(hi.t.device)
-            self.sampling_ixs = sampling_ixs
-            neigh = torch.gather(knn_ix, 1, picks).to(torch.int32).contiguous()       # neigh_ixs[arange(C)[:, None], sampling_ixs]  (:1565)
+            dev = hi.t.device
             self.__dict__.pop("embedding_knn", None)
-            self._neigh = neigh
-            sched = ops.hilbert_order(embedding) if embedding.shape[1] >= 2 else None      # scheduling only: same numbers in any order
+            sched = ops.hilbert_order(emb_dev) if embedding.shape[1] >= 2 else None        # scheduling only: same numbers in any order
             self.__dict__["_embed_order"] = sched
-            # f32 sqrt with a negligible pseudocount on a matrix of ordinary scale: the three-instruction form (decided from
-            # whole-matrix reductions); `vlm.literal_rule = True` (or VELOCYTO_AMD_LITERAL_RULE=1) keeps the literal rule
-            rules = ops.partial_rules_for(e, kern, psc, literal=bool(getattr(self, "literal_rule", False)))
-            if calculate_randomized:
+            corr = torch.empty((C, size), dtype=hi.dtype, device=dev)
+            corr_r = torch.empty((C, size), dtype=hi.dtype, device=dev) if calculate_randomized else None
+
+            def correlate(nb, c0, c1, order, presorted=None):
                 # the reference's two colDeltaCor*partial calls (:1578-1601) share e and the neighbour lists, hence every
                 # A = f(e_i - e_c): one dual-control pass instead of two launches (vcy_coldeltacor_partial_dual)
-                self._corr, self._corr_random = ops.coldeltacor_partial_dual(e, dmat, dmat_r, neigh, kern, rules, psc,
-                                                                             validate=False, order=sched)
+                if size == 0 or c1 == c0:
+                    return
+                if calculate_randomized:
+                    ops.coldeltacor_partial_dual(e, dmat, dmat_r, nb, kern, rules, psc, cell0=c0, order=order, out=corr[c0:c1],
+                                                 out_rndm=corr_r[c0:c1], validate=False, presorted=presorted)
+                else:
+                    ops.coldeltacor_partial(e, dmat, nb, kern, rules, psc, cell0=c0, order=order, out=corr[c0:c1], validate=False,
+                                            presorted=presorted)
+
+            if device_sampling:
+                # weighted sampling without replacement (Efraimidis-Spirakis keys u^(1/p), top `size`) with torch's device RNG
+                gen = torch.Generator(device=dev).manual_seed(int(random_seed))
+                keys = torch.log(torch.rand((C, n_cand), generator=gen, device=dev, dtype=torch.float64)) / \
+                    torch.as_tensor(p, device=dev)[None, :]
+                picks = torch.topk(keys, size, dim=1).indices
+                sampling_ixs = picks.cpu().numpy()
+                neigh = torch.gather(knn_ix, 1, picks).to(torch.int32).contiguous()       # neigh_ixs[arange(C)[:, None], sampling_ixs]  (:1565)
+                correlate(neigh, 0, C, sched)
             else:
-                self._corr = ops.coldeltacor_partial(e, dmat, neigh, kern, rules, psc, validate=False, order=sched)
+                # identical numpy legacy-RNG stream to the reference (:1561-1564), replayed on the host in blocks of cells; the
+                # correlations of a block are launched as soon as its rows are drawn, so the device works through stage D while
+                # the (sequential) replay goes on
+                neigh = torch.empty((C, size), dtype=torch.int32, device=dev)
+                rank = None
+                if sched is not None:
+                    rank = torch.empty(C, dtype=torch.int64, device=dev)
+                    rank[sched.long()] = torch.arange(C, device=dev)
+
+                # a block's rows go up on a side stream: on the current one the copy would queue behind the stage-D launch of the
+                # previous block and hold the replay up until that launch is through
+                copy_stream = torch.cuda.Stream(device=dev)
+
+                def on_block(rows, c0, c1):
+                    with torch.cuda.stream(copy_stream):
+                        picks = torch.from_numpy(rows[c0:c1]).to(dev)
+                    torch.cuda.current_stream().wait_stream(copy_stream)
+                    picks.record_stream(torch.cuda.current_stream())
+                    nb = torch.gather(knn_ix[c0:c1], 1, picks).to(torch.int32).contiguous()
+                    neigh[c0:c1] = nb
+                    # (presorted=False: sampled rows are in draw order; saying so spares the launch wrapper a look at the device)
+                    correlate(nb, c0, c1, None if rank is None else torch.argsort(rank[c0:c1]).to(torch.int32), presorted=False)
+
+                sampling_ixs = ops.choice_stream_host(n_cand, size, p, C, on_block=on_block)
+            self.sampling_ixs = sampling_ixs
+            self._neigh = neigh
+            self._corr = corr
             if ops.corr_fixup(self._corr, neigh, zero_self=True, fix_nan=True, nan_to=1.0):                      # :1604-1607
                 logging.warning("Nans encountered in corrcoef and corrected to 1s. If not identical cells were present it is probably a small isolated cluster converging after imputation.")
             if calculate_randomized:
+                self._corr_random = corr_r
                 if ops.corr_fixup(self._corr_random, neigh, zero_self=True, fix_nan=True, nan_to=1.0):
                     logging.warning("Nans encountered in corrcoef_random and corrected to 1s. If not identical cells were present it is probably a small isolated cluster converging after imputation.")
             else:

@@ -376,11 +376,12 @@ def _as_i32(ixs, dev) -> torch.Tensor:
 TILE_COLS = 256      # widest neighbour list one workgroup of the grouped kernel sorts in LDS (csrc/coldeltacor.hip)
 
 
-def _sorted_rows(ix: torch.Tensor, out: torch.Tensor):
+def _sorted_rows(ix: torch.Tensor, out: torch.Tensor, presorted: Optional[bool] = None):
     """Lists wider than one tile are walked in column tiles; a pair's value does not depend on its column, so the rows are
     sorted by neighbour index first (adjacent cells then meet the same rows in the same tile) and the results are put
-    back in the caller's column order.  Returns (ixs to launch with, (perm, sorted-order buffer) or None, caller's out)."""
-    if ix.shape[1] <= TILE_COLS or bool((ix[:, 1:] >= ix[:, :-1]).all()):
+    back in the caller's column order.  Returns (ixs to launch with, (perm, sorted-order buffer) or None, caller's out).
+    presorted: None = look (reads a flag back: a device sync); True / False = the caller knows (no sync)."""
+    if ix.shape[1] <= TILE_COLS or (bool((ix[:, 1:] >= ix[:, :-1]).all()) if presorted is None else presorted):
         return ix, None, out
     srt, perm = torch.sort(ix, dim=1)
     # the launch buffer starts as the caller's rows in sorted column order: rows the schedule does not name round-trip
@@ -435,7 +436,7 @@ def partial_rules_for(e: CellMatrix, transform: int, psc: float, stats: Optional
 
 def coldeltacor_partial(e: CellMatrix, d: CellMatrix, ixs, transform: int, rules: int = RULES_PARTIAL, psc: float = 0.0,
                         cell0: int = 0, order: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                        d_row0: int = 0, validate: bool = True) -> torch.Tensor:
+                        d_row0: int = 0, validate: bool = True, presorted: Optional[bool] = None) -> torch.Tensor:
     """Compact correlations out[c, n] = corr(cell0 + c, ixs[c, n]); ixs: (C_out, nrndm).
     `d` may hold only the rows of cells d_row0.. (cell-sharded runs); `validate` range-checks ixs
     (a device->host sync; hot loops that built ixs themselves pass False)."""
@@ -454,7 +455,7 @@ def coldeltacor_partial(e: CellMatrix, d: CellMatrix, ixs, transform: int, rules
         assert n_sched <= C_out
         if n_sched == 0:
             return out
-    ix, perm, user_out = _sorted_rows(ix, out)
+    ix, perm, user_out = _sorted_rows(ix, out, presorted)
     _lib.check(_lib.lib().vcy_coldeltacor_partial(e.t.data_ptr(), d.t.data_ptr(), ix.data_ptr(), (out if perm is None else perm[1]).data_ptr(), _p(order),
                                                   e.C, e.G, e.ld, cell0, n_sched, d_row0, nrndm, transform, rules, float(psc),
                                                   e.code, _stream()), "coldeltacor_partial")
@@ -505,7 +506,8 @@ def _sched(order, dev, C_out):
 
 def coldeltacor_partial_dual(e: CellMatrix, d: CellMatrix, d_rndm: CellMatrix, ixs, transform: int, rules: int = RULES_PARTIAL,
                              psc: float = 0.0, cell0: int = 0, order: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                             out_rndm: Optional[torch.Tensor] = None, d_row0: int = 0, validate: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+                             out_rndm: Optional[torch.Tensor] = None, d_row0: int = 0, validate: bool = True,
+                             presorted: Optional[bool] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """(corr, corr_rndm): the real and the randomised-control correlations of a neighbour list in one pass
     (vcy_coldeltacor_partial_dual; analysis.py:1539-1542, 1578-1601)."""
     assert e.ld == d.ld == d_rndm.ld and e.dtype == d.dtype == d_rndm.dtype and e.G == d.G == d_rndm.G and d.C == d_rndm.C
@@ -519,7 +521,7 @@ def coldeltacor_partial_dual(e: CellMatrix, d: CellMatrix, d_rndm: CellMatrix, i
     order, n_sched = _sched(order, e.t.device, C_out)
     if n_sched == 0:
         return out, out_rndm
-    ix, perm, _ = _sorted_rows(ix, out)
+    ix, perm, _ = _sorted_rows(ix, out, presorted)
     perm2 = None if perm is None else out_rndm.gather(1, perm[0])
     _lib.check(_lib.lib().vcy_coldeltacor_partial_dual(e.t.data_ptr(), d.t.data_ptr(), d_rndm.t.data_ptr(), ix.data_ptr(),
                                                        (out if perm is None else perm[1]).data_ptr(), (out_rndm if perm is None else perm2).data_ptr(),
@@ -1042,12 +1044,15 @@ def balance_knn_device_lists(idx: torch.Tensor, dist: torch.Tensor, maxl: int, k
     return got.cpu().numpy(), dsi_new, l
 
 
-def choice_stream_host(n: int, size: int, p: np.ndarray, cells: int, block: int = 4096, pool_factor: float = 1.5) -> np.ndarray:
+def choice_stream_host(n: int, size: int, p: np.ndarray, cells: int, block: int = 4096, pool_factor: float = 1.5,
+                       on_block=None) -> np.ndarray:
     """``np.stack([np.random.choice(n, size=size, replace=False, p=p) for _ in range(cells)])`` - the neighbour sampling of
     estimate_transition_prob (analysis.py:1561-1564) - with the same draws from numpy's global legacy RNG and the same RNG
     state afterwards, without the per-cell trips through RandomState.choice: the uniforms of a block of cells are drawn in one
     call and vcy_choice_stream_host replays choice's rounds over them.  The uniforms of the next block are drawn by a second thread
-    while a block is replayed (both release the GIL); how many a cell takes is measured on a short first block."""
+    while a block is replayed (both release the GIL); how many a cell takes is measured on a short first block.
+    on_block(out, c0, c1), if given, is called as soon as rows [c0, c1) of the result are final (the caller can start device work on
+    them while the replay goes on)."""
     from concurrent.futures import ThreadPoolExecutor
     p = np.ascontiguousarray(p, dtype=np.float64)
     n, size, cells = int(n), int(size), int(cells)
@@ -1087,6 +1092,8 @@ def choice_stream_host(n: int, size: int, p: np.ndarray, cells: int, block: int 
             _lib.check(_lib.lib().vcy_choice_stream_host(pool.ctypes.data, pool.size, p.ctypes.data, n, size, todo, out[done_total:].ctypes.data,
                                                          ctypes.byref(cd), ctypes.byref(used)), "choice_stream")
             pending = pool[used.value:]
+            if on_block is not None and cd.value:
+                on_block(out, done_total, done_total + cd.value)
             done_total += cd.value
             per_cell = (used.value / cd.value * 1.02 + 0.5) if cd.value else per_cell * 2       # measured; nothing fitted: draw more
             if fut is None and done_total < cells:           # the pool fell short on what was planned as the last block
