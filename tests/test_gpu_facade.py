@@ -58,6 +58,31 @@ def test_facade_normalize_impute(vcy, golden, dtype):
     assert vlm.Sx.flags.f_contiguous and vlm.Sx.dtype == np.float64                # layout fact of SURVEY 3.1
     close(vlm.Sx_sz, g["Sx"], rt, at)
     assert np.allclose(np.asarray(vlm.knn_smoothing_w.sum(1)).ravel(), 1)
+
+    def scipy_chain(space, k, diag):                                                # analysis.py:1004-1010 spelled with scipy, as the reference does
+        import warnings
+        knn = vcy.neighbors.knn_distance_matrix(space, k=k, mode="distance")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            conn = (knn > 0).astype(float)
+            conn.setdiag(diag)
+        return knn, vcy.neighbors.connectivity_to_weights(conn)
+
+    def same_csr(a, b):
+        a, b = a.tocsr(), b.tocsr()
+        a.sort_indices(); b.sort_indices()
+        return np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices) and np.array_equal(a.data, b.data)
+    for diag in (1, 0.3):                                                           # the directly written graph / weights are the chain's, to the bit
+        vlm.knn_imputation(k=12, n_pca_dims=10, diag=diag, n_jobs=1)
+        knn_ref, w_ref = scipy_chain(vlm.pcs[:, :10], 12, diag)
+        assert same_csr(vlm.knn, knn_ref) and same_csr(vlm.knn_smoothing_w, w_ref)
+    keep = vlm.pcs.copy()
+    vlm.pcs = keep.copy()
+    vlm.pcs[5] = vlm.pcs[9]                                                         # duplicate cells: a zero distance, the chain itself is used
+    vlm.knn_imputation(k=12, n_pca_dims=10, n_jobs=1)
+    knn_ref, w_ref = scipy_chain(vlm.pcs[:, :10], 12, 1)
+    assert same_csr(vlm.knn, knn_ref) and same_csr(vlm.knn_smoothing_w, w_ref) and vlm.knn_smoothing_w.nnz < 13 * vlm.knn.shape[0]
+    vlm.pcs = keep
     vlm.knn_imputation(k=12, n_pca_dims=10, diag=2.0, maximum=True, n_jobs=1)
     close(vlm.Sx, g["max_Sx"], rt, at)
     close(vlm.Ux, g["max_Ux"], rt, at)

@@ -133,6 +133,28 @@ def test_package_root_mirrors_the_reference_exports():
                                          "_colDeltaCorSqrtpartial", "_colDeltaCorLog10partial"))
 
 
+@pytest.mark.parametrize("n,k,diag", [(50, 7, 1), (200, 30, 1), (200, 30, 0.3), (64, 1, 2.5), (40, 39, 1), (7, 6, 1e-3)])
+def test_weights_written_directly_equal_the_scipy_chain(n, k, diag):
+    """knn_imputation's weights from a graph without zero distances (analysis.py:1006-1010) written out directly
+    (neighbors.weights_from_sorted_knn) against the reference's scipy chain: same structure, same values to the bit."""
+    import warnings
+    from scipy import sparse
+    from velocyto_amd.neighbors import weights_from_sorted_knn, connectivity_to_weights
+    rng = np.random.default_rng(n + k)
+    idx = np.stack([np.sort(rng.choice(np.delete(np.arange(n), c), k, replace=False)) for c in range(n)])
+    dist = rng.random((n, k)) + 0.1
+    perm = np.stack([rng.permutation(k) for _ in range(n)])                          # the reference's graph is nearest-first, not column-sorted
+    knn = sparse.csr_matrix((np.take_along_axis(dist, perm, 1).ravel(), np.take_along_axis(idx, perm, 1).ravel(), np.arange(0, n * k + 1, k)), shape=(n, n))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        conn = (knn > 0).astype(float)
+        conn.setdiag(diag)
+    ref = connectivity_to_weights(conn)
+    ref.sort_indices()
+    got = weights_from_sorted_knn(idx.astype(np.int32), diag)
+    assert np.array_equal(ref.indptr, got.indptr) and np.array_equal(ref.indices, got.indices) and np.array_equal(ref.data, got.data)
+
+
 def _rng_state_equal(a, b):
     return a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
 

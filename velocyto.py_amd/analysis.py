@@ -283,12 +283,26 @@ class VelocytoLoom(PreprocessMixin):
         else:
             if group_constraint is not None:
                 raise ValueError("group_constraint is currently supported only if the argument balanced is set to True")
-            self.knn = knn_distance_matrix(space, metric=metric, k=k, mode="distance", n_jobs=n_jobs)
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            connectivity = (self.knn > 0).astype(float)          # :1006 (also column-sorts self.knn in place, like scipy does there)
-            connectivity.setdiag(diag)
-        self.knn_smoothing_w = connectivity_to_weights(connectivity)
+            self.knn = None
+            if diag != 0:
+                # the graph with its rows sorted by cell number on the device - the state (self.knn > 0) leaves self.knn in, :1006 -
+                # and, when no distance is zero (no duplicate cells), the weights written out directly: the same matrices as the
+                # scipy chain below (tests/test_host_and_abi.py), without its four structure-changing passes over the graph
+                from .neighbors import _kneighbors_device, weights_from_sorted_knn
+                idx_s, dist_s, positive = _kneighbors_device(space, k, metric)
+                n_rows = idx_s.shape[0]
+                self.knn = sparse.csr_matrix((dist_s.ravel(), idx_s.ravel(), np.arange(0, n_rows * k + 1, k)), shape=(n_rows, n_rows))
+                self.knn.has_sorted_indices = True
+                if positive:
+                    self.knn_smoothing_w = weights_from_sorted_knn(idx_s, diag)
+            if self.knn is None:
+                self.knn = knn_distance_matrix(space, metric=metric, k=k, mode="distance", n_jobs=n_jobs)
+        if balanced or diag == 0 or not positive:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                connectivity = (self.knn > 0).astype(float)      # :1006 (also column-sorts self.knn in place, like scipy does there)
+                connectivity.setdiag(diag)
+            self.knn_smoothing_w = connectivity_to_weights(connectivity)
         # schedule the pooling along the Hilbert curve of the two leading coordinates of the search space (results do not
         # depend on it; neighbouring cells gather overlapping rows while they are still in L2)
         self.__dict__["_pool_order"] = ops.hilbert_order(np.ascontiguousarray(space[:, :2])) if np.shape(space)[1] >= 2 else None

@@ -45,6 +45,20 @@ def _kneighbors(data: np.ndarray, k: int, metric: Optional[str], include_self: b
     return dist, idx
 
 
+def _kneighbors_device(data: np.ndarray, k: int, metric: Optional[str]) -> Tuple[np.ndarray, np.ndarray, bool]:
+    """The kNN lists of knn_distance_matrix (query excluded) with every row sorted by cell number: (indices int32 (n, k),
+    distances float64 (n, k), all distances > 0)."""
+    import torch
+    X, corr = _search_space(data, "correlation" if metric == "correlation" else None)
+    idx, dist = ops.knn_search(X, k, include_self=False)
+    if corr:
+        dist = dist * dist / 2.0
+    idx_s, order = torch.sort(idx, dim=1)
+    dist_s = torch.gather(dist, 1, order)
+    positive = bool((dist_s > 0).all())
+    return idx_s.cpu().numpy(), dist_s.cpu().numpy(), positive
+
+
 def knn_distance_matrix(data: np.ndarray, metric: str = None, k: int = 40, mode: str = "connectivity", n_jobs: int = 4
                         ) -> sparse.csr_matrix:
     """neighbors.py:363-376: kNN graph (query excluded), k entries per row, nearest first.
@@ -53,6 +67,35 @@ def knn_distance_matrix(data: np.ndarray, metric: str = None, k: int = 40, mode:
     n = idx.shape[0]
     vals = dist.ravel() if mode == "distance" else np.ones(n * k)
     return sparse.csr_matrix((vals, idx.ravel(), np.arange(0, n * k + 1, k)), shape=(n, n))
+
+
+def weights_from_sorted_knn(idx_sorted: np.ndarray, diag: float) -> sparse.csr_matrix:
+    """What knn_imputation builds from a kNN graph whose distances are all positive (analysis.py:1006-1010):
+        connectivity = (knn > 0).astype(float); connectivity.setdiag(diag); connectivity_to_weights(connectivity)
+    written out for rows given as neighbour lists SORTED by cell number, query excluded (idx_sorted: (cells, k)): every row gets k
+    ones and `diag` on the diagonal, scaled by the reciprocal of (k + diag) - the same values, the same sorted CSR, without four
+    passes of scipy's structure-changing operations over the graph."""
+    idx_sorted = np.asarray(idx_sorted)
+    n, k = idx_sorted.shape
+    me = np.arange(n, dtype=idx_sorted.dtype)[:, None]
+    pos = (idx_sorted < me).sum(1)                                   # where the diagonal goes in the sorted row
+    cols = np.empty((n, k + 1), dtype=np.int32)
+    vals = np.ones((n, k + 1), dtype=np.float64)
+    slot = np.arange(k + 1)[None, :]
+    before = slot < pos[:, None]
+    cols[before] = idx_sorted[before[:, :k]] if k else 0
+    after = slot > pos[:, None]
+    cols[after] = idx_sorted[after[:, 1:]] if k else 0
+    rows = np.arange(n)
+    cols[rows, pos] = rows
+    vals[rows, pos] = diag
+    # scipy's row sum runs over a row in STORED order, and setdiag stores the new diagonal entry after the k ones (the matrix is
+    # only sorted later, by the multiply): (1 + ... + 1) + diag, the ones summing exactly
+    rowsum = np.float64(k) + np.float64(diag)
+    vals = vals * (1.0 / rowsum)
+    w = sparse.csr_matrix((vals.ravel(), cols.ravel(), np.arange(0, n * (k + 1) + 1, k + 1)), shape=(n, n))
+    w.has_sorted_indices = True
+    return w
 
 
 def balance_knn_loop(dsi: np.ndarray, dist: np.ndarray, lsi: np.ndarray, maxl: int, k: int, return_distance: bool) -> Tuple:
