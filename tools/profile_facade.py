@@ -30,4 +30,6 @@ torch.cuda.synchronize()
 pr = cProfile.Profile(); t0 = time.perf_counter(); pr.enable()
 calls[which](); torch.cuda.synchronize()
 pr.disable(); print(which, "wall", time.perf_counter() - t0)
-pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+st = pstats.Stats(pr).sort_stats("cumulative"); st.print_stats(22)
+if os.environ.get("CALLERS"):
+    st.print_callers(os.environ["CALLERS"])

@@ -35,7 +35,8 @@ extern "C" int vcy_choice_stream_host(const double *pool, int64_t pool_len, cons
         positive += p[i] > 0.0;
     }
     VCY_REQUIRE(positive >= size, "choice_stream: Fewer non-zero entries in p than size");
-    constexpr int64_t LUT = 128;                                 // power of two: v * LUT and b / LUT are exact
+    int64_t LUT = 128;                                           // power of two: v * LUT and b / LUT are exact; about two buckets
+    while (LUT < 2 * n && LUT < 4096) LUT *= 2;                  // per entry, so that the scan below is a few entries long
     constexpr int64_t WMAX = 32;                                 // widest bucket the fixed-length scan of round 1 is used for
     std::vector<double> pw((size_t)n), cs((size_t)n), cdf((size_t)n), cdf0((size_t)(n + WMAX), 2.0);     // cdf0 padded with values no draw reaches
     std::vector<int64_t> stamp((size_t)n, -1);
@@ -57,7 +58,7 @@ extern "C" int vcy_choice_stream_host(const double *pool, int64_t pool_len, cons
         for (int64_t i = 0; i < n; ++i) cdf0[(size_t)i] = cdf0[(size_t)i] / total;
         int64_t i = 0;
         for (int64_t b = 0; b < LUT; ++b) {
-            const double edge = (double)b * (1.0 / LUT);
+            const double edge = (double)b / (double)LUT;
             while (cdf0[(size_t)i] <= edge && i < n - 1) ++i;
             lut0[(size_t)b] = (int32_t)i;
         }
