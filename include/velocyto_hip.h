@@ -404,7 +404,7 @@ int vcy_diffuse_step_factored(const double *x, double *y, double *accum, const i
 /* The factored step when K_W is narrow against the extent of the embedding (prepare_markov is usually given a sigma_W of a grid step,
  * analysis.py:1818-1863): terms below 2^-cut of their weight are left out of the Gauss transform.  The caller sorts the cells along a
  * space-filling curve of the embedding: es_sorted (n, edim) = the scaled coordinates of vcy_prepare_markov_factored in that order,
- * rank (n) = position of every cell in it.  vcy_markov_cull_boxes fills `boxes` (vcy_markov_cull_boxes_bytes) with the bounding boxes
+ * rank (n) = position of every cell in it, order (n) = the cell at every position.  vcy_markov_cull_boxes fills `boxes` (vcy_markov_cull_boxes_bytes) with the bounding boxes
  * of runs of 32 consecutive sorted cells; vcy_diffuse_step_factored_culled skips the runs whose box is farther than sqrt(cut) (in the
  * scaled units, where K_W = g exp2(-d^2)) from the box of a workgroup's targets.  Same arguments and result as
  * vcy_diffuse_step_factored otherwise; per target at most n max(x / tot) 2^-cut is dropped (cut 48 / 72 for f32 / f64 compute). */
@@ -412,8 +412,8 @@ size_t vcy_markov_cull_boxes_bytes(int64_t n, int edim, int compute_dtype);
 int vcy_markov_cull_boxes(const void *es_sorted, void *boxes, int64_t n, int edim, int compute_dtype, vcy_stream stream);
 int vcy_diffuse_step_factored_culled(const double *x, double *y, double *accum, const int64_t *colptr, const int32_t *rowidx,
                                      const double *scsc, const double *tot, const double *kw, const void *es_sorted, const int32_t *rank,
-                                     const void *boxes, int edim, double sigma_W, double cut, void *workspace, int64_t n,
-                                     int compute_dtype, vcy_stream stream);
+                                     const int32_t *order, const void *boxes, int edim, double sigma_W, double cut, void *workspace,
+                                     int64_t n, int compute_dtype, vcy_stream stream);
 
 /* ---------------------------------------------------------------- stage F: Diffusion.diffuse step
  * (diffusion.py:93-105): y = x . tr, optionally accum += y (path_integral).  tr dense row-major

@@ -36,7 +36,7 @@ for frac in (0.005, 0.01, 0.02, 0.05, 0.2):
     samp = emb[:: max(1, C // 512)]
     inrange = float((torch.cdist(samp, emb) < radius).double().mean())
     # what the kernel's box tests leave: (256-target block, 32-source chunk) pairs within reach, and how unevenly they fall on workgroups
-    es_s, _, boxes, cut = fac.cull
+    es_s, _, boxes, cut, _ = fac.cull
     nc = (C + 31) // 32
     bx = boxes.view(torch.float32)
     clo, chi = bx[: nc * 2].view(nc, 2), bx[nc * 2: nc * 4].view(nc, 2)

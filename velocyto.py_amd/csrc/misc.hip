@@ -616,11 +616,13 @@ __global__ __launch_bounds__(256) void k_gauss_transform_culled(const CT *__rest
 }
 // y[j] += the folded partials (fixed order); path_integral: accum += y
 __global__ void k_gauss_reduce(const double *__restrict__ part, double *__restrict__ y, double *__restrict__ accum, int n, int nparts,
-                               const int32_t *__restrict__ rank)
+                               const int32_t *__restrict__ order)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const int jj = rank ? rank[j] : j;
+    // order (culled transform): the partials are indexed by position in the sorted order; thread = position, so that the nparts reads
+    // stay coalesced and only the one update of y is scattered
+    const int jj = blockIdx.x * blockDim.x + threadIdx.x;
+    if (jj >= n) return;
+    const int j = order ? order[jj] : jj;
     double s = 0.0;
     for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * n + jj];
     s += y[j];
@@ -812,7 +814,8 @@ static inline int64_t gt_chunks(int64_t n) { return (n + GT_CHUNK - 1) / GT_CHUN
 template <typename CT>
 static int diffuse_step_factored(const double *x, double *y, double *accum, const int64_t *colptr, const int32_t *rowidx, const double *scsc,
                                  const double *tot, const double *kw, const CT *es, int edim, double sigma_W, void *workspace, int64_t n,
-                                 hipStream_t st, const int32_t *rank = nullptr, const CT *boxes = nullptr, double cut = 0.0)
+                                 hipStream_t st, const int32_t *rank = nullptr, const int32_t *order = nullptr, const CT *boxes = nullptr,
+                                 double cut = 0.0)
 {
     double *v = (double *)workspace;
     CT *u = (CT *)(v + n);
@@ -832,7 +835,7 @@ static int diffuse_step_factored(const double *x, double *y, double *accum, cons
         switch (edim) { case 1: VCY_GTC(1); break; case 2: VCY_GTC(2); break; case 3: VCY_GTC(3); break; default: VCY_GTC(4); break; }
 #undef VCY_GTC
         VCY_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_gauss_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double *)part, y, accum, (int)n, nparts, rank);
+        hipLaunchKernelGGL(k_gauss_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double *)part, y, accum, (int)n, nparts, order);
         VCY_LAUNCH_CHECK();
         return VCY_OK;
     }
@@ -844,7 +847,7 @@ static int diffuse_step_factored(const double *x, double *y, double *accum, cons
     default: hipLaunchKernelGGL((k_gauss_transform<CT, 4, 2>), grid, dim3(256), 0, st, es, (const CT *)u, part, (int)n); break;
     }
     VCY_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_gauss_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double *)part, y, accum, (int)n, nparts, rank);
+    hipLaunchKernelGGL(k_gauss_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double *)part, y, accum, (int)n, nparts, order);
     VCY_LAUNCH_CHECK();
     return VCY_OK;
 }
@@ -877,13 +880,13 @@ extern "C" int vcy_markov_cull_boxes(const void *es_sorted, void *boxes, int64_t
 
 extern "C" int vcy_diffuse_step_factored_culled(const double *x, double *y, double *accum, const int64_t *colptr, const int32_t *rowidx,
                                                 const double *scsc, const double *tot, const double *kw, const void *es_sorted,
-                                                const int32_t *rank, const void *boxes, int edim, double sigma_W, double cut, void *workspace,
-                                                int64_t n, int compute_dtype, vcy_stream stream)
+                                                const int32_t *rank, const int32_t *order, const void *boxes, int edim, double sigma_W,
+                                                double cut, void *workspace, int64_t n, int compute_dtype, vcy_stream stream)
 {
-    VCY_REQUIRE(x && y && colptr && rowidx && scsc && tot && kw && es_sorted && rank && boxes && workspace && x != y, "diffuse_step_factored_culled: bad arguments");
+    VCY_REQUIRE(x && y && colptr && rowidx && scsc && tot && kw && es_sorted && rank && order && boxes && workspace && x != y, "diffuse_step_factored_culled: bad arguments");
     VCY_REQUIRE(n > 0 && n < (1ll << 31) && edim > 0 && edim <= 4 && sigma_W > 0 && cut > 0, "diffuse_step_factored_culled: bad arguments");
-    if (compute_dtype == VCY_F32) return diffuse_step_factored<float>(x, y, accum, colptr, rowidx, scsc, tot, kw, (const float *)es_sorted, edim, sigma_W, workspace, n, as_stream(stream), rank, (const float *)boxes, cut);
-    if (compute_dtype == VCY_F64) return diffuse_step_factored<double>(x, y, accum, colptr, rowidx, scsc, tot, kw, (const double *)es_sorted, edim, sigma_W, workspace, n, as_stream(stream), rank, (const double *)boxes, cut);
+    if (compute_dtype == VCY_F32) return diffuse_step_factored<float>(x, y, accum, colptr, rowidx, scsc, tot, kw, (const float *)es_sorted, edim, sigma_W, workspace, n, as_stream(stream), rank, order, (const float *)boxes, cut);
+    if (compute_dtype == VCY_F64) return diffuse_step_factored<double>(x, y, accum, colptr, rowidx, scsc, tot, kw, (const double *)es_sorted, edim, sigma_W, workspace, n, as_stream(stream), rank, order, (const double *)boxes, cut);
     return fail(VCY_ERR_INVALID, "%s: bad dtype", "diffuse_step_factored_culled");
 }
 

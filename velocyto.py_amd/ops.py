@@ -1403,10 +1403,10 @@ def diffuse(x0, tr, n_steps: int, accumulate: bool) -> Tuple[torch.Tensor, Optio
 
         def step(src, dst):
             if tr.cull is not None:
-                es_sorted, rank, boxes, cut = tr.cull
+                es_sorted, rank, boxes, cut, order = tr.cull
                 _lib.check(L.vcy_diffuse_step_factored_culled(src.data_ptr(), dst.data_ptr(), _p(acc), tr.colptr.data_ptr(), tr.rowidx.data_ptr(),
                                                               tr.scsc.data_ptr(), tr.tot.data_ptr(), tr.kw.data_ptr(), es_sorted.data_ptr(), rank.data_ptr(),
-                                                              boxes.data_ptr(), tr.edim, tr.sigma_W, cut, ws.data_ptr(), n, _DT[tr.compute_dtype],
+                                                              order.data_ptr(), boxes.data_ptr(), tr.edim, tr.sigma_W, cut, ws.data_ptr(), n, _DT[tr.compute_dtype],
                                                               _stream()), "diffuse_step_factored_culled")
                 return
             _lib.check(L.vcy_diffuse_step_factored(src.data_ptr(), dst.data_ptr(), _p(acc), tr.colptr.data_ptr(), tr.rowidx.data_ptr(), tr.scsc.data_ptr(),
@@ -1456,7 +1456,7 @@ class MarkovFactors:
         self.colptr, self.rowidx, self.scsc, self.tot, self.kw, self.es, self.compute_dtype = colptr, rowidx, scsc, tot, kw, es, compute_dtype
         self.n, self.edim = int(embedding.shape[0]), int(embedding.shape[1])
         self.shape = (self.n, self.n)
-        self.cull = None                                    # (es_sorted, rank, boxes, cut) of the culled Gauss transform, see enable_culling
+        self.cull = None                                    # (es_sorted, rank, boxes, cut, order) of the culled Gauss transform, see enable_culling
 
     def enable_culling(self, cut: Optional[float] = None) -> "MarkovFactors":
         """Sort the cells along the Hilbert curve of the embedding and box runs of them, so that the steps skip source runs whose
@@ -1475,7 +1475,7 @@ class MarkovFactors:
         code = _DT[self.compute_dtype]
         boxes = torch.empty(int(_lib.lib().vcy_markov_cull_boxes_bytes(self.n, self.edim, code)), dtype=torch.uint8, device=dev)
         _lib.check(_lib.lib().vcy_markov_cull_boxes(es_sorted.data_ptr(), boxes.data_ptr(), self.n, self.edim, code, _stream()), "markov_cull_boxes")
-        self.cull = (es_sorted, rank, boxes, float(cut))
+        self.cull = (es_sorted, rank, boxes, float(cut), order.to(torch.int32).contiguous())
         return self
 
     def dense(self, dtype=torch.float64) -> torch.Tensor:
