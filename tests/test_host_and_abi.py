@@ -187,6 +187,53 @@ def test_choice_stream_host_replays_numpy(lib, n, size, cells, kind):
         assert np.array_equal(np.random.random_sample(3), tail)
 
 
+@pytest.mark.parametrize("n,size,cells,kind,knobs", [
+    (60, 20, 6000, "ramp", {}),                                                  # production settings: 8 workers, chains meet within the slack
+    (60, 20, 3000, "steep", {"VCY_CHOICE_THREADS": "5"}),
+    (40, 1, 4000, "uniform", {}),                                                # one uniform per cell: every chain is the true one
+    (501, 250, 1400, "ramp", {"VCY_CHOICE_THREADS": "2"}),
+    (30, 12, 700, "ramp", {"VCY_CHOICE_MIN_SHARE": "16", "VCY_CHOICE_PREFIX": "8"}),          # many tiny shares
+    (30, 12, 700, "zeros", {"VCY_CHOICE_MIN_SHARE": "16", "VCY_CHOICE_PREFIX": "8", "VCY_CHOICE_SLACK": "0"}),   # no slack: chains are
+    (90, 40, 900, "steep", {"VCY_CHOICE_MIN_SHARE": "40", "VCY_CHOICE_PREFIX": "3", "VCY_CHOICE_SLACK": "1"}),   # continued cell by cell until they meet
+    (30, 12, 300, "ramp", {"VCY_CHOICE_MIN_SHARE": "1", "VCY_CHOICE_PREFIX": "1", "VCY_CHOICE_SLACK": "0", "VCY_CHOICE_THREADS": "64"}),
+])
+def test_choice_stream_parallel_chains_are_the_sequential_stream(lib, monkeypatch, n, size, cells, kind, knobs):
+    """vcy_choice_stream_host splits the cells among threads that replay from GUESSED pool positions and stitches the true chain
+    through the positions the chains share.  Against numpy's own per-cell calls on the same RandomState: every row, the number of
+    uniforms consumed, and the same again when the pool ends early (fewer cells done, never a wrong one)."""
+    import ctypes
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    p = {"ramp": np.linspace(0.5, 0.1, n), "uniform": np.ones(n), "steep": np.geomspace(1.0, 1e-4, n),
+         "zeros": np.where(np.arange(n) % 3 == 0, 0.0, np.linspace(1, 2, n))}[kind]
+    p = p / p.sum()
+    rs = np.random.RandomState(77 + n)
+    want = np.stack([rs.choice(n, size=size, replace=False, p=p) for _ in range(cells)])
+    starts = None
+    probe = np.random.RandomState(77 + n)                                           # how many uniforms those calls took
+    big = probe.random_sample(cells * size * 8 + 64)
+    L = lib.lib()
+    out = np.full((cells, size), -1, dtype=np.int64)
+    cd, used = ctypes.c_int64(0), ctypes.c_int64(0)
+    assert L.vcy_choice_stream_host(big.ctypes.data, big.size, p.ctypes.data, n, size, cells, out.ctypes.data, ctypes.byref(cd), ctypes.byref(used)) == 0
+    assert cd.value == cells and np.array_equal(out, want)
+    check = np.random.RandomState(77 + n)
+    check.random_sample(used.value)
+    assert np.array_equal(check.random_sample(4), rs.random_sample(4))             # consumed exactly what the per-cell calls consumed
+    total = used.value
+    for frac in (0.9, 0.51, 0.05):                                                 # the pool ends inside the stream
+        out2 = np.full((cells, size), -1, dtype=np.int64)
+        cut = int(total * frac)
+        assert L.vcy_choice_stream_host(big.ctypes.data, cut, p.ctypes.data, n, size, cells, out2.ctypes.data, ctypes.byref(cd), ctypes.byref(used)) == 0
+        assert 0 <= cd.value < cells and used.value <= cut
+        assert np.array_equal(out2[: cd.value], want[: cd.value])
+        # the next cell really did not fit: replaying it alone from where the stream stopped runs out of uniforms
+        one = np.full((1, size), -1, dtype=np.int64)
+        cd1, u1 = ctypes.c_int64(0), ctypes.c_int64(0)
+        L.vcy_choice_stream_host(big[used.value:].ctypes.data, cut - used.value, p.ctypes.data, n, size, 1, one.ctypes.data, ctypes.byref(cd1), ctypes.byref(u1))
+        assert cd1.value == 0
+
+
 def test_choice_stream_host_argument_errors(lib):
     from velocyto_amd import ops
     p = np.ones(10) / 10

@@ -1044,7 +1044,7 @@ def balance_knn_device_lists(idx: torch.Tensor, dist: torch.Tensor, maxl: int, k
     return got.cpu().numpy(), dsi_new, l
 
 
-def choice_stream_host(n: int, size: int, p: np.ndarray, cells: int, block: int = 4096, pool_factor: float = 1.5,
+def choice_stream_host(n: int, size: int, p: np.ndarray, cells: int, block: int = 16384, pool_factor: float = 1.5,
                        on_block=None) -> np.ndarray:
     """``np.stack([np.random.choice(n, size=size, replace=False, p=p) for _ in range(cells)])`` - the neighbour sampling of
     estimate_transition_prob (analysis.py:1561-1564) - with the same draws from numpy's global legacy RNG and the same RNG
