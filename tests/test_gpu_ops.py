@@ -470,8 +470,9 @@ def test_permute_rows_nsign_is_a_uniform_independent_shuffle_per_gene(ops, dtype
     for C, G in ((1, 3), (2, 70), (17, 70), (1000, 300), (5000, 70)):
         a = np.stack([rng.permutation(C) + 1.0 for _ in range(G)])          # distinct positive values per gene: the value names its source cell
         m = ops.CellMatrix.from_genes_major(a, dtype)
-        out = ops.permute_rows_nsign(m, 15071990)
+        out = ops.permute_rows_nsign(m, 15071990, gene_major=False)
         assert torch.all(out.t[:, G:] == 0)                                 # padding columns of the layout
+        assert torch.equal(ops.permute_rows_nsign(m, 15071990, gene_major=True).t, out.t)    # the gene-major route: the same shuffle
         o = out.to_genes_major()
         np.testing.assert_array_equal(np.sort(np.abs(o), 1), np.sort(a, 1))
         np.testing.assert_array_equal(ops.permute_rows_nsign(m, 15071990).to_genes_major(), o)

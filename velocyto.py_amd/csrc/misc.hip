@@ -98,6 +98,25 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
+__device__ __forceinline__ uint32_t perm_key(uint32_t seed_lo, uint32_t seed_hi, int g) { return mix32(seed_lo ^ mix32((uint32_t)g * 0x9e3779b9u + seed_hi)); }
+__device__ __forceinline__ uint32_t perm_cell(uint32_t c, uint32_t key, int hb, uint32_t C)
+{
+    const uint32_t mask = (1u << hb) - 1u;
+    uint32_t x = c;
+    do {
+        uint32_t L = x >> hb, R = x & mask;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const uint32_t t = L ^ (mix32(R + key + (uint32_t)r * 0x85ebca6bu) & mask);
+            L = R;
+            R = t;
+        }
+        x = (L << hb) | R;
+    } while (x >= C);
+    return x;
+}
+__device__ __forceinline__ uint32_t perm_sign(uint32_t c, uint32_t key) { return mix32(key ^ (c * 0xc2b2ae35u + 0x27d4eb2fu)) >> 31; }
+
 template <typename T, int CPT>
 __global__ __launch_bounds__(256) void k_permute_rows_nsign(const T *__restrict__ in, T *__restrict__ out, int C, int G, int64_t ld,
                                                              uint32_t seed_lo, uint32_t seed_hi, int hb)
@@ -109,30 +128,42 @@ __global__ __launch_bounds__(256) void k_permute_rows_nsign(const T *__restrict_
         for (int c = c0; c < min(C, c0 + CPT); ++c) out[(int64_t)c * ld + g] = T(0);
         return;
     }
-    const uint32_t key = mix32(seed_lo ^ mix32((uint32_t)g * 0x9e3779b9u + seed_hi));
-    const uint32_t mask = (1u << hb) - 1u;
+    const uint32_t key = perm_key(seed_lo, seed_hi, g);
     T v[CPT];
     uint32_t sg[CPT];
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
         const int c = min(c0 + i, C - 1);
-        uint32_t x = (uint32_t)c;
-        do {
-            uint32_t L = x >> hb, R = x & mask;
-#pragma unroll
-            for (int r = 0; r < 5; ++r) {
-                const uint32_t t = L ^ (mix32(R + key + (uint32_t)r * 0x85ebca6bu) & mask);
-                L = R;
-                R = t;
-            }
-            x = (L << hb) | R;
-        } while (x >= (uint32_t)C);
-        v[i] = in[(int64_t)x * ld + g];
-        sg[i] = mix32(key ^ ((uint32_t)c * 0xc2b2ae35u + 0x27d4eb2fu)) >> 31;
+        v[i] = in[(int64_t)perm_cell((uint32_t)c, key, hb, (uint32_t)C) * ld + g];
+        sg[i] = perm_sign((uint32_t)c, key);
     }
 #pragma unroll
     for (int i = 0; i < CPT; ++i)
         if (c0 + i < C) out[(int64_t)(c0 + i) * ld + g] = sg[i] ? -v[i] : v[i];
+}
+
+// The same shuffle on a GENE-MAJOR copy (G, C): a gene's values are contiguous, so the gather stays inside one 4 C-byte row that
+// lives in L2 - the cell-major gather above moves a 64-byte sector per 4-byte value (96 GB for a 6 GB matrix, 33 ms); two tiled
+// transposes and this kernel move 36 GB.  Lanes = consecutive cells of one gene.
+template <typename T, int CPT>
+__global__ __launch_bounds__(256) void k_permute_within_gene_rows(const T *__restrict__ in, T *__restrict__ out, int C, uint32_t seed_lo,
+                                                                   uint32_t seed_hi, int hb)
+{
+    const int g = blockIdx.y;
+    const uint32_t key = perm_key(seed_lo, seed_hi, g);
+    const T *row = in + (int64_t)g * C;
+    T *orow = out + (int64_t)g * C;
+    const int c0 = blockIdx.x * 256 * CPT + threadIdx.x;
+    T v[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = min(c0 + i * 256, C - 1);
+        const T x = row[perm_cell((uint32_t)c, key, hb, (uint32_t)C)];
+        v[i] = perm_sign((uint32_t)c, key) ? -x : x;
+    }
+#pragma unroll
+    for (int i = 0; i < CPT; ++i)
+        if (c0 + i * 256 < C) orow[c0 + i * 256] = v[i];
 }
 
 // np.fill_diagonal(corrcoef, 0); corrcoef[isnan] = nan_to   (analysis.py:1604-1606) on the compact form
@@ -671,17 +702,37 @@ extern "C" int vcy_delta_transform(const void *hi_dim, const void *delta_S, void
     return VCY_OK;
 }
 
-extern "C" int vcy_permute_rows_nsign(const void *in, void *out, int64_t C, int64_t G, int64_t ld, uint64_t seed, int dtype, vcy_stream stream)
+extern "C" size_t vcy_permute_rows_nsign_workspace_bytes(int64_t C, int64_t G, int dtype)
 {
-    VCY_REQUIRE(in && out && in != out && C > 0 && G > 0 && ld >= G && C < (1ll << 30), "permute_rows_nsign: bad arguments");
+    if (C <= 0 || G <= 0) return 0;
+    return (size_t)2 * (size_t)C * (size_t)G * (dtype == VCY_F64 ? 8 : 4);
+}
+
+extern "C" int vcy_permute_rows_nsign(const void *in, void *out, void *workspace, int64_t C, int64_t G, int64_t ld, uint64_t seed, int dtype,
+                                      vcy_stream stream)
+{
+    VCY_REQUIRE(in && out && in != out && C > 0 && G > 0 && ld >= G && C < (1ll << 30) && G < 65536ll * 256, "permute_rows_nsign: bad arguments");
+    VCY_REQUIRE(dtype == VCY_F32 || dtype == VCY_F64, "permute_rows_nsign: bad dtype");
     int hb = 1;
     while ((1ll << (2 * hb)) < C) ++hb;                      // 4^hb >= C: at most 4 walks per cell on average, 1.3 at 50 000
+    const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+    hipStream_t st = as_stream(stream);
+    if (workspace && G <= 65535) {                            // gene-major route: transpose, shuffle inside the rows, transpose back
+        const size_t half = (size_t)C * (size_t)G * (dtype == VCY_F64 ? 8 : 4);
+        void *A = workspace, *B = (char *)workspace + half;
+        int rc = vcy_transpose(in, A, C, G, ld, C, dtype, dtype, stream);
+        if (rc) return rc;
+        constexpr int CPT = 4;
+        const dim3 grid((unsigned)((C + 256 * CPT - 1) / (256 * CPT)), (unsigned)G);
+        if (dtype == VCY_F32) hipLaunchKernelGGL((k_permute_within_gene_rows<float, CPT>), grid, dim3(256), 0, st, (const float *)A, (float *)B, (int)C, lo, hi, hb);
+        else hipLaunchKernelGGL((k_permute_within_gene_rows<double, CPT>), grid, dim3(256), 0, st, (const double *)A, (double *)B, (int)C, lo, hi, hb);
+        VCY_LAUNCH_CHECK();
+        return vcy_transpose(B, out, G, C, C, ld, dtype, dtype, stream);
+    }
     constexpr int CPT = 8;
     const dim3 grid((unsigned)((ld + 255) / 256), (unsigned)((C + CPT - 1) / CPT));
-    const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
-    if (dtype == VCY_F32) hipLaunchKernelGGL((k_permute_rows_nsign<float, CPT>), grid, dim3(256), 0, as_stream(stream), (const float *)in, (float *)out, (int)C, (int)G, ld, lo, hi, hb);
-    else if (dtype == VCY_F64) hipLaunchKernelGGL((k_permute_rows_nsign<double, CPT>), grid, dim3(256), 0, as_stream(stream), (const double *)in, (double *)out, (int)C, (int)G, ld, lo, hi, hb);
-    else return fail(VCY_ERR_INVALID, "%s: bad dtype", "permute_rows_nsign");
+    if (dtype == VCY_F32) hipLaunchKernelGGL((k_permute_rows_nsign<float, CPT>), grid, dim3(256), 0, st, (const float *)in, (float *)out, (int)C, (int)G, ld, lo, hi, hb);
+    else hipLaunchKernelGGL((k_permute_rows_nsign<double, CPT>), grid, dim3(256), 0, st, (const double *)in, (double *)out, (int)C, (int)G, ld, lo, hi, hb);
     VCY_LAUNCH_CHECK();
     return VCY_OK;
 }

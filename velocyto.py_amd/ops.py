@@ -1321,13 +1321,20 @@ def delta_transform(hi_dim: CellMatrix, delta_S: CellMatrix, used_dt: float, mod
     return dm, eo
 
 
-def permute_rows_nsign(delta_S: CellMatrix, seed: int) -> CellMatrix:
+def permute_rows_nsign(delta_S: CellMatrix, seed: int, gene_major: Optional[bool] = None) -> CellMatrix:
     """The randomised control's delta_S (analysis.py:2407-2420): per gene, the values shuffled across the cells by an independent
     pseudo-random permutation and multiplied by independent random signs (vcy_permute_rows_nsign; a function of (seed, gene, cell),
-    statistical parity with the reference's numba stream)."""
+    statistical parity with the reference's numba stream).  gene_major: shuffle on a gene-major copy (two matrix-sized scratch
+    buffers, three streaming passes) instead of one gather with a sector per value; None = when the matrix is large and the scratch
+    fits in the free memory.  Same result either way."""
+    L = _lib.lib()
     out = CellMatrix(torch.empty_like(delta_S.t), delta_S.G)
-    _lib.check(_lib.lib().vcy_permute_rows_nsign(delta_S.t.data_ptr(), out.t.data_ptr(), delta_S.C, delta_S.G, delta_S.ld, int(seed) & (2**64 - 1),
-                                                 delta_S.code, _stream()), "permute_rows_nsign")
+    need = int(L.vcy_permute_rows_nsign_workspace_bytes(delta_S.C, delta_S.G, delta_S.code))
+    if gene_major is None:
+        gene_major = delta_S.C * delta_S.G >= (1 << 24) and delta_S.G <= 65535 and torch.cuda.mem_get_info(delta_S.t.device)[0] > 2 * need
+    ws = torch.empty(need, dtype=torch.uint8, device=delta_S.t.device) if gene_major else None
+    _lib.check(L.vcy_permute_rows_nsign(delta_S.t.data_ptr(), out.t.data_ptr(), _p(ws), delta_S.C, delta_S.G, delta_S.ld, int(seed) & (2**64 - 1),
+                                        delta_S.code, _stream()), "permute_rows_nsign")
     return out
 
 
