@@ -357,12 +357,13 @@ int vcy_delta_transform(const void *hi_dim, const void *delta_S, void *dmat, voi
 /* permute_rows_nsign (analysis.py:2407-2420, called at :1540-1541 for the randomised control): out[c, g] = +- in[pi_g(c), g] with
  * an independent pseudo-random permutation pi_g of the cells and independent random signs per gene, both functions of (seed, g).
  * The reference draws them from numba's RNG stream: statistical parity, not the same numbers.  in != out; padding columns of out
- * are zeroed.  workspace (optional, vcy_permute_rows_nsign_workspace_bytes = two gene-major copies): the shuffle runs on a
- * gene-major copy, where a gene's values are contiguous - three passes over the matrix instead of a 64-byte sector per value;
+ * are zeroed.  workspace_a / workspace_b (optional, both or neither; vcy_permute_rows_nsign_workspace_bytes each - any two
+ * buffers of a matrix's size will do, e.g. the ones the caller is about to fill with the two dmat transforms): the shuffle runs on
+ * a gene-major copy, where a gene's values are contiguous - three passes over the matrix instead of a 64-byte sector per value;
  * NULL: one gather on the cell-major matrix.  Same result either way.                           */
 size_t vcy_permute_rows_nsign_workspace_bytes(int64_t C, int64_t G, int dtype);
-int vcy_permute_rows_nsign(const void *in, void *out, void *workspace, int64_t C, int64_t G, int64_t ld, uint64_t seed, int dtype,
-                           vcy_stream stream);
+int vcy_permute_rows_nsign(const void *in, void *out, void *workspace_a, void *workspace_b, int64_t C, int64_t G, int64_t ld,
+                           uint64_t seed, int dtype, vcy_stream stream);
 /* np.fill_diagonal(corrcoef, 0) and corrcoef[isnan] = nan_to (analysis.py:1604-1612, 1666-1668) on
  * the compact (C_out, nrndm) form; nan_count (device int, may be NULL) counts the NaNs seen.  */
 int vcy_corr_fixup(void *vals, const int32_t *ixs, int64_t cell0, int64_t C_out, int64_t nrndm, int zero_self, int fix_nan,

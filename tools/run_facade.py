@@ -15,7 +15,8 @@ def timed(name, fn, *a, **k):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     r = fn(*a, **k)
     torch.cuda.synchronize()
-    print(f"{name:32s} {1e3*(time.perf_counter()-t0):10.1f} ms", flush=True)
+    mem = f"   [{torch.cuda.memory_allocated() / 2**30:6.1f} GiB in use, {torch.cuda.memory_reserved() / 2**30:6.1f} reserved]" if os.environ.get("MEM") else ""
+    print(f"{name:32s} {1e3*(time.perf_counter()-t0):10.1f} ms{mem}", flush=True)
     return r
 
 if os.environ.get("PRE", "1") == "1":
@@ -37,15 +38,21 @@ if os.environ.get("PRE", "1") == "1":
 
 vlm = vcy.analysis.VelocytoLoom.from_arrays(S, U)       # device matrices go in as they are
 vlm.pcs = pcs.cpu().numpy(); vlm.ts = vlm.pcs[:, :2].copy()
-timed("normalize", vlm.normalize, "both")
-timed("knn_imputation(k=30)", vlm.knn_imputation, k=30, n_pca_dims=30)
-timed("knn_imputation(balanced)", vlm.knn_imputation, k=30, n_pca_dims=30, balanced=True, b_sight=240, b_maxl=120)
-timed("fit_gammas(default)", vlm.fit_gammas)
-timed("fit_gammas(plain)", vlm.fit_gammas, fit_offset=False, weighted=False)
-timed("predict_U", vlm.predict_U); timed("calculate_velocity", vlm.calculate_velocity)
-timed("calculate_shift", vlm.calculate_shift); timed("extrapolate_cell_at_t", vlm.extrapolate_cell_at_t)
-timed("estimate_transition_prob", vlm.estimate_transition_prob, hidim="Sx_sz", embed="ts", n_neighbors=500, sampled_fraction=0.5)
-timed("calculate_embedding_shift", vlm.calculate_embedding_shift)
-timed("prepare_markov", vlm.prepare_markov, 2.0, 4.0)
-timed("run_markov(2500)", vlm.run_markov)
-print("total", time.perf_counter() - t_all, "s;  delta_embedding[:2] =", vlm.delta_embedding[:2])
+for _pass in range(int(os.environ.get("PASSES", 1))):          # PASSES=2: the second pass is the steady state (buffers come from the allocator's cache)
+    if _pass:
+        print(f"-- pass {_pass + 1}")
+        t_all = time.perf_counter()
+    timed("normalize", vlm.normalize, "both")
+    timed("knn_imputation(k=30)", vlm.knn_imputation, k=30, n_pca_dims=30)
+    timed("knn_imputation(balanced)", vlm.knn_imputation, k=30, n_pca_dims=30, balanced=True, b_sight=240, b_maxl=120)
+    timed("fit_gammas(default)", vlm.fit_gammas)
+    timed("fit_gammas(plain)", vlm.fit_gammas, fit_offset=False, weighted=False)
+    timed("predict_U", vlm.predict_U)
+    timed("calculate_velocity", vlm.calculate_velocity)
+    timed("calculate_shift", vlm.calculate_shift)
+    timed("extrapolate_cell_at_t", vlm.extrapolate_cell_at_t)
+    timed("estimate_transition_prob", vlm.estimate_transition_prob, hidim="Sx_sz", embed="ts", n_neighbors=500, sampled_fraction=0.5)
+    timed("calculate_embedding_shift", vlm.calculate_embedding_shift)
+    timed("prepare_markov", vlm.prepare_markov, 2.0, 4.0)
+    timed("run_markov(2500)", vlm.run_markov)
+    print("total", time.perf_counter() - t_all, "s;  delta_embedding[:2] =", vlm.delta_embedding[:2])

@@ -83,7 +83,7 @@ SIGNATURES = {
     "vcy_scale_log": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_dbl, c_int, c_int, c_vp]),
     "vcy_delta_transform": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_dbl, c_int, c_dbl, c_int, c_vp]),
     "vcy_permute_rows_nsign_workspace_bytes": (c_sz, [c_i64, c_i64, c_int]),
-    "vcy_permute_rows_nsign": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, ctypes.c_uint64, c_int, c_vp]),
+    "vcy_permute_rows_nsign": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, ctypes.c_uint64, c_int, c_vp]),
     "vcy_corr_fixup": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_dbl, c_vp, c_int, c_vp]),
     "vcy_transition_prob": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_dbl, c_int, c_vp]),
     "vcy_row_cosproj": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]),

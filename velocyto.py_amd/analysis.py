@@ -539,16 +539,24 @@ class VelocytoLoom(PreprocessMixin):
         kern = {"linear": ops.LINEAR, "sqrt": ops.SQRT, "log": ops.LOG10, "logratio": ops.LINEAR}[transform]
         # (uploaded before any kernel is queued: a host-to-device copy waits for what is ahead of it in the stream, and the host with it)
         emb_dev = torch.from_numpy(np.ascontiguousarray(embedding)).to(hi.t.device)
-        dmat, e_alt = ops.delta_transform(hi, dS, self.used_delta_t, mode, psc)     # :1538, 1575-1601
-        e = e_alt if transform == "logratio" else hi
         # f32 sqrt with a negligible pseudocount on a matrix of ordinary scale: the three-instruction form (decided from
         # whole-matrix reductions); `vlm.literal_rule = True` (or VELOCYTO_AMD_LITERAL_RULE=1) keeps the literal rule.
-        # (Decided here - it reads a scalar back - so that nothing below waits for the device before the sampling starts.)
-        rules = ops.partial_rules_for(e, kern, psc, literal=bool(getattr(self, "literal_rule", False))) if knn_random else None
+        # (Decided before anything is queued - it reads a scalar back - so that the host does not wait for the device on its way to
+        # the sampling; for logratio the matrix it looks at is only made below.)
+        literal = bool(getattr(self, "literal_rule", False))
+        rules = ops.partial_rules_for(hi, kern, psc, literal=literal) if knn_random and transform != "logratio" else None
+        dmat_buf = dmat_r_buf = None
+        if calculate_randomized:
+            # the randomised control first (:1540-1541): its gene-major shuffle borrows the two buffers the transforms below fill
+            dmat_buf, dmat_r_buf = (CellMatrix(torch.empty_like(hi.t), hi.G) for _ in range(2))
+            self._set_dev("delta_S_rndm", _permute_rows_nsign(dS, random_seed, scratch=(dmat_buf.t, dmat_r_buf.t)))
+        dmat, e_alt = ops.delta_transform(hi, dS, self.used_delta_t, mode, psc, out=dmat_buf)     # :1538, 1575-1601
+        e = e_alt if transform == "logratio" else hi
+        if knn_random and rules is None:
+            rules = ops.partial_rules_for(e, kern, psc, literal=literal)
         dmat_r = None
         if calculate_randomized:
-            self._set_dev("delta_S_rndm", _permute_rows_nsign(dS, random_seed))     # :1540-1541
-            dmat_r, _ = ops.delta_transform(hi, self.dev("delta_S_rndm"), self.used_delta_t, mode, psc)
+            dmat_r, _ = ops.delta_transform(hi, self.dev("delta_S_rndm"), self.used_delta_t, mode, psc, out=dmat_r_buf)
         # embedding kNN, n_neighbors + 1 nearest (query excluded)                    :1547-1549
         knn_ix, _ = ops.knn_search(emb_dev, n_neighbors + 1, include_self=False)
         if knn_random:
@@ -880,10 +888,10 @@ def _fill_diagonal_zero(m: torch.Tensor) -> None:
     m.diagonal().zero_()
 
 
-def _permute_rows_nsign(dS: CellMatrix, seed: int) -> CellMatrix:
+def _permute_rows_nsign(dS: CellMatrix, seed: int, scratch=None) -> CellMatrix:
     """analysis.py:2407-2420: per gene, shuffle the values across cells and flip signs at random (the reference uses numba's RNG
-    stream: statistical parity only).  One gather on the device, ops.permute_rows_nsign."""
-    return ops.permute_rows_nsign(dS, seed)
+    stream: statistical parity only).  On the device, ops.permute_rows_nsign."""
+    return ops.permute_rows_nsign(dS, seed, scratch=scratch)
 
 
 def gaussian_kernel(X: np.ndarray, mu: float = 0, sigma: float = 1) -> np.ndarray:

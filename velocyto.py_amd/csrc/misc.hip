@@ -705,21 +705,22 @@ extern "C" int vcy_delta_transform(const void *hi_dim, const void *delta_S, void
 extern "C" size_t vcy_permute_rows_nsign_workspace_bytes(int64_t C, int64_t G, int dtype)
 {
     if (C <= 0 || G <= 0) return 0;
-    return (size_t)2 * (size_t)C * (size_t)G * (dtype == VCY_F64 ? 8 : 4);
+    return (size_t)C * (size_t)G * (dtype == VCY_F64 ? 8 : 4);
 }
 
-extern "C" int vcy_permute_rows_nsign(const void *in, void *out, void *workspace, int64_t C, int64_t G, int64_t ld, uint64_t seed, int dtype,
-                                      vcy_stream stream)
+extern "C" int vcy_permute_rows_nsign(const void *in, void *out, void *workspace_a, void *workspace_b, int64_t C, int64_t G, int64_t ld,
+                                      uint64_t seed, int dtype, vcy_stream stream)
 {
+    VCY_REQUIRE((workspace_a == nullptr) == (workspace_b == nullptr) && (!workspace_a || (workspace_a != workspace_b && workspace_a != in && workspace_b != in &&
+                workspace_a != out && workspace_b != out)), "permute_rows_nsign: the two scratch buffers go together and are distinct from in / out");
     VCY_REQUIRE(in && out && in != out && C > 0 && G > 0 && ld >= G && C < (1ll << 30) && G < 65536ll * 256, "permute_rows_nsign: bad arguments");
     VCY_REQUIRE(dtype == VCY_F32 || dtype == VCY_F64, "permute_rows_nsign: bad dtype");
     int hb = 1;
     while ((1ll << (2 * hb)) < C) ++hb;                      // 4^hb >= C: at most 4 walks per cell on average, 1.3 at 50 000
     const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
     hipStream_t st = as_stream(stream);
-    if (workspace && G <= 65535) {                            // gene-major route: transpose, shuffle inside the rows, transpose back
-        const size_t half = (size_t)C * (size_t)G * (dtype == VCY_F64 ? 8 : 4);
-        void *A = workspace, *B = (char *)workspace + half;
+    if (workspace_a && G <= 65535) {                          // gene-major route: transpose, shuffle inside the rows, transpose back
+        void *A = workspace_a, *B = workspace_b;
         int rc = vcy_transpose(in, A, C, G, ld, C, dtype, dtype, stream);
         if (rc) return rc;
         constexpr int CPT = 4;

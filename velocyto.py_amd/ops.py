@@ -1310,10 +1310,12 @@ def scale_log(M: CellMatrix, factor: Optional[torch.Tensor], want_sz: bool = Tru
     return sz, nm
 
 
-def delta_transform(hi_dim: CellMatrix, delta_S: CellMatrix, used_dt: float, mode: int, psc: float) -> Tuple[CellMatrix, Optional[CellMatrix]]:
+def delta_transform(hi_dim: CellMatrix, delta_S: CellMatrix, used_dt: float, mode: int, psc: float,
+                    out: Optional[CellMatrix] = None) -> Tuple[CellMatrix, Optional[CellMatrix]]:
     """dmat (and e = log2(hi_dim + psc) for mode 3 = logratio) from a stored delta_S."""
     assert hi_dim.t.shape == delta_S.t.shape and hi_dim.dtype == delta_S.dtype
-    dm = CellMatrix(torch.empty_like(hi_dim.t), hi_dim.G)
+    assert out is None or (out.t.shape == hi_dim.t.shape and out.dtype == hi_dim.dtype and out.t.is_contiguous())
+    dm = CellMatrix(torch.empty_like(hi_dim.t), hi_dim.G) if out is None else out
     eo = CellMatrix(torch.empty_like(hi_dim.t), hi_dim.G) if mode == 3 else None
     _lib.check(_lib.lib().vcy_delta_transform(hi_dim.t.data_ptr(), delta_S.t.data_ptr(), dm.t.data_ptr(), None if eo is None else eo.t.data_ptr(),
                                               hi_dim.C, hi_dim.G, hi_dim.ld, float(used_dt), int(mode), float(psc), hi_dim.code, _stream()),
@@ -1321,20 +1323,27 @@ def delta_transform(hi_dim: CellMatrix, delta_S: CellMatrix, used_dt: float, mod
     return dm, eo
 
 
-def permute_rows_nsign(delta_S: CellMatrix, seed: int, gene_major: Optional[bool] = None) -> CellMatrix:
+def permute_rows_nsign(delta_S: CellMatrix, seed: int, gene_major: Optional[bool] = None,
+                       scratch: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> CellMatrix:
     """The randomised control's delta_S (analysis.py:2407-2420): per gene, the values shuffled across the cells by an independent
     pseudo-random permutation and multiplied by independent random signs (vcy_permute_rows_nsign; a function of (seed, gene, cell),
     statistical parity with the reference's numba stream).  gene_major: shuffle on a gene-major copy (two matrix-sized scratch
     buffers, three streaming passes) instead of one gather with a sector per value; None = when the matrix is large and the scratch
-    fits in the free memory.  Same result either way."""
+    is given or fits in the free memory.  scratch: two device buffers of at least the matrix's size to use for it (their contents
+    are destroyed) - e.g. the buffers the caller is about to fill anyway.  Same result either way."""
     L = _lib.lib()
     out = CellMatrix(torch.empty_like(delta_S.t), delta_S.G)
     need = int(L.vcy_permute_rows_nsign_workspace_bytes(delta_S.C, delta_S.G, delta_S.code))
+    if scratch is not None:
+        assert all(t.is_contiguous() and t.numel() * t.element_size() >= need and t.device == delta_S.t.device for t in scratch)
     if gene_major is None:
-        gene_major = delta_S.C * delta_S.G >= (1 << 24) and delta_S.G <= 65535 and torch.cuda.mem_get_info(delta_S.t.device)[0] > 2 * need
-    ws = torch.empty(need, dtype=torch.uint8, device=delta_S.t.device) if gene_major else None
-    _lib.check(L.vcy_permute_rows_nsign(delta_S.t.data_ptr(), out.t.data_ptr(), _p(ws), delta_S.C, delta_S.G, delta_S.ld, int(seed) & (2**64 - 1),
-                                        delta_S.code, _stream()), "permute_rows_nsign")
+        gene_major = delta_S.C * delta_S.G >= (1 << 24) and delta_S.G <= 65535 and \
+            (scratch is not None or torch.cuda.mem_get_info(delta_S.t.device)[0] > 4 * need)
+    a = b = None
+    if gene_major:
+        a, b = scratch if scratch is not None else (torch.empty(need, dtype=torch.uint8, device=delta_S.t.device) for _ in range(2))
+    _lib.check(L.vcy_permute_rows_nsign(delta_S.t.data_ptr(), out.t.data_ptr(), _p(a), _p(b), delta_S.C, delta_S.G, delta_S.ld,
+                                        int(seed) & (2**64 - 1), delta_S.code, _stream()), "permute_rows_nsign")
     return out
 
 
@@ -1380,9 +1389,15 @@ def _run_steps(step, x: torch.Tensor, y: torch.Tensor, n_steps: int) -> torch.Te
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             step(x, y); step(y, x)                      # warm-up outside capture
+            # captured by hand: the torch.cuda.graph context empties the caching allocator on entry, and every later method of
+            # the pipeline would then pay for fresh device allocations (24 GB for the next normalize: 0.5 s); the steps allocate
+            # nothing, so there is no pool to keep tidy
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
+            graph.capture_begin()
+            try:
                 step(x, y); step(y, x)
+            finally:
+                graph.capture_end()
         torch.cuda.current_stream().wait_stream(side)
         done = 2
         for _ in range((n_steps - done) // 2):
