@@ -165,7 +165,10 @@ def test_size_normalisations(vcy, golden, dtype):
     # the pooling fast path must see the rescaled U_sz (factor * counts with the adjusted factor)
     va.pcs = g["pcs"]
     va.knn_imputation(n_pca_dims=8, k=10, balanced=True, b_sight=80, b_maxl=40, n_jobs=1)
+    assert va.dev("Sx_sz") is va.dev("Sx") and va.dev("Ux_sz") is va.dev("Ux")      # one matrix under both names after the pooling ...
+    sx_before = va.Sx.copy()
     va.normalize_median()
+    assert va.dev("Sx_sz") is not va.dev("Sx") and np.array_equal(va.Sx, sx_before)   # ... until one of them is rescaled: Sx keeps its values
     close(va.Sx_sz, g["nm_Sx_sz"], max(rt, 1e-9), max(at, 1e-9))
     close(va.Ux_sz, g["nm_Ux_sz"], max(rt, 2e-6), max(at, 1e-9))                 # pooled from the SVR-adjusted U_sz
     ve = deepcopy(va)

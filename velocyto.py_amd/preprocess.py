@@ -426,6 +426,9 @@ class PreprocessMixin:
         """M[:, c] *= factor[c] on the device (in a new matrix when `name` is new)."""
         f = torch.as_tensor(np.asarray(factor, dtype=np.float64), device=self.dev(name).t.device)
         M = self.dev(name)
+        if any(k != name and v is M for k, v in self._dev.items()):      # shared with another attribute (Sx_sz is Sx after knn_imputation)
+            M = CellMatrix(M.t.clone(), M.G)
+            self._dev[name] = M
         M.t.mul_(f[:, None].to(M.dtype))
         self._host.pop(name, None)
         sc = self.__dict__.get("_sz_scale", {})
