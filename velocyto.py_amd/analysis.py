@@ -549,6 +549,8 @@ class VelocytoLoom(PreprocessMixin):
         literal = bool(getattr(self, "literal_rule", False))
         rules = ops.partial_rules_for(hi, kern, psc, literal=literal) if knn_random and transform != "logratio" else None
         dmat_buf = dmat_r_buf = None
+        self._dev.pop("delta_S_rndm", None)                       # a previous control goes back to the allocator before the new one is made
+        self._host.pop("delta_S_rndm", None)
         if calculate_randomized:
             # the randomised control first (:1540-1541): its gene-major shuffle borrows the two buffers the transforms below fill
             dmat_buf, dmat_r_buf = (CellMatrix(torch.empty_like(hi.t), hi.G) for _ in range(2))
