@@ -89,6 +89,17 @@ def test_facade_normalize_impute(vcy, golden, dtype):
     vlm.knn_imputation(k=12, n_pca_dims=10, balanced=True, b_sight=48, b_maxl=20, n_jobs=1)
     close(vlm.Sx, g["bal_Sx"], rt, at)
     close(vlm.Ux, g["bal_Ux"], rt, at)
+    # the balanced graph and its weights, written out directly, against the reference's chain on the same balanced lists
+    import warnings
+    bk = vcy.neighbors.BalancedKNN(k=12, sight_k=48, maxl=20, mode="distance")
+    bk.fit(vlm.pcs[:, :10])
+    knn_ref = bk.kneighbors_graph(mode="distance")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        conn = (knn_ref > 0).astype(float)                                          # (sorts knn_ref in place, as in the reference)
+        conn.setdiag(1)
+    assert same_csr(vlm.knn, knn_ref) and same_csr(vlm.knn_smoothing_w, vcy.neighbors.connectivity_to_weights(conn))
+    assert vlm.knn.nnz == 13 * vlm.knn.shape[0]
     w = vlm.knn_smoothing_w
     vlm.knn_imputation_precomputed(w)
     close(vlm.Sx, g["bal_Sx"], rt, at)

@@ -13,6 +13,7 @@ vlm.pcs = pcs.cpu().numpy(); vlm.ts = vlm.pcs[:, :2].copy()
 vlm.normalize("both")
 which = os.environ.get("WHICH", "knn_imputation")
 calls = {"knn_imputation": lambda: vlm.knn_imputation(k=30, n_pca_dims=30),
+         "balanced": lambda: vlm.knn_imputation(k=30, n_pca_dims=30, balanced=True, b_sight=240, b_maxl=120),
          "shift": lambda: (vlm.calculate_shift(), vlm.extrapolate_cell_at_t()),
          "embedding_shift": lambda: vlm.calculate_embedding_shift(),
          "prepare_markov": lambda: vlm.prepare_markov(2.0, 4.0),

@@ -280,6 +280,22 @@ class VelocytoLoom(PreprocessMixin):
             bknn = BalancedKNN(k=k, sight_k=b_sight, maxl=b_maxl, metric=metric, constraint=constraint, mode="distance", n_jobs=n_jobs)
             bknn.fit(space)
             self.knn = bknn.kneighbors_graph(mode="distance")
+            direct = False
+            if diag != 0:
+                # every row = the cell itself (distance 0, first) + k distinct neighbours at positive distances - no padding, no
+                # coincident cells: the graph column-sorted, as (self.knn > 0) leaves it, and the weights written out directly
+                from .neighbors import weights_from_sorted_knn
+                dsi, dst = np.asarray(bknn.dsi_new), np.asarray(bknn.dist_new)
+                n_rows = dsi.shape[0]
+                if dsi.shape[1] == k + 1 and np.array_equal(dsi[:, 0], np.arange(n_rows)) and bool((dst[:, 1:] > 0).all()):
+                    order = np.argsort(dsi, axis=1, kind="stable")
+                    cols = np.take_along_axis(dsi, order, 1)
+                    self.knn = sparse.csr_matrix((np.take_along_axis(dst, order, 1).ravel(), cols.ravel().astype(np.int32),
+                                                  np.arange(0, n_rows * (k + 1) + 1, k + 1)), shape=(n_rows, n_rows))
+                    self.knn.has_sorted_indices = True
+                    others = cols[cols != np.arange(n_rows)[:, None]].reshape(n_rows, k)       # the row without the cell itself, still sorted
+                    self.knn_smoothing_w = weights_from_sorted_knn(others, diag)
+                    direct = True
         else:
             if group_constraint is not None:
                 raise ValueError("group_constraint is currently supported only if the argument balanced is set to True")
@@ -297,7 +313,7 @@ class VelocytoLoom(PreprocessMixin):
                     self.knn_smoothing_w = weights_from_sorted_knn(idx_s, diag)
             if self.knn is None:
                 self.knn = knn_distance_matrix(space, metric=metric, k=k, mode="distance", n_jobs=n_jobs)
-        if balanced or diag == 0 or not positive:
+        if (balanced and not direct) or (not balanced and (diag == 0 or not positive)):
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 connectivity = (self.knn > 0).astype(float)      # :1006 (also column-sorts self.knn in place, like scipy does there)
