@@ -1,6 +1,7 @@
 #!/bin/bash
 # On the GPU box: everything the round's documents quote besides the rocprofv3 passes (tools/profile_round.sh <tag> runs first):
-# the 8-rank rehearsal on one device, the cfg5 lines, stage D on shard shapes / wide lists / with the randomised control, the shard model.
+# the 8-rank rehearsal on one device, the cfg5 lines, stage D on shard shapes / wide lists / with the randomised control, the shard model,
+# the facade timings.
 # Usage: tools/measure_round.sh <tag>   -> gpurun_out/<tag>_*
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -13,7 +14,14 @@ python tools/bench_shapes.py > gpurun_out/${T}_stage_d_shapes.txt 2>&1
 python tools/bench_dual.py > gpurun_out/${T}_stage_d_dual.txt 2>&1
 LITERAL=1 python tools/bench_dual.py >> gpurun_out/${T}_stage_d_dual.txt 2>&1
 python tools/shard_model.py > gpurun_out/${T}_shard_model.json 2> gpurun_out/${T}_shard_model.err
-C=50000 G=30000 PRE=0 python tools/run_facade.py > gpurun_out/${T}_facade_50k.txt 2>&1
+# the facade around the path: three passes (first calls with their allocations, then steady state), the per-op breakdown, the sampling
+# replay alone, and the kernels of one pass by total time
+{ echo "# MEM=1 PASSES=3 C=50000 G=30000 PRE=0 python tools/run_facade.py"; MEM=1 PASSES=3 C=50000 G=30000 PRE=0 python tools/run_facade.py 2>&1 | grep -v amdgpu.ids
+  echo; echo "# python tools/facade_breakdown.py  (steady state, every ops call device-synchronised)"; python tools/facade_breakdown.py 2>&1 | grep -v amdgpu.ids | awk '/^normalize/{n++} n>=2'
+  echo; echo "# python tools/bench_choice.py; VCY_CHOICE_THREADS=1 python tools/bench_choice.py"; python tools/bench_choice.py 2>&1 | grep -v amdgpu.ids | tail -1; VCY_CHOICE_THREADS=1 python tools/bench_choice.py 2>&1 | grep -v amdgpu.ids | tail -1
+} > gpurun_out/${T}_facade_50k.txt
+tools/kernel_stats.sh "C=50000 G=30000 PRE=0 python tools/run_facade.py" 32 > gpurun_out/${T}_facade_kernel_stats.txt 2>&1
+python tools/bench_markov.py > gpurun_out/${T}_markov_steps.txt 2>&1
 for f in gpurun_out/${T}_bench_8ranks_one_device_line.json gpurun_out/${T}_bench_cfg5_200k_line.json gpurun_out/${T}_bench_cfg5_1M_line.json; do cut -c1-250 $f; echo; done
 cat gpurun_out/${T}_stage_d_shapes.txt gpurun_out/${T}_stage_d_dual.txt | grep -v amdgpu.ids
-tail -25 gpurun_out/${T}_facade_50k.txt
+head -48 gpurun_out/${T}_facade_50k.txt
