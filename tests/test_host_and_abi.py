@@ -316,6 +316,50 @@ def test_choice_stream_host_hypothesis(lib):
     run()
 
 
+def test_choice_stream_parallel_chains_hypothesis(lib, monkeypatch):
+    """Random populations, sample sizes, thread counts, shares, prefixes and slacks: the stitched parallel replay always returns
+    numpy's own rows, consumes numpy's own number of uniforms, and stops at the same cell when the pool ends early."""
+    import ctypes
+    from hypothesis import given, settings, strategies as st
+    L = lib.lib()
+
+    @settings(max_examples=80, deadline=None)
+    @given(st.integers(2, 40), st.integers(30, 260), st.integers(0, 2 ** 31 - 1), st.sampled_from(["flat", "ramp", "spiky", "zeros"]),
+           st.integers(2, 24), st.integers(1, 24), st.integers(1, 12), st.integers(0, 30), st.floats(0.05, 1.0))
+    def run(n, cells, seed, kind, threads, share, prefix, slack, pool_frac):
+        rng = np.random.default_rng(seed)
+        p = {"flat": np.ones(n), "ramp": np.linspace(1.0, 0.05, n), "spiky": rng.random(n) ** 12 + 1e-12,
+             "zeros": np.where(rng.random(n) < 0.4, 0.0, rng.random(n) + 1e-3)}[kind]
+        if not (p > 0).any():
+            p[0] = 1.0
+        p = p / p.sum()
+        size = int(rng.integers(1, int((p > 0).sum()) + 1))
+        for k, v in (("VCY_CHOICE_THREADS", threads), ("VCY_CHOICE_MIN_SHARE", share), ("VCY_CHOICE_PREFIX", prefix), ("VCY_CHOICE_SLACK", slack)):
+            monkeypatch.setenv(k, str(v))
+        rs = np.random.RandomState(seed % (2 ** 32))
+        want = np.stack([rs.choice(n, size=(size,), replace=False, p=p) for _ in range(cells)], 0)
+        big = np.random.RandomState(seed % (2 ** 32)).random_sample(cells * size * 12 + 64)
+        out = np.full((cells, size), -1, dtype=np.int64)
+        cd, used = ctypes.c_int64(0), ctypes.c_int64(0)
+        assert L.vcy_choice_stream_host(big.ctypes.data, big.size, p.ctypes.data, n, size, cells, out.ctypes.data, ctypes.byref(cd), ctypes.byref(used)) == 0
+        assert cd.value == cells and np.array_equal(out, want)
+        check = np.random.RandomState(seed % (2 ** 32))
+        check.random_sample(used.value)
+        assert np.array_equal(check.random_sample(3), rs.random_sample(3))
+        cut = int(used.value * pool_frac)
+        out2 = np.full((cells, size), -1, dtype=np.int64)
+        cd2, used2 = ctypes.c_int64(0), ctypes.c_int64(0)
+        assert L.vcy_choice_stream_host(big.ctypes.data, cut, p.ctypes.data, n, size, cells, out2.ctypes.data, ctypes.byref(cd2), ctypes.byref(used2)) == 0
+        assert cd2.value <= cells and used2.value <= cut and np.array_equal(out2[: cd2.value], want[: cd2.value])
+        if cd2.value < cells:                                                      # the sequential replay stops at the same cell
+            monkeypatch.setenv("VCY_CHOICE_THREADS", "1")
+            cd3, used3 = ctypes.c_int64(0), ctypes.c_int64(0)
+            L.vcy_choice_stream_host(big.ctypes.data, cut, p.ctypes.data, n, size, cells, out2.ctypes.data, ctypes.byref(cd3), ctypes.byref(used3))
+            assert (cd3.value, used3.value) == (cd2.value, used2.value)
+
+    run()
+
+
 def test_atlas_memory_plan_for_one_million_cells():
     """The per-rank memory plan of the atlas path is plain arithmetic: 1M cells x 30k genes on 8 ranks must fit
     288 GB per rank with room to spare in resident mode, and a streamed single rank must stay O(block)."""
