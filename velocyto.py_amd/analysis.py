@@ -273,6 +273,7 @@ class VelocytoLoom(PreprocessMixin):
         if b_maxl is None and balanced:
             b_maxl = np.maximum(int(k * 4), N - 1)
         space = self.pcs[:, :n_pca_dims] if pca_space else self.S_norm.T
+        w_direct = False                                          # knn_smoothing_w written out directly (below) instead of through scipy
         if balanced:
             constraint = None
             if group_constraint is not None:
@@ -280,7 +281,6 @@ class VelocytoLoom(PreprocessMixin):
             bknn = BalancedKNN(k=k, sight_k=b_sight, maxl=b_maxl, metric=metric, constraint=constraint, mode="distance", n_jobs=n_jobs)
             bknn.fit(space)
             self.knn = bknn.kneighbors_graph(mode="distance")
-            direct = False
             if diag != 0:
                 # every row = the cell itself (distance 0, first) + k distinct neighbours at positive distances - no padding, no
                 # coincident cells: the graph column-sorted, as (self.knn > 0) leaves it, and the weights written out directly
@@ -295,11 +295,10 @@ class VelocytoLoom(PreprocessMixin):
                     self.knn.has_sorted_indices = True
                     others = cols[cols != np.arange(n_rows)[:, None]].reshape(n_rows, k)       # the row without the cell itself, still sorted
                     self.knn_smoothing_w = weights_from_sorted_knn(others, diag)
-                    direct = True
+                    w_direct = True
         else:
             if group_constraint is not None:
                 raise ValueError("group_constraint is currently supported only if the argument balanced is set to True")
-            self.knn = None
             if diag != 0:
                 # the graph with its rows sorted by cell number on the device - the state (self.knn > 0) leaves self.knn in, :1006 -
                 # and, when no distance is zero (no duplicate cells), the weights written out directly: the same matrices as the
@@ -311,9 +310,10 @@ class VelocytoLoom(PreprocessMixin):
                 self.knn.has_sorted_indices = True
                 if positive:
                     self.knn_smoothing_w = weights_from_sorted_knn(idx_s, diag)
-            if self.knn is None:
+                    w_direct = True
+            else:
                 self.knn = knn_distance_matrix(space, metric=metric, k=k, mode="distance", n_jobs=n_jobs)
-        if (balanced and not direct) or (not balanced and (diag == 0 or not positive)):
+        if not w_direct:
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 connectivity = (self.knn > 0).astype(float)      # :1006 (also column-sorts self.knn in place, like scipy does there)
