@@ -397,14 +397,16 @@ int vcy_prepare_markov(const int64_t *indptr, const int32_t *indices, const doub
  * that K_W = g exp2(-|es_c - es_j|^2).  vcy_diffuse_step_factored is one step y = x . tr (+ accum += y) of Diffusion.diffuse
  * (diffusion.py:93-105) from those factors: colptr / rowidx / scsc = s including its diagonal in CSC form; the Gauss transform is
  * evaluated on the fly in `compute_dtype` (8 terms folded before they reach the fp64 accumulator), the rest in fp64.
- * workspace: vcy_markov_factored_workspace_bytes(n).                                                                             */
+ * workspace: vcy_markov_factored_workspace_bytes(n).  prepared: 0 for a step that starts from an arbitrary x; 1 when x is the y of
+ * the previous step ON THE SAME WORKSPACE (a loop of steps): that step's fold has already written x / tot and its scaled copy there,
+ * and the scaling launch is skipped (loops of thousands of small steps are launch-bound).                                        */
 size_t vcy_markov_factored_workspace_bytes(int64_t n);
 int vcy_prepare_markov_factored(const int64_t *indptr, const int32_t *indices, const double *pval, const double *embedding, int edim,
                                 double *sval, double *sdiag, double *kw, double *tot, void *es, int64_t n, double sigma_D, double sigma_W,
                                 int compute_dtype, vcy_stream stream);
 int vcy_diffuse_step_factored(const double *x, double *y, double *accum, const int64_t *colptr, const int32_t *rowidx, const double *scsc,
                               const double *tot, const double *kw, const void *es, int edim, double sigma_W, void *workspace, int64_t n,
-                              int compute_dtype, vcy_stream stream);
+                              int prepared, int compute_dtype, vcy_stream stream);
 
 /* The factored step when K_W is narrow against the extent of the embedding (prepare_markov is usually given a sigma_W of a grid step,
  * analysis.py:1818-1863): terms below 2^-cut of their weight are left out of the Gauss transform.  The caller sorts the cells along a
@@ -418,7 +420,7 @@ int vcy_markov_cull_boxes(const void *es_sorted, void *boxes, int64_t n, int edi
 int vcy_diffuse_step_factored_culled(const double *x, double *y, double *accum, const int64_t *colptr, const int32_t *rowidx,
                                      const double *scsc, const double *tot, const double *kw, const void *es_sorted, const int32_t *rank,
                                      const int32_t *order, const void *boxes, int edim, double sigma_W, double cut, void *workspace,
-                                     int64_t n, int compute_dtype, vcy_stream stream);
+                                     int64_t n, int prepared, int compute_dtype, vcy_stream stream);
 
 /* ---------------------------------------------------------------- stage F: Diffusion.diffuse step
  * (diffusion.py:93-105): y = x . tr, optionally accum += y (path_integral).  tr dense row-major

@@ -645,12 +645,15 @@ __global__ __launch_bounds__(256) void k_gauss_transform_culled(const CT *__rest
     for (int t = 0; t < JPT; ++t)
         if (j0 + t * 256 < n) part[(int64_t)blockIdx.y * n + j0 + t * 256] = acc[t];
 }
-// y[j] += the folded partials (fixed order); path_integral: accum += y
+// y[j] += the folded partials (fixed order); path_integral: accum += y.  Then, what the NEXT step starts with (k_markov_scale_x of
+// the new y, saved a launch per step: thousands of steps of a few small kernels are bound by launches): v = y / tot, u = coef v / kw.
+template <typename CT>
 __global__ void k_gauss_reduce(const double *__restrict__ part, double *__restrict__ y, double *__restrict__ accum, int n, int nparts,
-                               const int32_t *__restrict__ order)
+                               const int32_t *__restrict__ order, const double *__restrict__ tot, const double *__restrict__ kw,
+                               double *__restrict__ v, CT *__restrict__ u, double coef)
 {
     // order (culled transform): the partials are indexed by position in the sorted order; thread = position, so that the nparts reads
-    // stay coalesced and only the one update of y is scattered
+    // stay coalesced and only the update of y (and v) is scattered; u is indexed by position too
     const int jj = blockIdx.x * blockDim.x + threadIdx.x;
     if (jj >= n) return;
     const int j = order ? order[jj] : jj;
@@ -659,6 +662,9 @@ __global__ void k_gauss_reduce(const double *__restrict__ part, double *__restri
     s += y[j];
     y[j] = s;
     if (accum) accum[j] += s;
+    const double vj = s / tot[j];
+    v[j] = vj;
+    u[jj] = (CT)(coef * vj / kw[j]);
 }
 
 static inline int grid_for(int64_t total) { const int64_t b = (total + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
@@ -866,15 +872,17 @@ static inline int64_t gt_chunks(int64_t n) { return (n + GT_CHUNK - 1) / GT_CHUN
 template <typename CT>
 static int diffuse_step_factored(const double *x, double *y, double *accum, const int64_t *colptr, const int32_t *rowidx, const double *scsc,
                                  const double *tot, const double *kw, const CT *es, int edim, double sigma_W, void *workspace, int64_t n,
-                                 hipStream_t st, const int32_t *rank = nullptr, const int32_t *order = nullptr, const CT *boxes = nullptr,
-                                 double cut = 0.0)
+                                 hipStream_t st, int prepared, const int32_t *rank = nullptr, const int32_t *order = nullptr,
+                                 const CT *boxes = nullptr, double cut = 0.0)
 {
     double *v = (double *)workspace;
     CT *u = (CT *)(v + n);
     double *part = v + 2 * n;
     const double coef = 0.2 / sqrt(2.0 * 3.14159265358979323846 * sigma_W * sigma_W);
-    hipLaunchKernelGGL(k_markov_scale_x<CT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, tot, kw, v, u, (int)n, coef, rank);
-    VCY_LAUNCH_CHECK();
+    if (!prepared) {   // v = x / tot, u = coef v / kw; a step that follows another one on the same workspace finds them written by its fold
+        hipLaunchKernelGGL(k_markov_scale_x<CT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, tot, kw, v, u, (int)n, coef, rank);
+        VCY_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(k_vecmat_csc<double>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, colptr, rowidx, scsc, (const double *)v, y, (double *)nullptr, (int)n);
     VCY_LAUNCH_CHECK();
     int nparts = gauss_parts(n);
@@ -887,7 +895,7 @@ static int diffuse_step_factored(const double *x, double *y, double *accum, cons
         switch (edim) { case 1: VCY_GTC(1); break; case 2: VCY_GTC(2); break; case 3: VCY_GTC(3); break; default: VCY_GTC(4); break; }
 #undef VCY_GTC
         VCY_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_gauss_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double *)part, y, accum, (int)n, nparts, order);
+        hipLaunchKernelGGL(k_gauss_reduce<CT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double *)part, y, accum, (int)n, nparts, order, tot, kw, v, u, coef);
         VCY_LAUNCH_CHECK();
         return VCY_OK;
     }
@@ -899,7 +907,7 @@ static int diffuse_step_factored(const double *x, double *y, double *accum, cons
     default: hipLaunchKernelGGL((k_gauss_transform<CT, 4, 2>), grid, dim3(256), 0, st, es, (const CT *)u, part, (int)n); break;
     }
     VCY_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_gauss_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double *)part, y, accum, (int)n, nparts, order);
+    hipLaunchKernelGGL(k_gauss_reduce<CT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double *)part, y, accum, (int)n, nparts, order, tot, kw, v, u, coef);
     VCY_LAUNCH_CHECK();
     return VCY_OK;
 }
@@ -933,22 +941,22 @@ extern "C" int vcy_markov_cull_boxes(const void *es_sorted, void *boxes, int64_t
 extern "C" int vcy_diffuse_step_factored_culled(const double *x, double *y, double *accum, const int64_t *colptr, const int32_t *rowidx,
                                                 const double *scsc, const double *tot, const double *kw, const void *es_sorted,
                                                 const int32_t *rank, const int32_t *order, const void *boxes, int edim, double sigma_W,
-                                                double cut, void *workspace, int64_t n, int compute_dtype, vcy_stream stream)
+                                                double cut, void *workspace, int64_t n, int prepared, int compute_dtype, vcy_stream stream)
 {
     VCY_REQUIRE(x && y && colptr && rowidx && scsc && tot && kw && es_sorted && rank && order && boxes && workspace && x != y, "diffuse_step_factored_culled: bad arguments");
     VCY_REQUIRE(n > 0 && n < (1ll << 31) && edim > 0 && edim <= 4 && sigma_W > 0 && cut > 0, "diffuse_step_factored_culled: bad arguments");
-    if (compute_dtype == VCY_F32) return diffuse_step_factored<float>(x, y, accum, colptr, rowidx, scsc, tot, kw, (const float *)es_sorted, edim, sigma_W, workspace, n, as_stream(stream), rank, order, (const float *)boxes, cut);
-    if (compute_dtype == VCY_F64) return diffuse_step_factored<double>(x, y, accum, colptr, rowidx, scsc, tot, kw, (const double *)es_sorted, edim, sigma_W, workspace, n, as_stream(stream), rank, order, (const double *)boxes, cut);
+    if (compute_dtype == VCY_F32) return diffuse_step_factored<float>(x, y, accum, colptr, rowidx, scsc, tot, kw, (const float *)es_sorted, edim, sigma_W, workspace, n, as_stream(stream), prepared, rank, order, (const float *)boxes, cut);
+    if (compute_dtype == VCY_F64) return diffuse_step_factored<double>(x, y, accum, colptr, rowidx, scsc, tot, kw, (const double *)es_sorted, edim, sigma_W, workspace, n, as_stream(stream), prepared, rank, order, (const double *)boxes, cut);
     return fail(VCY_ERR_INVALID, "%s: bad dtype", "diffuse_step_factored_culled");
 }
 
 extern "C" int vcy_diffuse_step_factored(const double *x, double *y, double *accum, const int64_t *colptr, const int32_t *rowidx, const double *scsc,
                                          const double *tot, const double *kw, const void *es, int edim, double sigma_W, void *workspace, int64_t n,
-                                         int compute_dtype, vcy_stream stream)
+                                         int prepared, int compute_dtype, vcy_stream stream)
 {
     VCY_REQUIRE(x && y && colptr && rowidx && scsc && tot && kw && es && workspace && x != y, "diffuse_step_factored: bad arguments");
     VCY_REQUIRE(n > 0 && n < (1ll << 31) && edim > 0 && edim <= 4 && sigma_W > 0, "diffuse_step_factored: bad arguments");
-    if (compute_dtype == VCY_F32) return diffuse_step_factored<float>(x, y, accum, colptr, rowidx, scsc, tot, kw, (const float *)es, edim, sigma_W, workspace, n, as_stream(stream));
-    if (compute_dtype == VCY_F64) return diffuse_step_factored<double>(x, y, accum, colptr, rowidx, scsc, tot, kw, (const double *)es, edim, sigma_W, workspace, n, as_stream(stream));
+    if (compute_dtype == VCY_F32) return diffuse_step_factored<float>(x, y, accum, colptr, rowidx, scsc, tot, kw, (const float *)es, edim, sigma_W, workspace, n, as_stream(stream), prepared);
+    if (compute_dtype == VCY_F64) return diffuse_step_factored<double>(x, y, accum, colptr, rowidx, scsc, tot, kw, (const double *)es, edim, sigma_W, workspace, n, as_stream(stream), prepared);
     return fail(VCY_ERR_INVALID, "%s: bad dtype", "diffuse_step_factored");
 }

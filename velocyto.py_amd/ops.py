@@ -1423,16 +1423,19 @@ def diffuse(x0, tr, n_steps: int, accumulate: bool) -> Tuple[torch.Tensor, Optio
         assert tr.n == n
         ws = torch.empty(int(L.vcy_markov_factored_workspace_bytes(n)), dtype=torch.uint8, device=dev)
 
+        chain = {"prepared": 0}                           # after the first step every step starts from the previous one's output
+
         def step(src, dst):
+            prepared, chain["prepared"] = chain["prepared"], 1
             if tr.cull is not None:
                 es_sorted, rank, boxes, cut, order = tr.cull
                 _lib.check(L.vcy_diffuse_step_factored_culled(src.data_ptr(), dst.data_ptr(), _p(acc), tr.colptr.data_ptr(), tr.rowidx.data_ptr(),
                                                               tr.scsc.data_ptr(), tr.tot.data_ptr(), tr.kw.data_ptr(), es_sorted.data_ptr(), rank.data_ptr(),
-                                                              order.data_ptr(), boxes.data_ptr(), tr.edim, tr.sigma_W, cut, ws.data_ptr(), n, _DT[tr.compute_dtype],
-                                                              _stream()), "diffuse_step_factored_culled")
+                                                              order.data_ptr(), boxes.data_ptr(), tr.edim, tr.sigma_W, cut, ws.data_ptr(), n, prepared,
+                                                              _DT[tr.compute_dtype], _stream()), "diffuse_step_factored_culled")
                 return
             _lib.check(L.vcy_diffuse_step_factored(src.data_ptr(), dst.data_ptr(), _p(acc), tr.colptr.data_ptr(), tr.rowidx.data_ptr(), tr.scsc.data_ptr(),
-                                                   tr.tot.data_ptr(), tr.kw.data_ptr(), tr.es.data_ptr(), tr.edim, tr.sigma_W, ws.data_ptr(), n,
+                                                   tr.tot.data_ptr(), tr.kw.data_ptr(), tr.es.data_ptr(), tr.edim, tr.sigma_W, ws.data_ptr(), n, prepared,
                                                    _DT[tr.compute_dtype], _stream()), "diffuse_step_factored")
         x = _run_steps(step, x, y, n_steps)
     elif sp.issparse(tr):
