@@ -27,6 +27,9 @@ def test_header_symbols_exported(lib):
         assert hasattr(L, name), f"{name} declared in velocyto_hip.h but not exported"
     assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
     assert L.vcy_abi_version() == 1
+    # and the maintainer's guide names every one of them (which reference call it replaces, or what a binder needs it for)
+    guide = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert not [n for n in sorted(declared) if n not in guide]
 
 
 def test_no_cpu_fallback_in_product():
