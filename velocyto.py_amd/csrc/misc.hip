@@ -478,11 +478,35 @@ __global__ void k_markov_scale_x(const double *__restrict__ x, const double *__r
 __device__ __forceinline__ float exp2_neg(float d2) { return __builtin_amdgcn_exp2f(-d2); }
 __device__ __forceinline__ double exp2_neg(double d2) { return exp2(-d2); }
 
+// The sparse half of a step, y[j] = sum_p scsc[p] v[rowidx[p]] over column j (k_vecmat_csc), riding in the Gauss-transform launch: the two
+// halves are independent, and a loop of thousands of steps is bound by the number of launches as soon as the kernels are small
+// (13 us per kernel whatever it does at 10 000 cells).  The first `rows` rows of the grid (blockIdx.y) do it, four columns per workgroup.
+struct SparseHalf {
+    const int64_t *colptr;
+    const int32_t *rowidx;
+    const double *scsc, *v;
+    double *y;
+    int n, rows;                                                // rows = 0: no sparse half in this launch
+};
+__device__ __forceinline__ void sparse_half(const SparseHalf &sp)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t j = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (j >= sp.n) return;
+    double acc = 0.0;
+    for (int64_t p = sp.colptr[j] + lane; p < sp.colptr[j + 1]; p += 64) acc = fma(sp.scsc[p], sp.v[sp.rowidx[p]], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) sp.y[j] = acc;
+}
+
 // part[blockIdx.y][j] = sum over this block's source range of u[c] exp2(-|es[c] - es[j]|^2).  A thread owns JPT targets; the source
 // index is uniform over the block (scalar loads).  8 terms are folded in CT before they are added to the fp64 accumulator.
 template <typename CT, int EDIM, int JPT>
-__global__ __launch_bounds__(256) void k_gauss_transform(const CT *__restrict__ es, const CT *__restrict__ u, double *__restrict__ part, int n)
+__global__ __launch_bounds__(256) void k_gauss_transform(const CT *__restrict__ es, const CT *__restrict__ u, double *__restrict__ part, int n,
+                                                          int nparts, SparseHalf sp)
 {
+    if ((int)blockIdx.y < sp.rows) { sparse_half(sp); return; }
+    const int by = (int)blockIdx.y - sp.rows;
     const int j0 = blockIdx.x * 256 * JPT + threadIdx.x;
     CT ej[JPT][EDIM];
 #pragma unroll
@@ -491,8 +515,8 @@ __global__ __launch_bounds__(256) void k_gauss_transform(const CT *__restrict__ 
 #pragma unroll
         for (int a = 0; a < EDIM; ++a) ej[t][a] = es[(int64_t)j * EDIM + a];
     }
-    const int per = (n + gridDim.y - 1) / gridDim.y;
-    const int c0 = blockIdx.y * per, c1 = min(n, c0 + per);
+    const int per = (n + nparts - 1) / nparts;
+    const int c0 = by * per, c1 = min(n, c0 + per);
     double acc[JPT];
 #pragma unroll
     for (int t = 0; t < JPT; ++t) acc[t] = 0.0;
@@ -529,7 +553,7 @@ __global__ __launch_bounds__(256) void k_gauss_transform(const CT *__restrict__ 
     }
 #pragma unroll
     for (int t = 0; t < JPT; ++t)
-        if (j0 + t * 256 < n) part[(int64_t)blockIdx.y * n + j0 + t * 256] = acc[t];
+        if (j0 + t * 256 < n) part[(int64_t)by * n + j0 + t * 256] = acc[t];
 }
 // The same transform for a kernel that is NARROW against the extent of the embedding (prepare_markov is typically called with sigma_W
 // of a grid step): terms below 2^-cut of their weight are left out.  Cells are visited in a spatially sorted order (Hilbert curve of
@@ -556,9 +580,12 @@ __global__ void k_gauss_boxes(const CT *__restrict__ pts, int npts, CT *__restri
 
 template <typename CT, int EDIM, int JPT>
 __global__ __launch_bounds__(256) void k_gauss_transform_culled(const CT *__restrict__ es, const CT *__restrict__ u, double *__restrict__ part, int n,
-                                                                 const CT *__restrict__ clo, const CT *__restrict__ chi, int nchunk, CT cut)
+                                                                 const CT *__restrict__ clo, const CT *__restrict__ chi, int nchunk, CT cut,
+                                                                 int nparts, SparseHalf sp)
 {
     __shared__ CT red[2][EDIM][4];
+    if ((int)blockIdx.y < sp.rows) { sparse_half(sp); return; }
+    const int by = (int)blockIdx.y - sp.rows;
     const int j0 = blockIdx.x * 256 * JPT + threadIdx.x;
     CT ej[JPT][EDIM];
 #pragma unroll
@@ -585,8 +612,8 @@ __global__ __launch_bounds__(256) void k_gauss_transform_culled(const CT *__rest
     }
     // the sources are split over blockIdx.y by chunks (finely: where the data is dense a few workgroups get all the work of a target
     // block, and the launch lasts as long as the busiest of them)
-    const int qper = (nchunk + gridDim.y - 1) / gridDim.y;
-    const int qa = blockIdx.y * qper, qb = min(nchunk, qa + qper);
+    const int qper = (nchunk + nparts - 1) / nparts;
+    const int qa = by * qper, qb = min(nchunk, qa + qper);
     const int lane = threadIdx.x & 63;
     double acc[JPT];
 #pragma unroll
@@ -643,7 +670,7 @@ __global__ __launch_bounds__(256) void k_gauss_transform_culled(const CT *__rest
     }
 #pragma unroll
     for (int t = 0; t < JPT; ++t)
-        if (j0 + t * 256 < n) part[(int64_t)blockIdx.y * n + j0 + t * 256] = acc[t];
+        if (j0 + t * 256 < n) part[(int64_t)by * n + j0 + t * 256] = acc[t];
 }
 // y[j] += the folded partials (fixed order); path_integral: accum += y.  Then, what the NEXT step starts with (k_markov_scale_x of
 // the new y, saved a launch per step: thousands of steps of a few small kernels are bound by launches): v = y / tot, u = coef v / kw.
@@ -883,15 +910,18 @@ static int diffuse_step_factored(const double *x, double *y, double *accum, cons
         hipLaunchKernelGGL(k_markov_scale_x<CT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, tot, kw, v, u, (int)n, coef, rank);
         VCY_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_vecmat_csc<double>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, colptr, rowidx, scsc, (const double *)v, y, (double *)nullptr, (int)n);
-    VCY_LAUNCH_CHECK();
+    // one launch for both halves of the step: the sparse product in the first rows of the grid, the Gauss transform in the others
+    SparseHalf sp{colptr, rowidx, scsc, (const double *)v, y, (int)n, 0};
+    const int64_t sparse_groups = (n + 3) / 4;
     int nparts = gauss_parts(n);
     if (boxes) {
         const int64_t nc = gt_chunks(n);
         nparts = nc < 64 ? (int)nc : 64;
         const CT *clo = boxes, *chi = clo + nc * edim;
-        dim3 gridc((unsigned)((n + 255) / 256), nparts);
-#define VCY_GTC(ED) hipLaunchKernelGGL((k_gauss_transform_culled<CT, ED, 1>), gridc, dim3(256), 0, st, es, (const CT *)u, part, (int)n, clo, chi, (int)nc, (CT)cut)
+        const unsigned gx = (unsigned)((n + 255) / 256);
+        sp.rows = (int)((sparse_groups + gx - 1) / gx);
+        dim3 gridc(gx, (unsigned)(sp.rows + nparts));
+#define VCY_GTC(ED) hipLaunchKernelGGL((k_gauss_transform_culled<CT, ED, 1>), gridc, dim3(256), 0, st, es, (const CT *)u, part, (int)n, clo, chi, (int)nc, (CT)cut, nparts, sp)
         switch (edim) { case 1: VCY_GTC(1); break; case 2: VCY_GTC(2); break; case 3: VCY_GTC(3); break; default: VCY_GTC(4); break; }
 #undef VCY_GTC
         VCY_LAUNCH_CHECK();
@@ -899,12 +929,14 @@ static int diffuse_step_factored(const double *x, double *y, double *accum, cons
         VCY_LAUNCH_CHECK();
         return VCY_OK;
     }
-    dim3 grid((unsigned)((n + 511) / 512), nparts);
+    const unsigned gx = (unsigned)((n + 511) / 512);
+    sp.rows = (int)((sparse_groups + gx - 1) / gx);
+    dim3 grid(gx, (unsigned)(sp.rows + nparts));
     switch (edim) {
-    case 1: hipLaunchKernelGGL((k_gauss_transform<CT, 1, 2>), grid, dim3(256), 0, st, es, (const CT *)u, part, (int)n); break;
-    case 2: hipLaunchKernelGGL((k_gauss_transform<CT, 2, 2>), grid, dim3(256), 0, st, es, (const CT *)u, part, (int)n); break;
-    case 3: hipLaunchKernelGGL((k_gauss_transform<CT, 3, 2>), grid, dim3(256), 0, st, es, (const CT *)u, part, (int)n); break;
-    default: hipLaunchKernelGGL((k_gauss_transform<CT, 4, 2>), grid, dim3(256), 0, st, es, (const CT *)u, part, (int)n); break;
+    case 1: hipLaunchKernelGGL((k_gauss_transform<CT, 1, 2>), grid, dim3(256), 0, st, es, (const CT *)u, part, (int)n, nparts, sp); break;
+    case 2: hipLaunchKernelGGL((k_gauss_transform<CT, 2, 2>), grid, dim3(256), 0, st, es, (const CT *)u, part, (int)n, nparts, sp); break;
+    case 3: hipLaunchKernelGGL((k_gauss_transform<CT, 3, 2>), grid, dim3(256), 0, st, es, (const CT *)u, part, (int)n, nparts, sp); break;
+    default: hipLaunchKernelGGL((k_gauss_transform<CT, 4, 2>), grid, dim3(256), 0, st, es, (const CT *)u, part, (int)n, nparts, sp); break;
     }
     VCY_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_gauss_reduce<CT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double *)part, y, accum, (int)n, nparts, order, tot, kw, v, u, coef);
