@@ -19,15 +19,21 @@ N > 1 (one rank per GPU over RCCL; launched by torch.distributed.run, or self-la
 WORLD_SIZE is not set): cells are sharded, total work fixed ("strong" scaling): ranks all-reduce the fit moments, exchange
 the halo rows of Sx their neighbour lists reference and all-gather the compact correlation rows.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_cdc_partial_grouped): it is VALU-issue-bound, so
-`achieved` is its VALU wave-instruction rate (instructions per launch from the rocprofv3 SQ_INSTS_VALU pass named in
-`roofline.counters_from`, scaled by the exact pair-chunk count of this run; time from HIP events of this run) against the
-issue peak of the chip; the HBM-side figures ride along (`hbm_frac_measured`, `vs_noreuse_model`).  `value` is the production
-mode (f32); `f64` is the same pass in the reference's own arithmetic (f64 storage and moments, literal branch rule) with its
-own roofline, and `precision_modes` puts the three modes (f32 production / f32 literal rule / f64) side by side.  `stages`
-holds the per-stage rooflines, `extra` the uint16-layer and randomised-control lines of the same workload.  `cpu_baseline`
-times the oracle restatement (oracle/libvelocyto_oracle.so + oracle.py) on a bounded closed sub-problem on the host cores
-and reports, as `parity`, how far the HIP path is from it on that same sub-problem in all three modes.
+Prints ONE JSON line (rank 0).  The headline (`value`, `dtype`, `ms_per_step`, `roofline`) is the pass in the REFERENCE'S
+arithmetic: f64 storage of the pooled matrices, f64 moments, the literal branch rule of speedboosted.pyx:372-378
+(`--dtype f64`, the default), timed with exactly --steps / --warmup.  `roofline` is for the dominant kernel
+(k_cdc_partial_grouped<double>): it is VALU-issue-bound, so `achieved` is its VALU wave-instruction rate (instructions per
+launch from the rocprofv3 SQ_INSTS_VALU pass named in `roofline.counters_from`, scaled by the exact pair-chunk count of this
+run; time from HIP events of this run) against the issue peak of the chip; the HBM-side figures ride along
+(`hbm_frac_measured`, `vs_noreuse_model`).  `precision_modes` holds the build's narrower production modes of the same pass
+(f32 storage with the no-pseudocount form of the rule, f32 with the literal rule, uint16 count layers), each with its own
+roofline block and its distance from the f64 pass over ALL correlations - reported, not the headline.  `stages` holds the
+per-stage rooflines.  `extra` holds the other lines SURVEY.md 8(d) asks for, all timed in this run at the headline size:
+E calculate_embedding_shift, F prepare_markov + run_markov, B fit_gammas with its defaults, D at the reference's default list
+width (n_neighbors = C/5, sampled_fraction = 0.3 => nrndm = 3000), the randomised control, and cfg2 (BASELINE.json
+configs[1]: 10 000 x 20 000, stages A + B, unbalanced and balanced kNN); their key numbers are repeated as scalars in `config`.
+`cpu_baseline` times the oracle restatement (oracle/libvelocyto_oracle.so + oracle.py) on a bounded closed sub-problem on
+the host cores and reports, as `parity`, how far the HIP path is from it on that same sub-problem in all three modes.
 """
 import argparse
 import json
@@ -60,8 +66,8 @@ MIX_CLK_PER_ELEMENT = {1: 27.7, 2: 23.3}
 # mix by tools/ubench/valu_issue_f64.hip (profiles/r03_valu_issue_f64.txt: "f64 element, f32 seed + 1 step + 1 correction", wall-clock column)
 MIX_CLK_PER_ELEMENT_F64 = 83.8
 F64_ISSUE_CLK = 4.1               # clocks per wave64 v_add_f64 / v_mul_f64 / v_fma_f64 per SIMD (same file): the f64 issue peak is 1 instruction / 4 clocks
-COUNTERS_FILE = os.path.join(ROOT, "profiles", "r03_cdc_counters.json")     # written by tools/summarize_profiles.py from the rocprofv3 passes
-COUNTERS_FALLBACK = os.path.join(ROOT, "profiles", "r02_cdc_counters.json")
+COUNTERS_FILE = os.path.join(ROOT, "profiles", "r04_cdc_counters.json")     # written by tools/summarize_profiles.py from the rocprofv3 passes
+COUNTERS_FALLBACK = os.path.join(ROOT, "profiles", "r03_cdc_counters.json")
 
 
 def parse():
@@ -75,7 +81,7 @@ def parse():
     ap.add_argument("--pca-dims", type=int, default=30)
     ap.add_argument("--n-neighbors", type=int, default=500)
     ap.add_argument("--sampled-fraction", type=float, default=0.5)
-    ap.add_argument("--cpu-cells", type=int, default=1024, help="cells of the closed CPU-baseline sub-problem")
+    ap.add_argument("--cpu-cells", type=int, default=512, help="cells of the closed CPU-baseline sub-problem")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass of THIS command; without it "
@@ -88,8 +94,10 @@ def parse():
     ap.add_argument("--knn", choices=["auto", "brute", "pruned"], default="auto", help="cfg5: exact kNN search by brute force or projection-pruned (auto: pruned from 100k cells)")
     ap.add_argument("--counts", choices=["auto", "u16"], default="auto",
                     help="storage of the resident count layers: auto = uint8 when no count exceeds 255, else uint16; u16 forces uint16")
-    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32", help="arithmetic / storage type of the path (f64 = the reference's)")
-    ap.add_argument("--no-extra", action="store_true", help="skip the f64 / uint16 / randomised-control lines")
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f64", help="arithmetic / storage type of the timed path (f64 = the reference's, the headline; "
+                                                                         "f32 = the build's production mode)")
+    ap.add_argument("--no-extra", action="store_true", help="skip precision_modes and the extra lines (E, F, default fit_gammas, nrndm = 3000, randomised control, cfg2)")
+    ap.add_argument("--extra-budget-s", type=float, default=40.0, help="extra lines are skipped (and say so) once this many seconds have gone into them")
     ap.add_argument("--literal-rule", action="store_true", help="stage D with the literal partial-sqrt rule (pseudocount kept) instead of the "
                                                                 "three-instruction f32 form ops.partial_rules_for picks")
     ap.add_argument("--slab", type=int, default=0, help="gene slab of the pooling kernel (0 = library default)")
@@ -560,6 +568,19 @@ def run(a, rank, local_rank, world):
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
         assert dist.get_world_size() == world and dist.get_rank() == rank, "process group does not match the launcher's ranks"
+        # every collective shape of the sharded path on tiny tensors first (distributed.self_check): a transport that cannot do
+        # the uneven all-to-all of the halo exchange is reported by name and the run falls back to --exchange allgather
+        from velocyto_amd import distributed as _D
+        chk = _D.self_check(dev)
+        bad = [n for n, ok in chk.get("agreed", {}).items() if not ok]
+        a.self_check = "skipped" if "skipped" in chk else ("all ok: " + ", ".join(_D.SELF_CHECKS) if not bad else "FAILED: " + "; ".join(f"{n} ({chk.get(n)})" for n in bad))
+        if bad:
+            print(f"[bench rank {rank}] collective self-check: {a.self_check}", file=sys.stderr, flush=True)
+            if any(n in bad for n in ("all_gather_rows_equal", "all_gather_rows_ragged", "all_reduce_min")):
+                raise RuntimeError(f"collective self-check: {a.self_check} - the sharded path has no fallback for these")
+            if a.exchange == "halo":                 # the halo plan needs the uneven all-to-all and the mask all-gather
+                a.exchange = "allgather"
+                a.self_check += " -> --exchange allgather"
     import velocyto_amd  # noqa: F401
     from velocyto_amd import _lib
     _lib.lib()   # fail loudly if the HIP library is missing
@@ -638,7 +659,7 @@ def run(a, rank, local_rank, world):
             "value": C / (ms_per_step * 1e-3), "unit": "cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
-            "rccl_ranks": rccl_ranks,
+            "rccl_ranks": rccl_ranks, "collective_self_check": getattr(a, "self_check", "not run (one rank)"),
             "config": {"workload": f"synthetic {C} cells x {G} genes (BASELINE.json configs[2]): knn_imputation(k={a.k}, "
                                    f"{a.pca_dims} PCs) -> fit_slope -> velocity chain -> colDeltaCorSqrtpartial(nrndm={nr}, "
                                    f"n_neighbors={a.n_neighbors}, sampled_fraction={a.sampled_fraction}, psc=1e-10)",
@@ -652,36 +673,19 @@ def run(a, rank, local_rank, world):
                                       ", all-gather of correlation rows",
                        "stage_ms": {"A_knn_imputation": stage[0], "B_fit_slope": stage[1], "C_velocity_chain": stage[2],
                                     "D_exchange": stage[3], "D_coldeltacor": stage[4]},
+                       "A_knn_search_ms": stage[5], "A_pooling_ms": stage[6], "B_fit_slope_ms": stage[1], "D_coldeltacor_ms": stage[4],
+                       "arithmetic": "f64 storage and moments, literal branch rule: the reference's (speedboosted.pyx:352-443)" if a.dtype == "f64" else
+                                     "f32 storage and lane accumulators (production mode; the reference is f64)",
                        **({"parallelism_detail": parallelism_detail(a, pipe, per_rank, s)} if per_rank is not None else {}),
                        "stage_D_rule": rule_name,
                        "velocity_chain": "folded into the staging of d[c] in the stage-D kernel" if a.fuse else "k_velocity_chain (dmat materialised)",
                        "cell_order_D": a.order + (f" ({a.curve} curve)" if a.order == "embedding" else "")},
             "roofline": roof, "stages": stages,
         }
-        if world == 1 and not a.no_extra and a.dtype == "f32" and a.counts == "auto":
-            res["extra"] = extra_lines(a, dev, pipe)
-            # ---- the same pass in its three arithmetic modes, in one place.  `value` is the production mode (f32 storage, the
-            #      no-pseudocount form of the partial-sqrt rule where ops.partial_rules_for admits it); the reference itself is fp64
-            #      with the literal rule (speedboosted.pyx:352-443): that run is the top-level `f64` object, with its own roofline.
-            modes = {"f32_production": {"cells_per_s": res["value"], "ms_per_step": ms_per_step, "D_ms": d_ms, "stage_D_rule": rule_name,
-                                        "is": "`value`: the K timed steps of this run"}}
-            lit = res["extra"].get("randomised_control", {}).get("literal_rule")
-            if lit:                                  # the whole pass with the literal rule in stage D: this run's other stages + the literal launch
-                ms_lit = ms_per_step - d_ms + lit["D_single_ms"]
-                lit["whole_pass_ms"] = ms_lit
-                lit["whole_pass_cells_per_s"] = C / (ms_lit * 1e-3)
-                modes["f32_literal_rule"] = {"cells_per_s": C / (ms_lit * 1e-3), "ms_per_step": ms_lit, "D_ms": lit["D_single_ms"],
-                                             "stage_D_rule": pipe.ops.RULE_NAMES[pipe.ops.RULES_PARTIAL],
-                                             "max_abs_dcorr_vs_production_all_pairs": lit["max_abs_dcorr_all_pairs"],
-                                             "is": "this run's stages A-C + one stage-D launch with VCY_RULES_PARTIAL"}
-            f64 = res["extra"].pop("f64", None)
-            if f64:
-                res["f64"] = f64
-                modes["f64_reference_arithmetic"] = {"cells_per_s": f64["value"], "ms_per_step": f64["ms_per_step"], "D_ms": f64["stage_ms"]["D_coldeltacor"],
-                                                     "stage_D_rule": pipe.ops.RULE_NAMES[pipe.ops.RULES_PARTIAL],
-                                                     "max_abs_dcorr_vs_production_all_pairs": f64["f32_vs_f64"]["max_abs_dcorr_all_pairs"],
-                                                     "is": "top-level `f64`: f64 storage and moments, literal rule, timed steps of a second pipeline on the same inputs"}
-            res["precision_modes"] = modes
+        if world == 1 and not a.no_extra and a.counts == "auto":
+            res["precision_modes"], res["extra"] = extra_lines(a, dev, pipe, res)
+            # the key numbers of the extra lines as scalars of `config` (the driver's record keeps scalars)
+            res["config"].update(extra_scalars(res["extra"], res["precision_modes"]))
         if not a.no_cpu_baseline and world == 1:     # reported on rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(pipe, a)
     finish(res, rank)
@@ -716,49 +720,236 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def extra_lines(a, dev, pipe):
-    """Same workload, one GPU: (1) stage D with the randomised control, (2) uint16 count layers, (3) the reference's own
-    arithmetic (f64 storage and accumulation) incl. the largest f32-vs-f64 difference over ALL correlations and gammas."""
-    out = {"randomised_control": pipe.time_dual()}
-    data = (pipe.cS, pipe.cU, pipe.fS, pipe.fU, pipe.pcs)
-    corr32, gamma32 = pipe.corr_loc.clone(), pipe.last_gamma.clone()
-    pipe.step()                                       # (time_dual overwrote corr_loc with the same values; keep it simple)
-    corr32 = pipe.corr_loc.clone()
+def _short(p, steps):
+    """One untimed + `steps` timed steps of a pipeline (wall clock between device syncs, HIP-event stage times inside)."""
+    p.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        p.step(timed=True)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
 
-    def short(p, steps):
-        p.step()
+
+def wide_list_line(a, dev, pipe):
+    """Stage D at the reference's DEFAULT list width (analysis.py:1452-1457: n_neighbors = cells / 5, sampled_fraction = 0.3 =>
+    nrndm = int(0.3 * (n_neighbors + 1)); 3000 at 50 000 cells), on the headline pipeline's pooled matrices and gammas, velocity
+    chain folded in: one launch in column tiles (ops.coldeltacor_partial_fused), timed by HIP events."""
+    ops = pipe.ops
+    C = a.cells
+    nn = C // 5
+    emb = pipe.pcs[:, :2].contiguous()
+    wide, _ = sample_neighbors_device(emb, nn, 0.3, dev)
+    out = torch.empty((C, wide.shape[1]), dtype=pipe.dtype, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.coldeltacor_partial_fused(pipe.e_rows, pipe.Ux_loc, pipe.last_gamma, None, wide, ops.SQRT, pipe.rules, 1e-10, order=pipe.order, out=out, validate=False)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    pairs = float(C) * wide.shape[1]
+    fin = torch.isfinite(out)
+    return {"ms": ms, "launches_timed": 1, "nrndm": int(wide.shape[1]), "n_neighbors": nn, "sampled_fraction": 0.3, "dtype": a.dtype,
+            "ns_per_pair": ms * 1e6 / pairs, "ns_per_pair_at_nrndm_250": float(np.mean(pipe.d_ms)) * 1e6 / (float(C) * pipe.nrndm),
+            "finite_fraction": float(fin.float().mean()), "max_abs_corr": float(out[fin].abs().max()),
+            "note": "estimate_transition_prob's defaults (analysis.py:1452-1457); the compact (cells, 3000) output, one launch"}
+
+
+def facade_lines(a, dev, data, dtype, passes=2, n_markov=2500):
+    """The VelocytoLoom facade (velocyto_amd.analysis, the reference's own method names and defaults) on the headline dataset,
+    method by method: wall clock between device syncs, last of `passes` passes (the first pays the allocations).  Gives the
+    lines SURVEY.md 8(d) lists beside the headline: default fit_gammas (B), calculate_embedding_shift (E), prepare_markov +
+    run_markov (F) - and the facade's own cost of A and D (randomised control included) for comparison with the kernel times."""
+    import velocyto_amd as vcy
+    cS, cU, fS, fU, pcs = data
+    vlm = vcy.analysis.VelocytoLoom.from_arrays(cS, cU, dtype=dtype)
+    vlm.pcs = pcs.cpu().numpy()
+    vlm.ts = vlm.pcs[:, :2].copy()
+    out = {}
+
+    def timed(name, fn, *args, **kw):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            p.step(timed=True)
+        fn(*args, **kw)
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / steps * 1e3
-    if pipe.cS.t.dtype == torch.uint8:
-        p16 = Pipeline(a, dev, 0, 1, dtype=torch.float32, data=data, counts="u16")
-        ms = short(p16, 2)
-        st = p16.stage_ms / 2
-        out["uint16_layers"] = {"ms_per_step": ms, "cells_per_s": a.cells / (ms * 1e-3), "A_pooling_ms": st[6],
-                                "note": "the loom's on-disk type (constants.py:11); taken when any count of a layer exceeds 255",
-                                "same_results_as_uint8": bool(torch.equal(p16.corr_loc, corr32))}
-        del p16
-    pipe.Sx_loc = pipe.e_rows = pipe.Ux_loc = None     # make room: the f64 pipeline holds 2 x 12 GB at 50k x 30k
+        out[name] = (time.perf_counter() - t0) * 1e3
+    for _ in range(passes):
+        timed("normalize_ms", vlm.normalize, "both", size=True, log=False)
+        timed("A_knn_imputation_ms", vlm.knn_imputation, k=a.k, n_pca_dims=a.pca_dims)
+        timed("B_fit_gammas_default_ms", vlm.fit_gammas)
+        timed("B_fit_gammas_plain_ms", vlm.fit_gammas, fit_offset=False, weighted=False)
+        timed("C_predict_U_ms", vlm.predict_U)
+        timed("C_calculate_velocity_ms", vlm.calculate_velocity)
+        timed("C_calculate_shift_ms", vlm.calculate_shift)
+        timed("C_extrapolate_cell_at_t_ms", vlm.extrapolate_cell_at_t)
+        timed("D_estimate_transition_prob_ms", vlm.estimate_transition_prob, hidim="Sx_sz", embed="ts", n_neighbors=a.n_neighbors,
+              sampled_fraction=a.sampled_fraction)
+        timed("E_calculate_embedding_shift_ms", vlm.calculate_embedding_shift)
+        timed("F_prepare_markov_ms", vlm.prepare_markov, 2.0, 4.0)
+        timed("F_run_markov_ms", vlm.run_markov, n_steps=n_markov)
+    out["F_run_markov_steps"] = n_markov
+    out["F_run_markov_ms_per_step"] = out["F_run_markov_ms"] / n_markov
+    out["dtype"] = "f64" if dtype == torch.float64 else "f32"
+    out["torch_peak_GiB"] = torch.cuda.max_memory_allocated() / 2 ** 30
+    out["note"] = ("velocyto_amd.analysis.VelocytoLoom methods with the reference's defaults unless a value is named: knn_imputation(k, n_pca_dims), "
+                   "fit_gammas() (maxmin_diag weights, offset), estimate_transition_prob(n_neighbors, sampled_fraction; randomised control in the same "
+                   "dual launch, numpy's sampling stream replayed on the host), calculate_embedding_shift() (expression scaling, control), "
+                   "prepare_markov(2, 4), run_markov(2500); steady-state pass")
+    del vlm
     torch.cuda.empty_cache()
-    p64 = Pipeline(a, dev, 0, 1, dtype=torch.float64, data=data)
-    n64 = 2
-    ms = short(p64, n64)
-    st = p64.stage_ms / n64
-    ok = torch.isfinite(p64.corr_loc) & torch.isfinite(corr32)
-    dcorr = float((p64.corr_loc[ok] - corr32[ok].double()).abs().max())
-    g64, g32 = p64.last_gamma.double(), gamma32.double()
-    dgam = float(((g64 - g32).abs() / g64.abs().clamp(min=1e-30))[g64 > 0].max())
-    out["f64"] = {"dtype": "f64", "value": a.cells / (ms * 1e-3), "unit": "cells/s", "ms_per_step": ms, "steps": n64, "warmup": 1,
-                  "stage_ms": {"A_knn_imputation": st[0], "B_fit_slope": st[1], "C_velocity_chain": st[2], "D_coldeltacor": st[4]},
-                  "stage_D_rule": p64.ops.RULE_NAMES.get(p64.rules, str(p64.rules)),
-                  "roofline": dominant_roofline(a, p64, float(np.mean(p64.d_ms)), "f64"),
-                  "f32_vs_f64": {"max_abs_dcorr_all_pairs": dcorr, "pairs_compared": int(ok.sum()), "nan_pattern_equal": bool(torch.equal(torch.isnan(p64.corr_loc), torch.isnan(corr32))),
-                                 "max_rel_dgamma": dgam},
-                  "note": "the reference's arithmetic (speedboosted.pyx:13-538 is fp64 throughout): f64 storage of Sx/Ux, f64 moments, literal branch rule, "
-                          "same kernels and the same inputs as the timed f32 run"}
+    return out
+
+
+def cfg2_lines(a, dev, dtype):
+    """BASELINE.json configs[1]: synthetic 10 000 cells x 20 000 genes, k = 30, 30 PCs, stages A + B through the
+    facade (knn_imputation -> fit_gammas(fit_offset=False, weighted=False) = fit_slope), unbalanced and balanced=True, b_sight=240, b_maxl=120."""
+    import velocyto_amd as vcy
+    C, G = 10000, 20000
+    cS, cU, fS, fU, pcs = synth_counts(C, G, a.pca_dims, dev, seed=20180810)
+    vlm = vcy.analysis.VelocytoLoom.from_arrays(cS, cU, dtype=dtype)
+    vlm.pcs = pcs.cpu().numpy()
+    vlm.normalize("both", size=True, log=False)
+    out = {"cells": C, "genes": G, "k": a.k, "dtype": "f64" if dtype == torch.float64 else "f32"}
+
+    def timed(fn, **kw):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(**kw)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3
+    for name, kw in (("unbalanced", {}), ("balanced", dict(balanced=True, b_sight=240, b_maxl=120))):
+        for _ in range(2):                          # second pass = steady state
+            tA = timed(vlm.knn_imputation, k=a.k, n_pca_dims=a.pca_dims, **kw)
+            tB = timed(vlm.fit_gammas, fit_offset=False, weighted=False)
+        out[name] = {"A_knn_imputation_ms": tA, "B_fit_slope_ms": tB, "cells_per_s": C / ((tA + tB) * 1e-3)}
+    out["note"] = "facade calls, wall clock between device syncs, second pass; balanced = BalancedKNN(sight_k=240, maxl=120) with the greedy balancing on the host (vcy_balance_knn_host32)"
+    del vlm
+    torch.cuda.empty_cache()
+    return out
+
+
+def extra_lines(a, dev, pipe, res):
+    """Everything beside the headline, same workload, one GPU.  Returns (precision_modes, extra).  Every line is guarded: a
+    failure or an exhausted time budget is recorded in the line, never raised - the headline is already measured."""
+    ops = pipe.ops
+    t_start = time.perf_counter()
+    C = a.cells
+    main_f64 = a.dtype == "f64"
+    data = (pipe.cS, pipe.cU, pipe.fS, pipe.fU, pipe.pcs)
+    extra, modes = {}, {}
+
+    def guarded(name, fn, store=extra):
+        spent = time.perf_counter() - t_start
+        if spent > a.extra_budget_s:
+            store[name] = {"skipped": f"time budget of the extra lines ({a.extra_budget_s:.0f} s) spent"}
+            return None
+        try:
+            t0 = time.perf_counter()
+            r = fn()
+            if isinstance(r, dict):
+                r["wall_s"] = time.perf_counter() - t0
+            store[name] = r
+            return r
+        except Exception as e:                                                  # noqa: BLE001
+            torch.cuda.synchronize()
+            store[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            return None
+
+    # ---- (1) stage D with the randomised control (dual launch) and at the reference's default list width, on the headline pipeline
+    guarded("randomised_control", lambda: pipe.time_dual(reps=2))
+    pipe.step()                                       # time_dual left corr_loc with the same values; keep it simple
+    torch.cuda.synchronize()
+    corr_main, gamma_main = pipe.corr_loc.clone(), pipe.last_gamma.clone()
+    guarded("D_reference_defaults_nrndm3000", lambda: wide_list_line(a, dev, pipe))
+    d_main = float(np.mean(pipe.d_ms))
+    pipe.Sx_loc = pipe.e_rows = pipe.Ux_loc = None     # make room for the other pipelines and the facade
+    torch.cuda.empty_cache()
+
+    # ---- (2) the same pass in the build's other arithmetic modes
+    def other_modes():
+        other = torch.float32 if main_f64 else torch.float64
+        oname = "f32" if main_f64 else "f64"
+        po = Pipeline(a, dev, 0, 1, dtype=other, data=data)
+        n = 3 if main_f64 else 2
+        ms = _short(po, n)
+        st = po.stage_ms / n
+        d_o = float(np.mean(po.d_ms))
+        ok = torch.isfinite(po.corr_loc) & torch.isfinite(corr_main)
+        dcorr = float((po.corr_loc[ok].double() - corr_main[ok].double()).abs().max())
+        g_a, g_b = po.last_gamma.double(), gamma_main.double()
+        g64 = g_b if main_f64 else g_a
+        dgam = float(((g_a - g_b).abs() / g64.abs().clamp(min=1e-30))[g64 > 0].max())
+        rule_o = ops.RULE_NAMES.get(po.rules, str(po.rules))
+        cmpd = {"max_abs_dcorr_all_pairs": dcorr, "pairs_compared": int(ok.sum()),
+                "nan_pattern_equal": bool(torch.equal(torch.isnan(po.corr_loc), torch.isnan(corr_main))), "max_rel_dgamma": dgam}
+        key = "f32_production" if main_f64 else "f64_reference_arithmetic"
+        modes[key] = {"dtype": oname, "cells_per_s": C / (ms * 1e-3), "ms_per_step": ms, "steps": n, "warmup": 1, "D_ms": d_o, "stage_D_rule": rule_o,
+                      "stage_ms": {"A_knn_imputation": st[0], "A_knn_search": st[5], "A_pooling": st[6], "B_fit_slope": st[1], "C_velocity_chain": st[2], "D_coldeltacor": st[4]},
+                      "roofline": dominant_roofline(a, po, d_o, oname), "vs_headline": cmpd,
+                      "is": ("f32 storage and lane accumulators, the no-pseudocount form of the rule where ops.partial_rules_for admits it: the build's production "
+                             "mode, narrower than the reference's arithmetic - reported, not the headline") if main_f64 else
+                            "f64 storage and moments, literal rule: the reference's arithmetic"}
+        if other == torch.float32:
+            dual = po.time_dual(reps=2)               # f32: dual control, and the literal rule in the same launch shape
+            modes[key]["randomised_control"] = {k: dual[k] for k in ("D_single_ms", "D_dual_ms", "dual_over_single")}
+            lit = dual.get("literal_rule")
+            if lit:
+                ms_lit = ms - d_o + lit["D_single_ms"]
+                modes["f32_literal_rule"] = {"dtype": "f32", "cells_per_s": C / (ms_lit * 1e-3), "ms_per_step": ms_lit, "D_ms": lit["D_single_ms"],
+                                             "stage_D_rule": ops.RULE_NAMES[ops.RULES_PARTIAL],
+                                             "max_abs_dcorr_vs_f32_production_all_pairs": lit["max_abs_dcorr_all_pairs"], "nan_pattern_equal": lit["nan_pattern_equal"],
+                                             "is": "the f32 run's stages A-C + one stage-D launch with VCY_RULES_PARTIAL (pseudocount kept)"}
+            po.step()
+            torch.cuda.synchronize()
+            if po.cS.t.dtype == torch.uint8:
+                c32 = po.corr_loc.clone()
+                p16 = Pipeline(a, dev, 0, 1, dtype=torch.float32, data=data, counts="u16")
+                ms16 = _short(p16, 2)
+                modes["f32_uint16_layers"] = {"dtype": "f32", "ms_per_step": ms16, "cells_per_s": C / (ms16 * 1e-3), "A_pooling_ms": (p16.stage_ms / 2)[6],
+                                              "same_results_as_uint8": bool(torch.equal(p16.corr_loc, c32)),
+                                              "is": "the loom's on-disk count type (constants.py:11); taken when any count of a layer exceeds 255"}
+                del p16, c32
+        del po
+        torch.cuda.empty_cache()
+        return None
+    guarded("_modes", other_modes, store=modes)
+    failed = modes.pop("_modes", None)
+    if failed:
+        modes["not_measured"] = failed
+    modes["headline"] = {"dtype": a.dtype, "cells_per_s": res["value"], "ms_per_step": res["ms_per_step"], "D_ms": d_main,
+                         "stage_D_rule": ops.RULE_NAMES.get(pipe.rules, str(pipe.rules)), "is": "`value`: the K timed steps of this run"}
+    del corr_main
+
+    # ---- (3) the facade lines (E, F, default fit_gammas) and cfg2, in the headline arithmetic
+    dtype = torch.float64 if main_f64 else torch.float32
+    guarded("facade", lambda: facade_lines(a, dev, data, dtype))
+    guarded("cfg2", lambda: cfg2_lines(a, dev, dtype))
+    extra["wall_s_total"] = time.perf_counter() - t_start
+    return modes, extra
+
+
+def extra_scalars(extra, modes):
+    """The extra lines' key numbers, flat (E, F, default fit_gammas, the nrndm = 3000 secondary, cfg2)."""
+    out = {}
+    fac = extra.get("facade") or {}
+    for k in ("E_calculate_embedding_shift_ms", "F_prepare_markov_ms", "F_run_markov_ms_per_step", "F_run_markov_steps", "B_fit_gammas_default_ms",
+              "A_knn_imputation_ms", "D_estimate_transition_prob_ms"):
+        if k in fac:
+            out[("facade_" + k) if k[0] in "AD" else k] = fac[k]
+    w = extra.get("D_reference_defaults_nrndm3000") or {}
+    if "ms" in w:
+        out["D_reference_defaults_nrndm3000_ms"] = w["ms"]
+    rc = extra.get("randomised_control") or {}
+    if "dual_over_single" in rc:
+        out["D_dual_control_over_single"] = rc["dual_over_single"]
+    c2 = extra.get("cfg2") or {}
+    for name in ("unbalanced", "balanced"):
+        if name in c2:
+            out[f"cfg2_{name}_A_ms"] = c2[name]["A_knn_imputation_ms"]
+            out[f"cfg2_{name}_B_ms"] = c2[name]["B_fit_slope_ms"]
+    for key, short in (("f32_production", "f32_production"), ("f32_literal_rule", "f32_literal"), ("f64_reference_arithmetic", "f64")):
+        if key in modes and "cells_per_s" in modes[key]:
+            out[f"{short}_cells_per_s"] = modes[key]["cells_per_s"]
     return out
 
 

@@ -58,6 +58,8 @@ typedef enum {
 typedef void *vcy_stream;  /* hipStream_t */
 
 const char *vcy_last_error(void);
+/* 2 (round 4).  History: 1 -> 2: vcy_diffuse_step_factored gained `int prepared` before compute_dtype; vcy_gram added;
+ * vcy_knn_pool_csr requires >= 4 stored elements.  A binder refuses a library whose version it was not built against. */
 int vcy_abi_version(void);
 /* Number of CUs / LDS bytes per workgroup of the current device (host query). */
 int vcy_device_info(int *cu_count, int *lds_bytes_per_block, int64_t *hbm_bytes);
@@ -183,7 +185,10 @@ int vcy_knn_pool_counts(const void *countsS, const void *countsU, const double *
  * `dtype`; g_indptr / g_indices / w: the kNN graph rows of the C_out output cells (entries name CSR rows);
  * scale (C) per-row size factors; maximum: np.maximum with the cell's own scaled counts (row cell0 + c).  Results are
  * bit-identical to vcy_knn_pool_counts on the densified layer.  slabptr: the table vcy_csr_slab_ptr fills,
- * C x (ceil(G / vcy_csr_slab_genes()) + 1) int32 = offsets inside each row of the first non-zero of every gene slab.  */
+ * C x (ceil(G / vcy_csr_slab_genes()) + 1) int32 = offsets inside each row of the first non-zero of every gene slab.
+ * `indices` and `data` must hold at least 4 elements (the kernel reads quads of consecutive non-zeros with 16-byte loads,
+ * pulled back to end inside the arrays): a layer with fewer than 4 non-zeros is padded by the caller; elements at or past
+ * indptr[C] belong to no row and never enter a result.  */
 int64_t vcy_csr_slab_genes(void);
 int vcy_csr_slab_ptr(const int64_t *indptr, const int32_t *indices, int32_t *slabptr, int64_t C, int64_t G, vcy_stream stream);
 int vcy_knn_pool_csr(const int64_t *indptr, const int32_t *indices, const void *data, const int32_t *slabptr, const double *scale,

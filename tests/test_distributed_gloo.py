@@ -206,3 +206,43 @@ def test_overlap_schedules_round_alignment():
     # fewer interior cells than one round: nothing runs before the halo has landed
     first, second = D.overlap_schedules(base, torch.zeros(n, dtype=torch.bool).index_fill_(0, base[:100], True), 2048)
     assert first.numel() == 0 and torch.equal(second.long(), base)
+
+
+def _self_check_worker(rank, world, port, inject, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), VCY_SELF_CHECK_FAIL=inject)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import velocyto_amd
+        from velocyto_amd import distributed as D
+        q.put((rank, D.self_check(torch.device("cpu"))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,inject", [(2, ""), (3, ""), (3, "all_to_all_uneven@1")])
+def test_collective_self_check(world, inject):
+    """distributed.self_check: every collective shape of the sharded path on tiny tensors (uneven all-to-all with empty
+    segments, ragged and equal all-gathers, SUM / MIN all-reduces, the halo masks).  A failure on ONE rank becomes the same
+    verdict on every rank (bench.py then switches all of them to --exchange allgather)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_self_check_worker, args=(r, world, port, inject, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from velocyto_amd import distributed as D
+    for rank, res in got.items():
+        assert set(res["agreed"]) == set(D.SELF_CHECKS)
+        if not inject:
+            assert all(res[n] == "ok" for n in D.SELF_CHECKS), res
+            assert all(res["agreed"].values())
+        else:
+            name, bad_rank = inject.split("@")
+            assert (res[name] != "ok") == (rank == int(bad_rank))              # only that rank saw it fail ...
+            assert res["agreed"][name] is False                                # ... every rank knows
+            assert all(ok for n, ok in res["agreed"].items() if n != name)

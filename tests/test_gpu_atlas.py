@@ -99,6 +99,34 @@ def test_knn_pool_csr_bit_identical_to_dense(ops, dtype, big, G):
     np.testing.assert_allclose(got, ref_o, rtol=2e-6 if dtype == "float32" else 1e-12, atol=1e-6 if dtype == "float32" else 1e-12)
 
 
+@pytest.mark.parametrize("nnz", [0, 1, 3, 4, 5])
+def test_knn_pool_csr_layers_with_a_handful_of_nonzeros(ops, nnz):
+    """A CSR layer holding fewer non-zeros than one 16-byte quad of the pooling kernel (its loads are pulled back to end inside
+    the arrays): the container pads the stored arrays to 4 elements (contract of vcy_knn_pool_csr, velocyto_hip.h), the padding
+    belongs to no row, and pooling equals the dense kernel bit for bit - also when the few non-zeros sit in the LAST row."""
+    rng = np.random.default_rng(nnz)
+    C, G, k = 40, 700, 5
+    a = np.zeros((C, G), dtype=np.int64)
+    spots = [(C - 1, G - 1), (C - 1, 3), (0, 0), (17, 350), (C - 1, 100)][:nnz]
+    for r, g in spots:
+        a[r, g] = rng.integers(1, 200)
+    dense = ops.CountMatrix.from_genes_major(a.T.copy())
+    csr = ops.CsrCounts.from_dense(dense)
+    assert csr.nnz == nnz and csr.indices.numel() == nnz and csr.data.numel() == nnz and csr._istore.numel() >= 4
+    assert np.array_equal(csr.to_dense().as_int32().cpu().numpy(), a) and np.array_equal(csr.row_sums().cpu().numpy(), a.sum(1))
+    indptr = np.arange(0, C * k + 1, k)
+    indices = np.concatenate([rng.choice(C, k, replace=False) for _ in range(C)]).astype(np.int32)
+    indices[(C - 1) * k] = C - 1                              # somebody pools the last row
+    w = rng.random(indices.size)
+    scale = torch.as_tensor(rng.gamma(4.0, 0.25, C))
+    for dtype in ("float32", "float64"):
+        for maximum in (False, True):
+            ref = ops.knn_pool_counts(dense, None, scale, None, indptr, indices, w, dtype=dtype, maximum=maximum)
+            got = ops.knn_pool_csr(csr, scale, indptr, indices, w, dtype=dtype, maximum=maximum)
+            assert torch.equal(got.t, ref.t)
+    assert np.array_equal(csr.rows(torch.tensor([C - 1, 0, 17])).to_dense().as_int32().cpu().numpy(), a[[C - 1, 0, 17]])
+
+
 def _dense_reference(ops, atlas, cS, cU, fS, fU, pcs, emb, k, n_neighbors, frac):
     """The resident dense path on the same data: knn_pool_counts -> fit_slope -> fused stage D with a full-height e."""
     C = cS.C

@@ -1,0 +1,71 @@
+"""The ONE JSON line of bench.py, with everything SURVEY.md 8(d) asks for, on a small instance of the workload: the headline in
+the reference's arithmetic (f64, literal rule) with its roofline block, the narrower production modes beside it, the extra
+lines (E, F, default fit_gammas, the reference-default list width, the randomised control, cfg2) and the CPU baseline with
+its parity block.  The full-size numbers are the driver's; this test pins the STRUCTURE the driver's record is parsed from
+and that no guarded line fails."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_structure():
+    from velocyto_amd import ops
+    ops.require_gpu()
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "bench.py", "--cells", "6000", "--genes", "2048", "--n-neighbors", "100", "--k", "12", "--steps", "2", "--warmup", "1",
+           "--cpu-cells", "128", "--extra-budget-s", "300"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.strip()]
+    j = json.loads(lines[-1])
+    # ---- the headline: the reference's arithmetic, timed with the flags given
+    assert j["dtype"] == "f64" and j["steps"] == 2 and j["warmup"] == 1 and j["n_gpus"] == 1 and j["unit"] == "cells/s"
+    assert abs(j["value"] - 6000 / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
+    assert "literal" in j["config"]["stage_D_rule"] and j["config"]["arithmetic"].startswith("f64")
+    roof = j["roofline"]
+    assert roof["dtype"] == "f64" and "double" in roof["kernel"] and roof["bound"] == "valu" and roof["avg_launch_ms"] > 0
+    for k in ("A_knn_search_ms", "A_pooling_ms", "B_fit_slope_ms", "D_coldeltacor_ms"):
+        assert j["config"][k] > 0
+    # ---- the production modes beside it, each with its own roofline block and its distance from the headline
+    pm = j["precision_modes"]
+    assert "not_measured" not in pm, pm.get("not_measured")
+    f32 = pm["f32_production"]
+    assert f32["dtype"] == "f32" and f32["roofline"]["dtype"] == "f32" and "float" in f32["roofline"]["kernel"]
+    assert f32["vs_headline"]["max_abs_dcorr_all_pairs"] < 5e-5 and f32["vs_headline"]["nan_pattern_equal"]
+    assert f32["cells_per_s"] > j["value"]                                  # narrower arithmetic is faster - and is not the headline
+    assert pm["headline"]["dtype"] == "f64"
+    # ---- SURVEY 8(d)'s other lines, all present and none of them failed or skipped
+    ex = j["extra"]
+    for name in ("randomised_control", "D_reference_defaults_nrndm3000", "facade", "cfg2"):
+        assert name in ex and "error" not in ex[name] and "skipped" not in ex[name], (name, ex.get(name))
+    fac = ex["facade"]
+    for k in ("B_fit_gammas_default_ms", "E_calculate_embedding_shift_ms", "F_prepare_markov_ms", "F_run_markov_ms", "F_run_markov_ms_per_step",
+              "A_knn_imputation_ms", "D_estimate_transition_prob_ms"):
+        assert fac[k] > 0, k
+    assert fac["dtype"] == "f64" and fac["F_run_markov_steps"] == 2500
+    wide = ex["D_reference_defaults_nrndm3000"]
+    assert wide["n_neighbors"] == 1200 and wide["nrndm"] == int(0.3 * 1201) and wide["finite_fraction"] > 0.99 and wide["max_abs_corr"] <= 1.0 + 1e-9
+    c2 = ex["cfg2"]
+    assert (c2["cells"], c2["genes"]) == (10000, 20000)
+    for name in ("unbalanced", "balanced"):
+        assert c2[name]["A_knn_imputation_ms"] > 0 and c2[name]["B_fit_slope_ms"] > 0
+    assert ex["randomised_control"]["dual_over_single"] < 2.0
+    # ---- the same numbers as scalars of `config` (what the driver's record keeps)
+    cfg = j["config"]
+    for k in ("E_calculate_embedding_shift_ms", "F_run_markov_ms_per_step", "B_fit_gammas_default_ms", "D_reference_defaults_nrndm3000_ms",
+              "cfg2_unbalanced_A_ms", "cfg2_unbalanced_B_ms", "cfg2_balanced_A_ms", "cfg2_balanced_B_ms", "f32_production_cells_per_s", "D_dual_control_over_single"):
+        assert isinstance(cfg[k], float) and cfg[k] > 0, k
+    # ---- CPU baseline: the oracle on the host cores, with the HIP path's distance from it on the same sub-problem
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert cb["parity"]["f64"]["max_abs_dcorr"] < 1e-9 and cb["parity"]["f32_nopsc"]["max_abs_dcorr"] < 5e-5

@@ -23,12 +23,12 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ARGS = ["--no-cpu-baseline", "--cells", "4100", "--genes", "1536", "--n-neighbors", "100", "--k", "12", "--steps", "1", "--warmup", "1"]
+ARGS = ["--no-cpu-baseline", "--no-extra", "--cells", "4100", "--genes", "1536", "--n-neighbors", "100", "--k", "12", "--steps", "1", "--warmup", "1"]
 
 
-def run(world, dump, extra=(), port=29611, backend="gloo", force="1", self_launch=False):
+def run(world, dump, extra=(), port=29611, backend="gloo", force="1", self_launch=False, env_extra=None):
     env = dict(os.environ, VCY_SINGLE_DEVICE="1", VCY_DIST_BACKEND=backend, VCY_FORCE_COLLECTIVES=force, MASTER_PORT=str(port),
-               MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+               MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     if world == 1 or self_launch:            # self_launch: bench.py spawns its own ranks (no torch.distributed.run wrapper)
@@ -55,6 +55,23 @@ def test_sharded_pipeline_equals_one_rank(tmp_path, world, extra):
     assert np.array_equal(np.isfinite(many["corr"]), fin)
     np.testing.assert_allclose(many["corr"][fin], one["corr"][fin], atol=2e-6)
     assert one["corr"].shape == (4100, 50) and fin.mean() > 0.99
+
+
+def test_failed_collective_self_check_falls_back_to_allgather(tmp_path):
+    """bench.py's start-up self-check (distributed.self_check): the uneven all-to-all made to fail on rank 1 only -> every rank
+    reports it by name, the run switches to --exchange allgather on all ranks and still reproduces the one-rank results."""
+    import json
+    from velocyto_amd import ops
+    ops.require_gpu()
+    one, j1 = run(1, str(tmp_path / "one.npz"), port=29671)
+    many, j2 = run(2, str(tmp_path / "two.npz"), port=29672, env_extra={"VCY_SELF_CHECK_FAIL": "all_to_all_uneven@1"})
+    chk1, chk2 = json.loads(j1)["collective_self_check"], json.loads(j2)["collective_self_check"]
+    assert chk1.startswith("all ok") and "all_to_all_uneven" in chk1                 # forced collectives at one rank: checks ran
+    assert chk2.startswith("FAILED: all_to_all_uneven") and chk2.endswith("-> --exchange allgather")
+    assert "all-gather of Sx shards" in json.loads(j2)["config"]["parallelism"]
+    assert np.array_equal(one["neigh"], many["neigh"])
+    fin = np.isfinite(one["corr"])
+    np.testing.assert_allclose(many["corr"][fin], one["corr"][fin], atol=2e-6)
 
 
 def test_rccl_collectives_on_one_gpu(tmp_path):
@@ -132,8 +149,11 @@ def test_eight_ranks_at_full_size_on_one_device(tmp_path):
     assert sum(r["halo_rows_received"] for r in ranks) == sum(r["halo_rows_sent"] for r in ranks)
     assert all(0 < r["interior_cells"] < 6250 for r in ranks) and all(r["stage_ms"]["D_coldeltacor"] > 0 for r in ranks)
     # the launch that overlaps the transfer holds whole device rounds of interior cells (distributed.overlap_schedules)
-    assert all(r["cells_run_while_the_halo_moves"] % 2048 == 0 and r["cells_run_while_the_halo_moves"] <= r["interior_cells"] for r in ranks)
+    per_round = 256 * (6 if j8["dtype"] == "f64" else 8)        # one workgroup per CU, 6 (f64) / 8 (f32) cells per workgroup
+    assert all(r["cells_run_while_the_halo_moves"] % per_round == 0 and r["cells_run_while_the_halo_moves"] <= r["interior_cells"] for r in ranks)
     b = det["bytes_per_collective"]
-    assert b["B_all_reduce_fit_moments"] == 3 * 30000 * 8 and b["D_all_gather_correlation_rows_total"] == 50000 * 250 * 4
-    assert b["D_halo_all_to_all_received_per_rank"] == [r["halo_rows_received"] * 30016 * 4 for r in ranks]
+    es = {"f32": 4, "f64": 8}[j8["dtype"]]                  # the bench's default arithmetic is the reference's (f64)
+    assert j8["dtype"] == j1["dtype"] == "f64"
+    assert b["B_all_reduce_fit_moments"] == 3 * 30000 * 8 and b["D_all_gather_correlation_rows_total"] == 50000 * 250 * es
+    assert b["D_halo_all_to_all_received_per_rank"] == [r["halo_rows_received"] * 30016 * es for r in ranks]
     assert j8["config"]["stage_D_rule"] == j1["config"]["stage_D_rule"]

@@ -191,6 +191,21 @@ def test_facade_fit_gammas_steady_state(vcy, golden, oracle, dtype):
         ge, qe, r2e = oracle.fit_gammas(g["Sx"], g["Ux"], g["Sx"], g["Ux"], exact=True, steady_state=m, **kw)
         close(vlm.gammas, ge, max(gt, 1e-5), max(gt, 1e-6))
         close(vlm.q, qe, max(gt, 1e-5), max(gt, 1e-5))
+    # an array of cell INDICES selects like the mask does (tmpS[:, steady_state] takes both in the reference); a shuffled index
+    # array gives the same sums in another order, a repeated cell counts twice (numpy's fancy indexing)
+    idx = np.flatnonzero(m)
+    vlm.fit_gammas(steady_state_bool=idx, fit_offset=False, weighted=False)
+    assert np.array_equal(vlm.steady_state, idx)
+    close(vlm.gammas, st["gammas_plain"], gt, 0)
+    vlm.fit_gammas(steady_state_bool=list(idx[::-1] - len(m)), fit_offset=False, weighted=False)       # negative numbers count from the end
+    close(vlm.gammas, st["gammas_plain"], max(gt, 1e-12), 0)
+    twice = np.concatenate([idx, idx[:5]])
+    vlm.fit_gammas(steady_state_bool=twice, fit_offset=False, weighted=False)
+    close(vlm.gammas, np.nan_to_num(oracle.fit_slope(g["Ux"][:, twice], g["Sx"][:, twice])), max(gt, 1e-6), 0)      # NaN -> 0 (:1260)
+    with pytest.raises(IndexError):
+        vlm.fit_gammas(steady_state_bool=np.array([0, len(m)]))
+    with pytest.raises(ValueError):
+        vlm.fit_gammas(steady_state_bool=np.zeros(len(m), dtype=bool))
     # the whole-dataset fit is untouched by a previous masked call
     vlm.fit_gammas()
     assert vlm.steady_state.all()

@@ -414,3 +414,92 @@ def sparse_from_lists(dsi, dist, n):
     m = sparse.csr_matrix((dist.ravel(), dsi.ravel(), np.arange(0, dsi.size + 1, dsi.shape[1])), shape=(n, n))
     m.sort_indices()
     return m
+
+
+def test_fullsize_stage_d_reference_default_list_width_against_the_oracle(world, oracle):
+    """Stage D at the headline size with the reference's DEFAULT neighbour lists (analysis.py:1452-1457, 1528-1572: n_neighbors =
+    cells / 5 = 10 000, sampled_fraction = 0.3 => nrndm = 3000, walked in 12+ column tiles per group) against the fp64 oracle on
+    32 whole cells x ALL 3000 columns x 30 000 genes: 16 cells from the middle of the launch schedule and the LAST 16 of it
+    (the groups beyond the last full round, which run as narrower column tiles).  Every arithmetic mode of the build:
+    f64 storage with the literal rule (the reference's arithmetic, 1e-9), f32 with the production rule and with the literal
+    rule (5e-5); the fused launch and the fused dual-control launch (the control's correlations against the oracle too, and the
+    real ones of the dual launch equal to the single launch: bit for bit in f32 - same chunk length, same order of summation -, to
+    1e-12 in f64 where the dual kernel's chunks are shorter)."""
+    w, ops = world, world["ops"]
+    dev = w["dev"]
+    import bench
+    pcs = w["pcs"]
+    emb = pcs[:, :2].contiguous()
+    wide, _ = bench.sample_neighbors_device(emb, C // 5, 0.3, dev)
+    assert wide.shape == (C, 3000)
+    order = ops.hilbert_order(emb)
+    pos_mid = 20000
+    cells = torch.cat([order[pos_mid:pos_mid + 16], order[C - 16:]]).long()
+    assert C - 16 >= (C // 8 // 256) * 256 * 8 and C - 16 >= (-(-C // 6) // 256) * 256 * 6       # the last 16 sit in the tiled tail part (8- and 6-cell groups)
+    # the graph and the pooled matrices from the count layers, in both storage types
+    idx, dist = ops.knn_search(pcs, K)
+    cS, cU, fS, fU, _ = bench_counts()
+    conn = (dist > 0).double()
+    wrow = torch.cat([torch.ones((C, 1), device=dev, dtype=torch.float64), conn], 1)
+    wrow = (wrow / wrow.sum(1, keepdim=True)).contiguous()
+    indices = torch.cat([torch.arange(C, device=dev, dtype=torch.int32)[:, None], idx], 1).contiguous()
+    indptr = torch.arange(0, (C + 1) * (K + 1), K + 1, device=dev, dtype=torch.int64)
+    indices, wrow = ops.canonical_graph_rows(indices, wrow)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    got, ref_inputs = {}, None
+    for dtype, name in ((torch.float64, "f64"), (torch.float32, "f32")):
+        Sx, Ux = ops.knn_pool_counts(cS, cU, fS, fU, indptr, indices, wrow.to(dtype), dtype=dtype, validate=False)
+        gam = ops.fit_slope(Ux, Sx)
+        gam[~torch.isfinite(gam)] = 0.0
+        d2 = ops.CellMatrix(torch.randn(Sx.t.shape, generator=gen, device=dev, dtype=torch.float32).to(dtype), G)   # a control with the shape of dmat_rndm
+        d2.t[:, G:] = 0
+        if name == "f64":
+            ref_inputs = (Sx, Ux, gam.double().cpu().numpy(), d2)
+        rule_sets = (("literal", ops.RULES_PARTIAL),) if name == "f64" else (("production", ops.partial_rules_for(Sx, ops.SQRT, 1e-10)), ("literal", ops.RULES_PARTIAL))
+        if name == "f32":
+            assert rule_sets[0][1] == ops.RULES_PARTIAL_NOPSC
+        for rname, rules in rule_sets:
+            single = ops.coldeltacor_partial_fused(Sx, Ux, gam, None, wide, ops.SQRT, rules, 1e-10, order=order, validate=False)
+            real, ctrl = ops.coldeltacor_partial_fused_dual(Sx, Ux, gam, None, d2, wide, ops.SQRT, rules, 1e-10, order=order, validate=False)
+            fin = torch.isfinite(single)
+            assert float(fin.float().mean()) > 0.999 and float(single[fin].abs().max()) <= 1 + 1e-5
+            if name == "f32":                  # same chunk length as the single kernel -> same order of summation
+                assert torch.equal(torch.nan_to_num(real, nan=7.0), torch.nan_to_num(single, nan=7.0)), "dual launch must reproduce the single launch bit for bit"
+            else:                              # f64: the dual kernel walks 768-gene chunks, the single one 1024: summation order differs
+                assert torch.equal(torch.isfinite(real), fin) and float((real[fin] - single[fin]).abs().max()) < 1e-12
+            got[(name, rname)] = (single[cells].double().cpu().numpy(), ctrl[cells].double().cpu().numpy())
+            del single, real, ctrl
+        if name == "f32":
+            del Sx, Ux, d2
+    # ---- the oracle on the rows these cells touch (fp64 pooled matrices downloaded; the batch's cells are columns 0..15)
+    Sx, Ux, g64, d2 = ref_inputs
+    tol = {"f64": 1e-9, "f32": 5e-5}
+    worst = {}
+    for b in range(0, 32, 16):
+        cs = cells[b:b + 16]
+        nb = wide[cs].long().cpu().numpy()
+        cs_np = cs.cpu().numpy()
+        others = np.setdiff1d(np.unique(nb.ravel()), cs_np)
+        rows = np.concatenate([cs_np, others])
+        assert len(rows) < 20000                                # spatially adjacent cells share their 10 000 nearest: the sub-problem stays small
+        col = np.full(C, -1, dtype=np.int64)
+        col[rows] = np.arange(len(rows))
+        e_sub = Sx.t[torch.as_tensor(rows, device=dev), :G].cpu().numpy().T.copy()          # (G, rows), the oracle's layout
+        s, u = e_sub[:, :16], Ux.t[cs, :G].cpu().numpy().T
+        Dv = (s + (u - g64[:, None] * s)) - s
+        ixs = np.zeros((len(rows), nb.shape[1]), dtype=np.int64)
+        ixs[:16] = col[nb]
+        refs = []
+        for dvals in (np.sign(Dv) * np.sqrt(np.abs(Dv) + 1e-10), d2.t[cs, :G].cpu().numpy().T):
+            d_sub = np.zeros_like(e_sub)
+            d_sub[:, :16] = dvals
+            refs.append(oracle.coldeltacor_partial_compact(e_sub, d_sub, ixs, "sqrt", 1e-10, c0=0, c1=16)[:16])
+            del d_sub
+        for key, (real, ctrl) in got.items():
+            for which, g_, ref in (("real", real[b:b + 16], refs[0]), ("control", ctrl[b:b + 16], refs[1])):
+                ok = np.isfinite(ref)
+                assert np.array_equal(np.isnan(g_), ~ok), (key, which)
+                worst[key + (which,)] = max(worst.get(key + (which,), 0.0), float(np.abs(g_[ok] - ref[ok]).max()))
+        del e_sub
+    for key, v in worst.items():
+        assert v <= tol[key[0]], worst

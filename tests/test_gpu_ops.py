@@ -1083,3 +1083,28 @@ def test_partial_nopsc_is_rejected_where_it_is_not_defined(ops):
         ops.coldeltacor_partial(E64, D64, ixs, ops.SQRT, ops.RULES_PARTIAL_NOPSC, 1e-10)
     with pytest.raises(ValueError, match="NOPSC"):
         ops.coldeltacor_partial(E32, D32, ixs, ops.LOG10, ops.RULES_PARTIAL_NOPSC, 1e-10)
+
+
+def test_f64_sqrt_element_accuracy_and_domain(ops, oracle):
+    """The f64 partial-sqrt element seeds its square root from the f32 unit (sqrt_normal_f64: v_rsq_f32 + one Goldschmidt step +
+    one residual correction, <= 2 ulp against a correctly rounded sqrt - not bit-equal to it, stated in DESIGN.md 3).  (1) Over a
+    matrix whose differences sweep 30 decades, correlations stay within the f64 bar (1e-10) of the oracle's correctly rounded arithmetic;
+    (2) the element is defined inside the f32 exponent range only: a matrix reaching 1e38 is refused by the callers' checks
+    (ops.partial_rules_for, validate=True) instead of being evaluated with silent zeros."""
+    rng = np.random.default_rng(3)
+    G, C, nr = 900, 40, 9
+    e = rng.gamma(2.0, 1.0, (G, C)) * 10.0 ** rng.integers(-15, 15, (G, 1))
+    d = rng.normal(size=(G, C))
+    ixs = np.stack([rng.choice(C, nr, replace=False) for _ in range(C)])
+    E, Dm = ops.CellMatrix.from_genes_major(e, "float64"), ops.CellMatrix.from_genes_major(d, "float64")
+    got = ops.coldeltacor_partial(E, Dm, ixs, ops.SQRT, ops.RULES_PARTIAL, 1e-10).cpu().numpy()
+    ref = oracle.coldeltacor_partial_compact(e, d, ixs, "sqrt", 1e-10)
+    _nan_close(got, ref, CORR_ATOL["float64"])
+    assert ops.partial_rules_for(E, ops.SQRT, 1e-10) == ops.RULES_PARTIAL
+    e[5, 7] = 2e38
+    E = ops.CellMatrix.from_genes_major(e, "float64")
+    with pytest.raises(ValueError, match="outside the supported range"):
+        ops.coldeltacor_partial(E, Dm, ixs, ops.SQRT, ops.RULES_PARTIAL, 1e-10)
+    with pytest.raises(ValueError, match="outside the supported range"):
+        ops.partial_rules_for(E, ops.SQRT, 1e-10)
+    ops.coldeltacor_partial(E, Dm, ixs, ops.LINEAR, ops.RULES_PARTIAL, 0.0)                  # other transforms have no such limit

@@ -26,7 +26,7 @@ def test_header_symbols_exported(lib):
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in velocyto_hip.h but not exported"
     assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
-    assert L.vcy_abi_version() == 1
+    assert L.vcy_abi_version() == 2
     # and the maintainer's guide names every one of them (which reference call it replaces, or what a binder needs it for)
     guide = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert not [n for n in sorted(declared) if n not in guide]
@@ -235,6 +235,32 @@ def test_choice_stream_parallel_chains_are_the_sequential_stream(lib, monkeypatc
         cd1, u1 = ctypes.c_int64(0), ctypes.c_int64(0)
         L.vcy_choice_stream_host(big[used.value:].ctypes.data, cut - used.value, p.ctypes.data, n, size, 1, one.ctypes.data, ctypes.byref(cd1), ctypes.byref(u1))
         assert cd1.value == 0
+
+
+def test_choice_stream_host_rewinds_the_rng_when_a_block_fails(lib):
+    """An exception out of on_block (a stage-D launch of estimate_transition_prob failing) must not leave numpy's global RNG
+    advanced by the uniforms prefetched for later blocks: afterwards it stands exactly where the per-cell np.random.choice calls
+    for the cells finished so far would have left it."""
+    from velocyto_amd import ops
+    n, size, cells = 101, 50, 40
+    p = np.linspace(0.5, 0.1, n)
+    p = p / p.sum()
+    for fail_at in (0, 2):
+        seen = []
+
+        def on_block(rows, c0, c1):
+            seen.append((c0, c1))
+            if len(seen) == fail_at + 1:
+                raise RuntimeError("launch failed")
+        np.random.seed(7)
+        with pytest.raises(RuntimeError, match="launch failed"):
+            ops.choice_stream_host(n, size, p, cells, block=7, on_block=on_block)
+        done = seen[-1][1]
+        state = np.random.get_state()
+        np.random.seed(7)
+        for _ in range(done):
+            np.random.choice(n, size=(size,), replace=False, p=p)
+        assert 0 < done < cells and _rng_state_equal(state, np.random.get_state())
 
 
 def test_choice_stream_host_argument_errors(lib):

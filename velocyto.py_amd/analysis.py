@@ -372,20 +372,34 @@ class VelocytoLoom(PreprocessMixin):
         # analysis.py:1159-1162 stores the mask and :1223-1257 fits on tmpS[:, steady_state], tmpU[:, steady_state].  Two things of
         # the reference are fixed here rather than reproduced: `if steady_state_bool:` raises on an array of
         # more than one element (a list works), and the weights W - built from percentiles over ALL cells, :1179-1219 - are not
-        # subset, so the weighted fits fail on broadcasting as soon as the mask drops a cell.  Here any boolean mask of length
-        # `cells` is taken, the thresholds / weights are computed over all cells as in the reference and restricted to the same cells.
+        # subset, so the weighted fits fail on broadcasting as soon as the mask drops a cell.  Here a boolean mask of length
+        # `cells` or an array of cell indices is taken (both work as `tmpS[:, steady_state]` in the reference), the thresholds / weights
+        # are computed over all cells as in the reference and restricted to the same cells.
         ss_rows = None
-        if steady_state_bool is None or (np.ndim(steady_state_bool) == 0 and not steady_state_bool):
+        if steady_state_bool is None or np.ndim(steady_state_bool) == 0:
+            # a scalar: the reference stores it and indexes with it (True adds an axis and the fits fail); taken as "all cells"
             self.steady_state = np.ones(C_all, dtype=bool)
         else:
             ss = np.asarray(steady_state_bool)
-            if ss.dtype != np.bool_ or ss.shape != (C_all,):
-                raise ValueError(f"steady_state_bool must be a boolean mask over the {C_all} cells")
-            self.steady_state = ss
-            if not ss.all():
+            if ss.dtype == np.bool_:
+                if ss.shape != (C_all,):
+                    raise ValueError(f"steady_state_bool must be a boolean mask over the {C_all} cells (or an array of cell indices)")
                 if not ss.any():
                     raise ValueError("steady_state_bool selects no cell")
-                ss_rows = torch.from_numpy(np.flatnonzero(ss)).to(self.dev("S").t.device)
+                rows = None if ss.all() else np.flatnonzero(ss)
+            elif np.issubdtype(ss.dtype, np.integer) and ss.ndim == 1:
+                # tmpS[:, self.steady_state] with an index array (analysis.py:1223-1257): numpy's fancy indexing - any order, repeats
+                # count twice, negative numbers from the end
+                if ss.size == 0:
+                    raise ValueError("steady_state_bool selects no cell")
+                if ss.min() < -C_all or ss.max() >= C_all:
+                    raise IndexError(f"steady_state_bool: cell index out of range for {C_all} cells")
+                rows = np.where(ss < 0, ss + C_all, ss).astype(np.int64)
+            else:
+                raise ValueError(f"steady_state_bool must be a boolean mask over the {C_all} cells or a 1-d array of cell indices")
+            self.steady_state = ss
+            if rows is not None:
+                ss_rows = torch.from_numpy(rows).to(self.dev("S").t.device)
         if use_imputed_data:
             tmpS, tmpU = (self.dev("Sx_sz"), self.dev("Ux_sz")) if use_size_norm else (self.dev("Sx"), self.dev("Ux"))
         else:

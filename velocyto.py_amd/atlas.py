@@ -235,6 +235,8 @@ class AtlasPath:
         if self.rules is None:
             # stage D's branch rule is decided ONCE from whole-matrix reductions, all-reduced: identical on every rank and for
             # every block size (a per-block or per-rank decision could differ on borderline data)
+            if abs_st is None:                      # a rank without a block still takes part in the all-reduce: the neutral element
+                abs_st = torch.tensor([0.0, float("inf"), 0.0], dtype=torch.float64, device=self._ebuf.t.device)
             self.rules = ops.partial_rules_for(self._ebuf, ops.SQRT, self.psc, stats=D.all_reduce_abs_stats(abs_st), cells=self.C)
         ev[0].record()
         D.all_reduce_sum(mom)

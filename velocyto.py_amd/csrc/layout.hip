@@ -96,7 +96,8 @@ static int launch_transpose(const void *src, void *dst, int64_t rows, int64_t co
 using namespace vcy;
 
 extern "C" const char *vcy_last_error(void) { return g_err; }
-extern "C" int vcy_abi_version(void) { return 1; }
+// 2: vcy_diffuse_step_factored gained `prepared` (round 3); vcy_gram added and vcy_knn_pool_csr's 4-element minimum stated (round 4)
+extern "C" int vcy_abi_version(void) { return 2; }
 
 extern "C" int vcy_device_info(int *cu_count, int *lds_bytes_per_block, int64_t *hbm_bytes)
 {

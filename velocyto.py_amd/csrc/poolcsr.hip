@@ -73,7 +73,9 @@ __global__ __launch_bounds__(64 * CSR_WAVES) void k_knn_pool_csr(const int64_t *
     const int sper = (nslab + nsplit - 1) / nsplit, s0 = split * sper, s1 = min(nslab, s0 + sper);
     const int64_t p0 = g_indptr[cl], p1 = g_indptr[cl + 1];
     const int64_t own = cell0 + cl;
-    const int64_t nnz_total = indptr[C_rows];                  // (the 16-byte loads below never read past it)
+    // (the 16-byte loads below never read past it; contract of vcy_knn_pool_csr: `indices` / `data` hold at least 4 elements -
+    //  a layer with fewer non-zeros is padded by the caller, elements at or past indptr[C] belong to no row and are masked)
+    const int64_t nnz_total = max(indptr[C_rows], (int64_t)4);
 
     for (int64_t pb = p0; pb < p1 || pb == p0; pb += 64) {     // batches of 64 graph entries (one batch for any kNN graph)
         const bool first = pb == p0, last = pb + 64 >= p1;

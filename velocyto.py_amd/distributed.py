@@ -328,3 +328,87 @@ def overlap_schedules(base: torch.Tensor, interior: torch.Tensor, cells_per_roun
     taken = torch.zeros(interior.numel(), dtype=torch.bool, device=base.device)
     taken[first] = True
     return first.to(torch.int32).contiguous(), base[~taken[base]].to(torch.int32).contiguous()
+
+
+SELF_CHECKS = ("all_reduce_sum", "all_reduce_min", "all_to_all_uneven", "all_gather_rows_equal", "all_gather_rows_ragged", "all_gather_masks")
+
+
+def self_check(device: torch.device, group=None) -> dict:
+    """Tiny instances of every collective SHAPE the sharded path issues, each checked against the values it must deliver, before
+    any real data moves: the all-reduce of the fit moments (3 x G fp64, SUM) and of the branch-rule facts (MIN), the halo
+    exchange (ONE all_to_all_single with uneven splits, zero-length segments included - the self segment always, some peers
+    too), the all-gather of equal and of ragged row shards (correlation rows, Sx shards) and the uint8 mask all-gather HaloPlan
+    is built from.  Returns {check: "ok" | "<error>"} plus "agreed": the per-check verdict AND-ed over the ranks (a MIN
+    all-reduce), so that every rank takes the same fallback decision (bench.py: a failed uneven all-to-all switches the run to
+    --exchange allgather).  Raises only when the plain all-reduce itself does not work - then no
+    sharded run is possible and the message says which call failed."""
+    rank, ws = world()
+    res = {}
+    if not active():
+        return {"agreed": {}, "skipped": "one rank, collectives not forced"}
+
+    inject = os.environ.get("VCY_SELF_CHECK_FAIL", "")       # tests: "name" or "name@rank" makes that check fail (on that rank only)
+
+    def attempt(name, fn):
+        try:
+            fn()
+            if inject and inject.split("@")[0] == name and (("@" not in inject) or int(inject.split("@")[1]) == rank):
+                raise RuntimeError("failure injected by VCY_SELF_CHECK_FAIL")
+            if device.type == "cuda":
+                torch.cuda.synchronize(device)
+            res[name] = "ok"
+        except Exception as e:                                                  # noqa: BLE001 (the report IS the point)
+            res[name] = f"{type(e).__name__}: {e}"[:240]
+
+    def ar_sum():
+        t = torch.full((3, 64), float(rank + 1), dtype=torch.float64, device=device)
+        all_reduce_sum(t, group)
+        assert float(t[2, 63]) == ws * (ws + 1) / 2, f"sum over ranks = {float(t[2, 63])}"
+
+    def ar_min():
+        st = torch.tensor([1.0, 10.0 + rank, 2.0], dtype=torch.float64, device=device)
+        all_reduce_abs_stats(st, group)
+        assert st.tolist() == [float(ws), 10.0, 2.0 * ws], st.tolist()
+
+    def a2a():
+        # rank r sends (r + 2 p) % 3 rows to peer p: lengths 0, 1 and 2 all occur from 3 ranks up, the self segment is always empty
+        n_to = lambda src, dst: 0 if src == dst else (src + 2 * dst) % 3
+        send_splits = [n_to(rank, p) for p in range(ws)]
+        recv_splits = [n_to(p, rank) for p in range(ws)]
+        send = torch.cat([torch.full((n, 4), 1000.0 * rank + p, dtype=torch.float32, device=device) for p, n in enumerate(send_splits)] +
+                         [torch.empty((0, 4), dtype=torch.float32, device=device)])
+        recv = all_to_all_uneven(send, send_splits, recv_splits, group)
+        want = torch.cat([torch.full((n, 4), 1000.0 * p + rank, dtype=torch.float32, device=device) for p, n in enumerate(recv_splits)] +
+                         [torch.empty((0, 4), dtype=torch.float32, device=device)])
+        assert recv.shape == want.shape and torch.equal(recv, want), "rows arrived in the wrong place"
+
+    def gather(n_total):
+        def run():
+            a, b = shard_bounds(n_total, ws, rank)
+            local = torch.arange(a, b, dtype=torch.float32, device=device)[:, None].repeat(1, 3).contiguous()
+            out = all_gather_rows(local, n_total, group=group)
+            assert torch.equal(out[:, 1], torch.arange(n_total, dtype=torch.float32, device=device)), "rows out of order"
+        return run
+
+    def masks():
+        need = torch.zeros(4 * ws, dtype=torch.bool, device=device)
+        need[rank::ws] = True
+        HaloPlan(need, 4 * ws, group)
+
+    attempt("all_reduce_sum", ar_sum)
+    if res["all_reduce_sum"] != "ok":
+        raise RuntimeError(f"rank {rank}: the basic all-reduce of the '{dist.get_backend(group)}' backend failed, no sharded run is possible: {res['all_reduce_sum']}")
+    attempt("all_reduce_min", ar_min)
+    attempt("all_to_all_uneven", a2a)
+    attempt("all_gather_rows_equal", gather(2 * ws))
+    attempt("all_gather_rows_ragged", gather(2 * ws + 1) if ws > 1 else gather(2))
+    attempt("all_gather_masks", masks)
+    flags = torch.tensor([1.0 if res[n] == "ok" else 0.0 for n in SELF_CHECKS], dtype=torch.float64, device=device)
+    if _host_staged(flags, group):
+        h = flags.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MIN, group=group)
+        flags = h
+    else:
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN, group=group)
+    res["agreed"] = {n: bool(v > 0.5) for n, v in zip(SELF_CHECKS, flags.tolist())}
+    return res

@@ -231,16 +231,24 @@ class CsrCounts:
     analysis.py:59-61, 240 GB).  ``slabptr`` is the per-row table of gene-slab boundaries the pooling kernel walks
     (vcy_csr_slab_ptr), built on first use."""
 
-    __slots__ = ("indptr", "indices", "data", "G", "_slabptr")
+    __slots__ = ("indptr", "indices", "data", "G", "_slabptr", "_nnz", "_istore", "_dstore")
 
     def __init__(self, indptr: torch.Tensor, indices: torch.Tensor, data: torch.Tensor, G: int):
         assert indptr.dtype == torch.int64 and indices.dtype == torch.int32 and data.dtype in (torch.uint8, torch.int16)
         assert indptr.is_cuda and indices.is_cuda and data.is_cuda and indices.numel() == data.numel()
-        self.indptr, self.indices, self.data, self.G = indptr.contiguous(), indices.contiguous(), data.contiguous(), int(G)
+        self._nnz = int(indices.numel())
+        indices, data = indices.contiguous(), data.contiguous()
+        self._istore, self._dstore = indices, data                # what the kernels are handed
+        if indices.numel() < 4:                                   # vcy_knn_pool_csr reads quads of consecutive non-zeros: at least 4 stored
+            pad = 4 - indices.numel()                             # elements (velocyto_hip.h); those past indptr[C] belong to no row
+            self._istore = torch.cat([indices, torch.zeros(pad, dtype=indices.dtype, device=indices.device)])
+            self._dstore = torch.cat([data, torch.zeros(pad, dtype=data.dtype, device=data.device)])
+            indices, data = self._istore[: self._nnz], self._dstore[: self._nnz]
+        self.indptr, self.indices, self.data, self.G = indptr.contiguous(), indices, data, int(G)
         self._slabptr = None
 
     C = property(lambda self: int(self.indptr.numel()) - 1)
-    nnz = property(lambda self: int(self.indices.numel()))
+    nnz = property(lambda self: self._nnz)
     code = property(lambda self: U8 if self.data.dtype == torch.uint8 else U16)
     nbytes = property(lambda self: self.indptr.numel() * 8 + self.indices.numel() * 4 + self.data.numel() * self.data.element_size())
 
@@ -251,7 +259,7 @@ class CsrCounts:
             nslab = (self.G + int(L.vcy_csr_slab_genes()) - 1) // int(L.vcy_csr_slab_genes())
             sp = torch.empty((max(self.C, 1), nslab + 1), dtype=torch.int32, device=self.indptr.device)
             if self.C:
-                _lib.check(L.vcy_csr_slab_ptr(self.indptr.data_ptr(), self.indices.data_ptr(), sp.data_ptr(), self.C, self.G, _stream()), "csr_slab_ptr")
+                _lib.check(L.vcy_csr_slab_ptr(self.indptr.data_ptr(), self._istore.data_ptr(), sp.data_ptr(), self.C, self.G, _stream()), "csr_slab_ptr")
             self._slabptr = sp
         return self._slabptr
 
@@ -345,7 +353,7 @@ def knn_pool_csr(counts: CsrCounts, scale, indptr, indices, weights, dtype=None,
     if order is not None:
         order = order.to(device=dev, dtype=torch.int32).contiguous()
         assert order.numel() == C_out
-    _lib.check(_lib.lib().vcy_knn_pool_csr(counts.indptr.data_ptr(), counts.indices.data_ptr(), counts.data.data_ptr(), counts.slabptr.data_ptr(),
+    _lib.check(_lib.lib().vcy_knn_pool_csr(counts.indptr.data_ptr(), counts._istore.data_ptr(), counts._dstore.data_ptr(), counts.slabptr.data_ptr(),
                                            sc.data_ptr(), out.t.data_ptr(), ip.data_ptr(), ix.data_ptr(), w.data_ptr(), _p(order), counts.C, counts.G,
                                            out.ld, cell0, C_out, int(maximum), counts.code, out.code, _stream()), "knn_pool_csr")
     return out
@@ -398,6 +406,20 @@ def abs_stats(e: CellMatrix) -> torch.Tensor:
     return out
 
 
+F64_SQRT_MAX = 1e38
+
+
+def check_f64_sqrt_domain(e: CellMatrix) -> None:
+    """The f64 partial-sqrt element (csrc/coldeltacor.hip, sqrt_normal_f64) seeds its square root from the f32 unit: faithfully
+    rounded (<= 2 ulp against a correctly rounded sqrt) for arguments inside the f32 exponent range, silently 0 above 3.4e38.  A
+    count-derived matrix never comes near it; a matrix that does is refused here (one reduction, one device->host sync - the
+    callers that decide the branch rule once per matrix come through here, ops.partial_rules_for)."""
+    lo, hi = e.t.aminmax()
+    m = max(abs(float(lo)), abs(float(hi)))
+    if m >= F64_SQRT_MAX:
+        raise ValueError(f"colDeltaCor sqrt transform in f64: |e| reaches {m:.3g}, outside the supported range (< {F64_SQRT_MAX:g})")
+
+
 def literal_rule_forced() -> bool:
     """VELOCYTO_AMD_LITERAL_RULE=1: never pick the no-pseudocount form (the facade's `literal_rule` attribute does the same per object)."""
     import os
@@ -426,6 +448,8 @@ def partial_rules_for(e: CellMatrix, transform: int, psc: float, stats: Optional
     i.e. <= psc * sqrt(mean_g 1/|t_g|) / sd(A) over the genes with 0 < |t_g| < 2^24 psc: a few 1e-7 on count-scale data
     (measured 1.5e-7 over all 12.5 M pairs of the bench workload), and below the f32 tolerance of 1e-5 down to matrix scales of
     1e-4 (tests/test_gpu_ops.py::test_partial_nopsc_rule_bound_on_scaled_matrices)."""
+    if transform == SQRT and e.dtype == torch.float64 and e.C:
+        check_f64_sqrt_domain(e)
     if transform != SQRT or e.dtype != torch.float32 or not (0.0 <= float(psc) <= PSC_NEGLIGIBLE) or e.C == 0 or literal or literal_rule_forced():
         return RULES_PARTIAL
     st = abs_stats(e) if stats is None else stats
@@ -446,6 +470,8 @@ def coldeltacor_partial(e: CellMatrix, d: CellMatrix, ixs, transform: int, rules
     assert d_row0 <= cell0 and cell0 + C_out <= d_row0 + d.C
     if validate and ix.numel() and (int(ix.min()) < 0 or int(ix.max()) >= e.C):
         raise ValueError("neighbour index out of range")
+    if validate and transform == SQRT and e.dtype == torch.float64 and e.C:
+        check_f64_sqrt_domain(e)
     if out is None:
         out = torch.empty((C_out, nrndm), dtype=e.dtype, device=e.t.device)
     n_sched = C_out
@@ -516,6 +542,8 @@ def coldeltacor_partial_dual(e: CellMatrix, d: CellMatrix, d_rndm: CellMatrix, i
     assert d_row0 <= cell0 and cell0 + C_out <= d_row0 + d.C
     if validate and ix.numel() and (int(ix.min()) < 0 or int(ix.max()) >= e.C):
         raise ValueError("neighbour index out of range")
+    if validate and transform == SQRT and e.dtype == torch.float64 and e.C:
+        check_f64_sqrt_domain(e)
     out = torch.empty((C_out, nrndm), dtype=e.dtype, device=e.t.device) if out is None else out
     out_rndm = torch.empty((C_out, nrndm), dtype=e.dtype, device=e.t.device) if out_rndm is None else out_rndm
     order, n_sched = _sched(order, e.t.device, C_out)
@@ -1079,35 +1107,50 @@ def choice_stream_host(n: int, size: int, p: np.ndarray, cells: int, block: int 
     def want(todo, have):
         return max(int(todo * per_cell) + size - have, size)
 
+    def hand_back(left):                                     # leave the RNG where the per-cell calls would have left it: `left` = uniforms
+        while left > 0:                                      # drawn but not consumed, counted from the end of the stream
+            state, drawn = draws.pop()
+            np.random.set_state(state)
+            if drawn >= left:
+                if drawn > left:
+                    np.random.random_sample(drawn - left)
+                left = 0
+            else:
+                left -= drawn
+
     with ThreadPoolExecutor(1) as ex:
         fut = ex.submit(draw, want(block_cells(cells), 0)) if cells > 0 and size > 0 else None
-        while fut is not None:
-            state, fresh = fut.result()
-            draws.append((state, fresh.size))
-            pool = np.concatenate([pending, fresh]) if pending.size else fresh
-            todo = block_cells(cells - done_total) if len(draws) > 1 else min(256, int(block), cells)
-            # the uniforms of the block after this one are drawn while this one is replayed
-            after = cells - done_total - todo
-            fut = ex.submit(draw, want(min(int(block), after), max(0, pool.size - int(todo * per_cell)))) if after > 0 else None
-            _lib.check(_lib.lib().vcy_choice_stream_host(pool.ctypes.data, pool.size, p.ctypes.data, n, size, todo, out[done_total:].ctypes.data,
-                                                         ctypes.byref(cd), ctypes.byref(used)), "choice_stream")
-            pending = pool[used.value:]
-            if on_block is not None and cd.value:
-                on_block(out, done_total, done_total + cd.value)
-            done_total += cd.value
-            per_cell = (used.value / cd.value * 1.02 + 0.5) if cd.value else per_cell * 2       # measured; nothing fitted: draw more
-            if fut is None and done_total < cells:           # the pool fell short on what was planned as the last block
-                fut = ex.submit(draw, want(cells - done_total, pending.size))
-    left = pending.size                                      # leave the RNG where the per-cell calls would have left it
-    while left > 0:
-        state, drawn = draws.pop()
-        np.random.set_state(state)
-        if drawn >= left:
-            if drawn > left:
-                np.random.random_sample(drawn - left)
-            left = 0
-        else:
-            left -= drawn
+        try:
+            while fut is not None:
+                state, fresh = fut.result()
+                fut = None
+                draws.append((state, fresh.size))
+                pool = np.concatenate([pending, fresh]) if pending.size else fresh
+                pending = pool                               # (until the replay has said how many it used)
+                todo = block_cells(cells - done_total) if len(draws) > 1 else min(256, int(block), cells)
+                # the uniforms of the block after this one are drawn while this one is replayed
+                after = cells - done_total - todo
+                fut = ex.submit(draw, want(min(int(block), after), max(0, pool.size - int(todo * per_cell)))) if after > 0 else None
+                _lib.check(_lib.lib().vcy_choice_stream_host(pool.ctypes.data, pool.size, p.ctypes.data, n, size, todo, out[done_total:].ctypes.data,
+                                                             ctypes.byref(cd), ctypes.byref(used)), "choice_stream")
+                pending = pool[used.value:]
+                if on_block is not None and cd.value:
+                    on_block(out, done_total, done_total + cd.value)
+                done_total += cd.value
+                per_cell = (used.value / cd.value * 1.02 + 0.5) if cd.value else per_cell * 2       # measured; nothing fitted: draw more
+                if fut is None and done_total < cells:           # the pool fell short on what was planned as the last block
+                    fut = ex.submit(draw, want(cells - done_total, pending.size))
+        except BaseException:
+            # a failure in the replay or in the caller's on_block (a stage-D launch): the prefetched draw must not stay consumed -
+            # rewind the global RNG to just after the last uniform a finished cell took, then let the error through
+            extra = 0
+            if fut is not None:
+                state, fresh = fut.result()
+                draws.append((state, fresh.size))
+                extra = fresh.size
+            hand_back(pending.size + extra)
+            raise
+    hand_back(pending.size)
     return out
 
 
