@@ -437,6 +437,25 @@ int vcy_diffuse_step_dense(const void *tr, const double *x, double *y, double *a
 int vcy_diffuse_step_csc(const int64_t *colptr, const int32_t *rowidx, const void *val, const double *x, double *y,
                          double *accum, int64_t n, int dtype, vcy_stream stream);
 
+/* ---------------------------------------------------------------- upstream caller: perform_PCA's dense contraction (f64 MFMA)
+ * VelocytoLoom.perform_PCA (analysis.py:678-702) fits sklearn.decomposition.PCA on S_norm[pca_genes].T: centre every gene, then
+ * the spectral decomposition of the centred (cells x genes) matrix.  The device path takes the covariance route; its one dense
+ * product is
+ *     vcy_gram:     gram[i][j] = sum_c (X[c][i] - mean[i]) (X[c][j] - mean[j])       G x G fp64, row pitch ldg, both triangles
+ *     vcy_gram_tn:  out[i][j]  = sum_c (X[c][i] - mean[i]) Y[c][j]                   G x L fp64 (the block product X_c^T (X_c Z)
+ *                                                                                    of the subspace iteration; Y (C, ldy) fp64)
+ * X: (C, ld) cells-major of `dtype` (16-byte aligned rows); mean: (G) fp64 device or NULL (no centring); the contraction runs on
+ * v_mfma_f64_16x16x4_f64 with fp64 accumulation in a fixed order (results are reproducible run to run).  workspace:
+ * vcy_gram_workspace_bytes(C, G, L, symmetric) bytes (symmetric = 1 for vcy_gram, where L is ignored) - partial tiles when the
+ * cells are split over several workgroups per output tile; vcy_col_means uses the same workspace.
+ * vcy_col_means: mean[g] = sum_c X[c][g] / C in fp64, fixed summation order (sklearn's X.mean(axis=0)).                          */
+size_t vcy_gram_workspace_bytes(int64_t C, int64_t G, int64_t L, int symmetric);
+int vcy_col_means(const void *X, double *mean, void *workspace, int64_t C, int64_t G, int64_t ld, int dtype, vcy_stream stream);
+int vcy_gram(const void *X, const double *mean, double *gram, void *workspace, int64_t C, int64_t G, int64_t ld, int64_t ldg, int dtype,
+             vcy_stream stream);
+int vcy_gram_tn(const void *X, const double *mean, const double *Y, double *out, void *workspace, int64_t C, int64_t G, int64_t L, int64_t ld,
+                int64_t ldy, int64_t ldo, int dtype, vcy_stream stream);
+
 /* ---------------------------------------------------------------- upstream callers: epsilon-SVR, RBF kernel, scalar inputs
  * The noise models of score_cv_vs_mean (analysis.py:280-282, 324-326: sklearn.svm.SVR(gamma=150/G).fit(log2 mean, log2 CV), one point
  * per gene) and adjust_totS_totU (analysis.py:844-851: SVR(C=100, kernel="rbf", gamma=1e-6) on per-cell totals).  scikit-learn

@@ -185,8 +185,9 @@ def test_pca_on_device(vcy, golden, dtype):
     f32 = dtype == "float32"
     k = 40
     assert va.pcs.shape == g["pcs"].shape and va.pca.components_.shape == g["pca_components"].shape
-    close(va.pca.explained_variance_ratio_, g["explained_variance_ratio"], 2e-5 if f32 else 1e-8, 1e-9 if f32 else 1e-13)
-    close(va.pca.explained_variance_, g["pca_explained_variance"], 2e-5 if f32 else 1e-8, 1e-9 if f32 else 1e-13)
+    # (the covariance product is csrc/gram.hip on the f64 matrix cores: explained variances to 1e-9 of scikit-learn's in f64 storage)
+    close(va.pca.explained_variance_ratio_, g["explained_variance_ratio"], 2e-5 if f32 else 1e-9, 1e-9 if f32 else 1e-13)
+    close(va.pca.explained_variance_, g["pca_explained_variance"], 2e-5 if f32 else 1e-9, 1e-9 if f32 else 1e-13)
     close(va.pca.mean_, g["pca_mean"], 1e-6 if f32 else 1e-12, 1e-6 if f32 else 1e-12)
     close(va.pcs[:, :k], g["pcs"][:, :k], 0, 2e-3 if f32 else 1e-7)
     close(va.pca.components_[:k], g["pca_components"][:k], 0, 2e-4 if f32 else 1e-7)
@@ -254,3 +255,52 @@ def test_pca_subspace_iteration_matches_the_exact_route():
     np.testing.assert_allclose(auto.components_, exact.components_, atol=1e-6)                                  # same signs (svd_flip)
     np.testing.assert_allclose(p_auto, p_exact, atol=1e-5 * np.abs(p_exact).max())
     np.testing.assert_allclose(auto.mean_, exact.mean_, rtol=1e-13)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("C,G", [(37, 5), (300, 130), (1000, 257), (5000, 700), (4200, 1153)])
+def test_gram_kernel_against_the_library_gemm(dtype, C, G):
+    """vcy_gram (csrc/gram.hip, v_mfma_f64_16x16x4_f64): the centred covariance product of perform_PCA (analysis.py:678-702)
+    against torch's fp64 GEMM of the explicitly centred matrix - "bit-near": both accumulate in fp64, in different orders.
+    Shapes cover one partial tile, ragged tile edges, odd gene counts (scalar tail of a column pair), cell counts that are not
+    a multiple of the slab, and the split of the cells over several workgroups per tile (partials reduced in a fixed order)."""
+    import velocyto_amd
+    from velocyto_amd import ops
+    dev = ops.require_gpu()
+    gen = torch.Generator(device=dev).manual_seed(C + G)
+    X = torch.randn((C, G), generator=gen, device=dev, dtype=torch.float64) * torch.linspace(0.5, 3.0, G, device=dev, dtype=torch.float64) + \
+        torch.linspace(-2.0, 40.0, G, device=dev, dtype=torch.float64)                   # means far from zero: centring matters
+    M = ops.CellMatrix.from_cells_major(X, getattr(torch, dtype))
+    Xs = M.t[:, :G].double()                                                             # what the kernel reads (f32 storage rounds)
+    mean = ops.col_means(M)
+    assert float((mean - Xs.mean(0)).abs().max()) <= 1e-12 * 40
+    A = Xs - mean
+    ref = A.T @ A
+    got = ops.gram(M, mean)
+    scale = float(ref.diagonal().max())
+    assert got.shape == (G, G) and float((got - ref).abs().max()) <= 1e-12 * scale
+    assert torch.equal(got, got.T), "both triangles must hold the same bits"
+    assert torch.equal(got, ops.gram(M, mean)), "fixed summation order: run-to-run identical"
+    raw = ops.gram(M, None)                                                              # no centring: X^T X
+    assert float((raw - Xs.T @ Xs).abs().max()) <= 1e-12 * float((Xs * Xs).sum(0).max())
+    # the thin block product of the subspace iteration, with an ASYMMETRIC right-hand side (a row <-> column slip cannot hide)
+    for L in (1, 7, 50, 64, 130):
+        Y = torch.randn((C, L), generator=gen, device=dev, dtype=torch.float64) * torch.arange(1, L + 1, device=dev, dtype=torch.float64)
+        w = ops.gram_tn(M, mean, Y)
+        wref = A.T @ Y
+        assert w.shape == (G, L) and float((w - wref).abs().max()) <= 1e-12 * float(wref.abs().max()) + 1e-9
+
+
+def test_gram_kernel_identity_probe():
+    """Lane maps of the f64 MFMA pinned with an identity probe: X = [I; 0] (cells x genes) against an asymmetric Y gives
+    X^T Y = Y's first rows exactly - any slip in the A / B / D lane layout (the f64 D map differs from the f32 one) moves entries."""
+    import velocyto_amd
+    from velocyto_amd import ops
+    dev = ops.require_gpu()
+    G, C, L = 200, 333, 96
+    X = torch.zeros((C, G), dtype=torch.float64, device=dev)
+    X[:G] = torch.eye(G, dtype=torch.float64, device=dev)
+    Y = (torch.arange(C, device=dev, dtype=torch.float64)[:, None] * 1000.0 + torch.arange(L, device=dev, dtype=torch.float64)[None, :]).contiguous()
+    M = ops.CellMatrix.from_cells_major(X, torch.float64)
+    assert torch.equal(ops.gram_tn(M, None, Y), Y[:G])
+    assert torch.equal(ops.gram(M, None), torch.eye(G, dtype=torch.float64, device=dev))

@@ -71,6 +71,10 @@ SIGNATURES = {
     "vcy_diffuse_step_factored_culled": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_dbl, c_dbl, c_vp,
                                                  c_i64, c_int, c_int, c_vp]),
     "vcy_diffuse_step_factored": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_dbl, c_vp, c_i64, c_int, c_int, c_vp]),
+    "vcy_gram_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_int]),
+    "vcy_col_means": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]),
+    "vcy_gram": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp]),
+    "vcy_gram_tn": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_vp]),
     "vcy_svr_workspace_bytes": (c_i64, [c_i64]),
     "vcy_svr_rbf_fit": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_dbl, c_dbl, c_dbl, c_dbl, c_i64, c_vp]),
     "vcy_svr_rbf_predict": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_dbl, c_vp]),

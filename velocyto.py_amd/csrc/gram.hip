@@ -1,0 +1,333 @@
+// gram.hip -- the dense contraction next to the path: perform_PCA's covariance product.
+//
+// Reference: VelocytoLoom.perform_PCA (velocyto/analysis.py:678-702) hands S_norm[pca_genes].T (cells x genes) to
+// sklearn.decomposition.PCA, whose arithmetic is: centre every gene, then the spectral decomposition of the centred matrix.
+// On the device the matrix is cells-major, X (C, ld); the covariance route needs
+//     gram[i][j] = sum_c (X[c][i] - mean[i]) (X[c][j] - mean[j])          (G x G, fp64)
+// and the subspace iteration for few components of many genes needs the same contraction against a thin block,
+//     out[i][j]  = sum_c (X[c][i] - mean[i]) Y[c][j]                      (G x L, Y fp64 (C, L)).
+// Both contract over CELLS, the slow dimension of both operands ("TN" product): a slab of KS cells x 128 genes is one
+// contiguous 1 KiB run per cell, staged once into LDS with the mean subtracted on the way (centring costs one VALU subtract per
+// loaded element and no extra pass), and every staged f64 feeds 8 matrix instructions.
+//
+// Matrix core use.  v_mfma_f64_16x16x4_f64: D(16x16) += A(16x4) B(4x16), one f64 of A and of B per lane
+// (A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15]), four f64 of D per lane
+// (col = lane & 15, row = (lane >> 4) + 4 reg - NOT the f32 map).  Both operands of the TN product are read from LDS tiles laid
+// out [cell][gene], so A- and B-fragments are the same access: 16 consecutive doubles of cell k0 + (lane >> 4).
+// A workgroup of 4 waves owns a 128 x 128 tile of the output; wave (wm, wn) owns 64 x 64 of it = 4 x 4 MFMA tiles = 64 f64
+// accumulators per lane (128 VGPRs); per step of 4 cells it reads 4 + 4 fragments and issues 16 MFMAs (8 LDS bytes per 2048
+// flop).  Peak: 2048 flop per instruction at one instruction per 64 clocks per SIMD = 78.6 Tflop/s on 1024 SIMDs at 2.4 GHz - the
+// same rate as the f64 vector unit, but without its operand traffic.
+// Symmetry: the Gram matrix is computed on the tiles of its upper triangle only (diagonal tiles whole) and mirrored on write.
+// Few output tiles (3000 genes: 300) would leave the 256 CUs x 2 resident workgroups unevenly loaded: the cells are then split
+// over `ksplit` workgroups per tile, each writing its partial tile to a workspace; k_gram_reduce adds the partials in a fixed
+// order (deterministic - no atomics) and mirrors.
+#include "common.h"
+
+namespace vcy {
+
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+
+constexpr int GM_T = 128;          // edge of a workgroup's output tile
+constexpr int GM_KS = 16;          // cells per staged slab
+constexpr int GM_LD = GM_T + 16;   // LDS row pitch in doubles: consecutive cells start 32 banks apart
+constexpr int GM_THREADS = 256;
+
+// two consecutive elements from an address that is always inside the matrix (callers clamp row and column and mask the values
+// afterwards: no branch around a load, so the compiler never closes a load with its own s_waitcnt)
+template <typename T> __device__ __forceinline__ void load2(const T *p, double &a, double &b)
+{
+    if constexpr (sizeof(T) == 8) { const double2 v = *reinterpret_cast<const double2 *>(p); a = v.x; b = v.y; }
+    else { const float2 v = *reinterpret_cast<const float2 *>(p); a = (double)v.x; b = (double)v.y; }
+}
+
+// out (Ga x Gb) = (A - ma)^T (B - mb); A (C, lda) of TA, B (C, ldb) of TB.  SYM: B is A (Gb == Ga), only tile pairs it <= jt.
+// TN: columns of the output tile (128: waves 2 x 2, each 64 x 64; 64: waves 4 x 1, each 32 x 64 - the thin blocks of the
+// subspace iteration, where a 128-wide tile would multiply mostly padding).
+template <typename TA, typename TB, bool SYM, int TN>
+__global__ __launch_bounds__(GM_THREADS, 2) void k_gram(const TA *__restrict__ A, const TB *__restrict__ B, const double *__restrict__ ma,
+                                                         const double *__restrict__ mb, double *__restrict__ out, int C, int Ga, int Gb,
+                                                         int64_t lda, int64_t ldb, int64_t ldo, int nta, int ntb, int ksplit, int cells_per_split,
+                                                         int64_t part_stride)
+{
+    static_assert(TN == 128 || TN == 64, "tile widths");
+    constexpr int XT = TN == 128 ? 4 : 2, YT = 4;                     // 16 x 16 MFMA tiles per wave along i and j
+    constexpr int LDB = TN + 16;                                      // LDS pitch of the B slab
+    constexpr int PB = TN / 2, RB = GM_THREADS / PB, UB = GM_KS / RB; // B staging: column pairs per row, rows per pass, passes
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *As = reinterpret_cast<double *>(smem);                    // [2][KS][GM_LD]
+    double *Bs = As + 2 * GM_KS * GM_LD;                              // [2][KS][LDB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntile = SYM ? nta * (nta + 1) / 2 : nta * ntb;
+    // XCD-aware: workgroup b runs on XCD b % 8 (observed; speed only) -> an XCD owns a contiguous range of (split, tile): tiles
+    // next to each other share a row panel of A in one L2
+    const int total = ntile * ksplit, per = (total + 7) / 8;
+    const int q = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (q >= total) return;
+    const int s = q / ntile, p = q - s * ntile;
+    int it, jt;
+    if (SYM) {
+        it = 0;
+        int rem = p;
+        while (rem >= nta - it) { rem -= nta - it; ++it; }
+        jt = it + rem;
+    } else {
+        it = p / ntb;
+        jt = p - it * ntb;
+    }
+    const int i0 = it * GM_T, j0 = jt * TN;
+    const int c_begin = s * cells_per_split, c_end = min(C, c_begin + cells_per_split);
+    // staging roles.  A slab: column pair cp of the tile (genes 2 cp, 2 cp + 1), rows r0 + 4 u; B slab: pair cpb, rows r0b + RB u
+    const int cp = tid & 63, r0 = tid >> 6, cpb = tid % PB, r0b = tid / PB;
+    const int ga = i0 + 2 * cp, gb = j0 + 2 * cpb;
+    const bool a_ok0 = ga < Ga, a_ok1 = ga + 1 < Ga, b_ok0 = gb < Gb, b_ok1 = gb + 1 < Gb;
+    const double ma0 = (ma && a_ok0) ? ma[ga] : 0.0, ma1 = (ma && a_ok1) ? ma[ga + 1] : 0.0;
+    const double mb0 = (mb && b_ok0) ? mb[gb] : 0.0, mb1 = (mb && b_ok1) ? mb[gb + 1] : 0.0;
+    // rows are padded to an even pitch >= the column count: a pair starting at an even column below the pitch lies inside its row
+    const int ca = ga < lda ? ga : 0, cb = gb < ldb ? gb : 0;
+    // fetch() only ISSUES the loads of a slab (raw values into registers); the centring, the masking and the LDS writes wait in
+    // stash(), after the slab in hand has been multiplied - a subtract right behind its load would put the wait for the load in
+    // front of the matrix instructions it is meant to hide behind
+    double ra[4][2], rb[UB][2];
+
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + r0 + 4 * u;
+            load2<TA>(A + (int64_t)min(c, c_end - 1) * lda + ca, ra[u][0], ra[u][1]);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {                                // (a diagonal tile of the Gram matrix stages the same slab twice:
+            const int c = c0 + r0b + RB * u;                          //  one tile in nta, and no branch around a load)
+            load2<TB>(B + (int64_t)min(c, c_end - 1) * ldb + cb, rb[u][0], rb[u][1]);
+        }
+    };
+    auto stash = [&](int buf, int c0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + 4 * u;
+            const bool in = c0 + r < c_end;
+            const double a0 = (in && a_ok0) ? ra[u][0] - ma0 : 0.0, a1 = (in && a_ok1) ? ra[u][1] - ma1 : 0.0;
+            *reinterpret_cast<double2 *>(As + (buf * GM_KS + r) * GM_LD + 2 * cp) = double2{a0, a1};
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int r = r0b + RB * u;
+            const bool in = c0 + r < c_end;
+            const double b0 = (in && b_ok0) ? rb[u][0] - mb0 : 0.0, b1 = (in && b_ok1) ? rb[u][1] - mb1 : 0.0;
+            *reinterpret_cast<double2 *>(Bs + (buf * GM_KS + r) * LDB + 2 * cpb) = double2{b0, b1};
+        }
+    };
+
+    const int wm = TN == 128 ? wave >> 1 : wave, wn = TN == 128 ? wave & 1 : 0;
+    const int wi = wm * XT * 16, wj = wn * YT * 16;                   // the wave's corner inside the tile
+    v4d_t acc[XT][YT];
+#pragma unroll
+    for (int x = 0; x < XT; ++x)
+#pragma unroll
+        for (int y = 0; y < YT; ++y) acc[x][y] = v4d_t{0.0, 0.0, 0.0, 0.0};
+    const int lrow = lane >> 4, lcol = lane & 15;
+
+    int buf = 0;
+    if (c_begin < c_end) {
+        fetch(c_begin);
+        stash(0, c_begin);
+    }
+    __syncthreads();
+    for (int c0 = c_begin; c0 < c_end; c0 += GM_KS) {
+        const bool more = c0 + GM_KS < c_end;
+        if (more) fetch(c0 + GM_KS);                                  // next slab in flight while this one is multiplied
+        __builtin_amdgcn_sched_barrier(0);
+        const double *as = As + buf * GM_KS * GM_LD, *bs = Bs + buf * GM_KS * LDB;
+#pragma unroll
+        for (int kk = 0; kk < GM_KS / 4; ++kk) {
+            double a[XT], b[YT];
+#pragma unroll
+            for (int x = 0; x < XT; ++x) a[x] = as[(kk * 4 + lrow) * GM_LD + wi + x * 16 + lcol];
+#pragma unroll
+            for (int y = 0; y < YT; ++y) b[y] = bs[(kk * 4 + lrow) * LDB + wj + y * 16 + lcol];
+#pragma unroll
+            for (int x = 0; x < XT; ++x)
+#pragma unroll
+                for (int y = 0; y < YT; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) stash(buf ^ 1, c0 + GM_KS);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // ---- write: D[row = (lane >> 4) + 4 reg][col = lane & 15] of every 16 x 16 tile
+    // (split runs: `out` is the workspace, partial s a compact Ga x Gb matrix of its own - ldo is Gb then)
+    double *dst = out + (ksplit > 1 ? (int64_t)s * part_stride : 0);
+    const bool mirror = SYM && ksplit == 1 && it != jt;
+#pragma unroll
+    for (int x = 0; x < XT; ++x)
+#pragma unroll
+        for (int y = 0; y < YT; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + wi + x * 16 + lrow + 4 * r, j = j0 + wj + y * 16 + lcol;
+                if (i < Ga && j < Gb) {
+                    dst[(int64_t)i * ldo + j] = acc[x][y][r];
+                    if (mirror) dst[(int64_t)j * ldo + i] = acc[x][y][r];
+                }
+            }
+}
+
+// out[i][j] = sum over the splits, in split order; SYM: the lower triangle's tiles are read from their mirror images
+template <bool SYM>
+__global__ __launch_bounds__(256) void k_gram_reduce(const double *__restrict__ part, double *__restrict__ out, int Ga, int Gb, int64_t ldo, int ksplit,
+                                                      int64_t part_stride)
+{
+    const int64_t n = (int64_t)Ga * Gb;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(t / Gb), j = (int)(t - (int64_t)i * Gb);
+        const bool flip = SYM && (i / GM_T) > (j / GM_T);
+        const int64_t src = flip ? (int64_t)j * Gb + i : (int64_t)i * Gb + j;            // partials are compact (row pitch Gb)
+        double v = 0.0;
+        for (int s = 0; s < ksplit; ++s) v += part[(int64_t)s * part_stride + src];
+        out[(int64_t)i * ldo + j] = v;
+    }
+}
+
+// column means of a cells-major matrix, fp64, fixed order: block b sums rows b, b + nb, ...; the partials are folded in block order
+template <typename T>
+__global__ __launch_bounds__(256) void k_col_sums_partial(const T *__restrict__ X, double *__restrict__ part, int C, int G, int64_t ld, int nb)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (g >= G) return;
+    double s = 0.0;
+    for (int c = b; c < C; c += nb) s += (double)X[(int64_t)c * ld + g];
+    part[(int64_t)b * G + g] = s;
+}
+__global__ __launch_bounds__(256) void k_col_means_fold(const double *__restrict__ part, double *__restrict__ mean, int C, int G, int nb)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= G) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += part[(int64_t)b * G + g];
+    mean[g] = s / (double)C;
+}
+
+constexpr int GM_MEAN_BLOCKS = 64;
+
+static int gram_ksplit(int64_t ntile, int64_t C, int64_t Ga, int64_t Gb, int cus)
+{
+    // at least ~4 workgroups per CU slot pair, at least 1024 cells per split, partials within 2 GiB
+    int64_t want = (4LL * 2 * (cus > 0 ? cus : 256) + ntile - 1) / ntile;
+    const int64_t by_cells = C / 1024 > 0 ? C / 1024 : 1;
+    if (want > by_cells) want = by_cells;
+    const int64_t by_mem = (int64_t)(2LL << 30) / (Ga * Gb * 8 > 0 ? Ga * Gb * 8 : 1);
+    if (want > by_mem) want = by_mem;
+    if (want < 1) want = 1;
+    if (ntile >= 4LL * 2 * (cus > 0 ? cus : 256)) want = 1;
+    return (int)want;
+}
+
+static inline int gram_tile_cols(int64_t Gb, bool sym) { return (!sym && Gb <= 64) ? 64 : 128; }
+
+template <typename TA, typename TB, bool SYM, int TN>
+static int launch_gram_t(const void *A, const void *B, const double *ma, const double *mb, double *out, void *ws, int64_t C, int64_t Ga, int64_t Gb,
+                         int64_t lda, int64_t ldb, int64_t ldo, hipStream_t st)
+{
+    DevInfo dev;
+    int rc = device_info(&dev);
+    if (rc) return rc;
+    const int64_t nta = (Ga + GM_T - 1) / GM_T, ntb = (Gb + TN - 1) / TN;
+    const int64_t ntile = SYM ? nta * (nta + 1) / 2 : nta * ntb;
+    const int ksplit = gram_ksplit(ntile, C, Ga, Gb, dev.cus);
+    int64_t cps = (C + ksplit - 1) / ksplit;
+    cps = (cps + GM_KS - 1) / GM_KS * GM_KS;
+    const int64_t total = ntile * ksplit, blocks = (total + 7) / 8 * 8;
+    if (blocks >= (1LL << 31)) return fail(VCY_ERR_INVALID, "%s: grid too large", "gram");
+    if (ksplit > 1 && !ws) return fail(VCY_ERR_INVALID, "%s: workspace missing (vcy_gram_workspace_bytes)", "gram");
+    const size_t lds = (size_t)2 * GM_KS * (GM_LD + TN + 16) * sizeof(double);
+    auto kern = k_gram<TA, TB, SYM, TN>;
+    rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+    if (rc) return rc;
+    const int64_t part_stride = Ga * Gb;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(GM_THREADS), lds, st, (const TA *)A, (const TB *)B, ma, mb, ksplit > 1 ? (double *)ws : out, (int)C,
+                       (int)Ga, (int)Gb, lda, ldb, ksplit > 1 ? Gb : ldo, (int)nta, (int)ntb, ksplit, (int)cps, part_stride);
+    VCY_LAUNCH_CHECK();
+    if (ksplit > 1) {
+        const int64_t n = Ga * Gb;
+        const int rb = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+        hipLaunchKernelGGL(k_gram_reduce<SYM>, dim3(rb), dim3(256), 0, st, (const double *)ws, out, (int)Ga, (int)Gb, ldo, ksplit, part_stride);
+        VCY_LAUNCH_CHECK();
+    }       // (ksplit == 1: the kernel wrote `out` itself and mirrored its off-diagonal tiles)
+    return VCY_OK;
+}
+
+template <typename TA, typename TB, bool SYM>
+static int launch_gram(const void *A, const void *B, const double *ma, const double *mb, double *out, void *ws, int64_t C, int64_t Ga, int64_t Gb,
+                       int64_t lda, int64_t ldb, int64_t ldo, hipStream_t st)
+{
+    if constexpr (!SYM) {
+        if (gram_tile_cols(Gb, false) == 64) return launch_gram_t<TA, TB, false, 64>(A, B, ma, mb, out, ws, C, Ga, Gb, lda, ldb, ldo, st);
+    }
+    return launch_gram_t<TA, TB, SYM, 128>(A, B, ma, mb, out, ws, C, Ga, Gb, lda, ldb, ldo, st);
+}
+
+}  // namespace vcy
+
+using namespace vcy;
+
+extern "C" size_t vcy_gram_workspace_bytes(int64_t C, int64_t G, int64_t L, int symmetric)
+{
+    DevInfo dev;
+    if (device_info(&dev)) dev.cus = 256;
+    const int tn = gram_tile_cols(L, symmetric != 0);
+    const int64_t nta = (G + GM_T - 1) / GM_T, ntb = (L + tn - 1) / tn;
+    const int64_t ntile = symmetric ? nta * (nta + 1) / 2 : nta * ntb;
+    const int ksplit = gram_ksplit(ntile, C, G, symmetric ? G : L, dev.cus);
+    const size_t means = (size_t)GM_MEAN_BLOCKS * (size_t)G * sizeof(double);
+    const size_t parts = ksplit > 1 ? (size_t)ksplit * (size_t)G * (size_t)(symmetric ? G : L) * sizeof(double) : 0;
+    return parts > means ? parts : means;
+}
+
+extern "C" int vcy_col_means(const void *X, double *mean, void *workspace, int64_t C, int64_t G, int64_t ld, int dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(X && mean && workspace, "col_means: null pointer");
+    VCY_REQUIRE(C > 0 && G > 0 && ld >= G, "col_means: bad shape");
+    VCY_REQUIRE(dtype == VCY_F32 || dtype == VCY_F64, "col_means: bad dtype");
+    hipStream_t st = as_stream(stream);
+    const int nb = (int)(C < GM_MEAN_BLOCKS ? C : GM_MEAN_BLOCKS);
+    dim3 grid((unsigned)((G + 255) / 256), (unsigned)nb);
+    if (dtype == VCY_F32) hipLaunchKernelGGL(k_col_sums_partial<float>, grid, dim3(256), 0, st, (const float *)X, (double *)workspace, (int)C, (int)G, ld, nb);
+    else hipLaunchKernelGGL(k_col_sums_partial<double>, grid, dim3(256), 0, st, (const double *)X, (double *)workspace, (int)C, (int)G, ld, nb);
+    VCY_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_col_means_fold, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, (const double *)workspace, mean, (int)C, (int)G, nb);
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}
+
+static int check_gram_args(const char *who, const void *X, const void *out, int64_t C, int64_t G, int64_t ld, int64_t ldo, int64_t L, int dtype)
+{
+    if (!(X && out)) return fail(VCY_ERR_INVALID, "%s: null pointer", who);
+    if (!(C > 0 && G > 0 && L > 0 && ld >= G && ldo >= L)) return fail(VCY_ERR_INVALID, "%s: bad shape", who);
+    if (C >= (1LL << 31) || G >= (1LL << 31) || L >= (1LL << 31)) return fail(VCY_ERR_INVALID, "%s: dimension too large", who);
+    if (!(dtype == VCY_F32 || dtype == VCY_F64)) return fail(VCY_ERR_INVALID, "%s: bad dtype", who);
+    if (ld % (dtype == VCY_F32 ? 4 : 2) != 0 || ((uintptr_t)X % 16)) return fail(VCY_ERR_INVALID, "%s: rows of X must be 16-byte aligned", who);
+    return VCY_OK;
+}
+
+extern "C" int vcy_gram(const void *X, const double *mean, double *gram, void *workspace, int64_t C, int64_t G, int64_t ld, int64_t ldg, int dtype,
+                        vcy_stream stream)
+{
+    int rc = check_gram_args("gram", X, gram, C, G, ld, ldg, G, dtype);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    if (dtype == VCY_F32) return launch_gram<float, float, true>(X, X, mean, mean, gram, workspace, C, G, G, ld, ld, ldg, st);
+    return launch_gram<double, double, true>(X, X, mean, mean, gram, workspace, C, G, G, ld, ld, ldg, st);
+}
+
+extern "C" int vcy_gram_tn(const void *X, const double *mean, const double *Y, double *out, void *workspace, int64_t C, int64_t G, int64_t L, int64_t ld,
+                           int64_t ldy, int64_t ldo, int dtype, vcy_stream stream)
+{
+    int rc = check_gram_args("gram_tn", X, out, C, G, ld, ldo, L, dtype);
+    if (rc) return rc;
+    VCY_REQUIRE(Y && ldy >= L && ldy % 2 == 0 && ((uintptr_t)Y % 16) == 0, "gram_tn: Y must be (C, ldy) fp64 with 16-byte aligned rows");
+    hipStream_t st = as_stream(stream);
+    if (dtype == VCY_F32) return launch_gram<float, double, false>(X, Y, mean, nullptr, out, workspace, C, G, L, ld, ldy, ldo, st);
+    return launch_gram<double, double, false>(X, Y, mean, nullptr, out, workspace, C, G, L, ld, ldy, ldo, st);
+}

@@ -1214,6 +1214,50 @@ def gene_stats(M, cell_scale=None, lo=None, hi=None, cell_mask=None) -> torch.Te
     return out
 
 
+def _gram_workspace(C: int, G: int, L: int, symmetric: bool, dev) -> torch.Tensor:
+    return torch.empty(max(16, int(_lib.lib().vcy_gram_workspace_bytes(C, G, L, int(symmetric)))), dtype=torch.uint8, device=dev)
+
+
+def col_means(X: CellMatrix) -> torch.Tensor:
+    """Per-gene means over the cells in fp64 (vcy_col_means; sklearn's X.mean(axis=0) of the (cells, genes) matrix PCA centres with)."""
+    mean = torch.empty(X.G, dtype=torch.float64, device=X.t.device)
+    ws = _gram_workspace(X.C, X.G, 1, True, X.t.device)
+    _lib.check(_lib.lib().vcy_col_means(X.t.data_ptr(), mean.data_ptr(), ws.data_ptr(), X.C, X.G, X.ld, X.code, _stream()), "col_means")
+    return mean
+
+
+def gram(X: CellMatrix, mean: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(G, G) fp64 Gram matrix of the (centred) genes, sum_c (X[c, i] - mean[i]) (X[c, j] - mean[j]), on the f64 matrix cores
+    (vcy_gram; the covariance product of perform_PCA, analysis.py:678-702).  mean None: no centring."""
+    dev = X.t.device
+    m = None if mean is None else mean.to(device=dev, dtype=torch.float64).contiguous()
+    assert m is None or m.numel() == X.G
+    out = torch.empty((X.G, X.G), dtype=torch.float64, device=dev)
+    ws = _gram_workspace(X.C, X.G, X.G, True, dev)
+    _lib.check(_lib.lib().vcy_gram(X.t.data_ptr(), _p(m), out.data_ptr(), ws.data_ptr(), X.C, X.G, X.ld, X.G, X.code, _stream()), "gram")
+    return out
+
+
+def gram_tn(X: CellMatrix, mean: Optional[torch.Tensor], Y: torch.Tensor) -> torch.Tensor:
+    """(G, L) fp64 block product (X - mean)^T Y, Y (C, L) fp64 on the device (vcy_gram_tn: the second half of the subspace
+    iteration's A^T (A Z))."""
+    dev = X.t.device
+    assert Y.dim() == 2 and Y.shape[0] == X.C and Y.dtype == torch.float64 and Y.is_cuda
+    L = int(Y.shape[1])
+    if L % 2 or not Y.is_contiguous():                         # rows of Y 16-byte aligned: an even pitch
+        ldy = L + (L % 2)
+        Yp = torch.zeros((X.C, ldy), dtype=torch.float64, device=dev)
+        Yp[:, :L] = Y
+    else:
+        ldy, Yp = L, Y
+    m = None if mean is None else mean.to(device=dev, dtype=torch.float64).contiguous()
+    out = torch.empty((X.G, L), dtype=torch.float64, device=dev)
+    ws = _gram_workspace(X.C, X.G, L, False, dev)
+    _lib.check(_lib.lib().vcy_gram_tn(X.t.data_ptr(), _p(m), Yp.data_ptr(), out.data_ptr(), ws.data_ptr(), X.C, X.G, L, X.ld, ldy, L, X.code,
+                                      _stream()), "gram_tn")
+    return out
+
+
 def svr_fit(x, t, C: float = 1.0, epsilon: float = 0.1, gamma: float = 1.0, tol: float = 1e-3, max_iter: int = -1):
     """epsilon-SVR (RBF kernel, scalar inputs) fitted on the device: (coef (n) = alpha - alpha*, intercept (1), info (4) int32 =
     [SMO steps, converged, barrier failed, workgroups]).  The fit sklearn.svm.SVR(C, epsilon, gamma, tol).fit(x[:, None], t) does

@@ -106,15 +106,10 @@ class DevicePCA:
         # solver that is iterated to convergence instead of stopped after a fixed number of passes.
         if self.svd_solver == "subspace" or (self.svd_solver == "auto" and min(C, G) > 4096 and k <= 0.25 * min(C, G)):
             return self._fit_subspace(X, k, block)
-        mean = torch.zeros(G, dtype=torch.float64, device=dev)
-        for s in range(0, C, block):
-            mean += X.t[s:s + block, :G].sum(0, dtype=torch.float64)
-        mean /= C
-        if G <= C:      # covariance of the genes (G x G)
-            gram = torch.zeros((G, G), dtype=torch.float64, device=dev)
-            for s in range(0, C, block):
-                A = X.t[s:s + block, :G].double() - mean
-                gram.addmm_(A.T, A)
+        mean = ops.col_means(X)
+        if G <= C:      # covariance of the genes (G x G): the centred Gram product on the f64 matrix cores (csrc/gram.hip), then the
+            #             symmetric eigenproblem of the small matrix as a library call (rocSOLVER through torch.linalg.eigh)
+            gram = ops.gram(X, mean)
             w, V = torch.linalg.eigh(gram)
             w, V = w.flip(0).clamp_(min=0.0), V.flip(1)                  # descending
             comps = V[:, :k].T.contiguous()                               # (k, G)
@@ -158,15 +153,14 @@ class DevicePCA:
         mean /= C
         total_var = float((ssq - C * (mean * mean).sum()) / (C - 1))            # trace of the covariance
 
-        def AtA(Z):                                                             # A^T (A Z), A centred, block by block
-            out = torch.zeros_like(Z)
+        def AtA(Z):                                                             # A^T (A Z), A centred
+            # Y = A Z (C x l): a thin projection, library GEMM per block of cells; A^T Y (G x l): the contraction over the cells
+            # on the f64 matrix cores with the centring folded into the staging (vcy_gram_tn)
             mz = mean @ Z
+            Y = torch.empty((C, Z.shape[1]), dtype=torch.float64, device=dev)
             for s in range(0, C, block):
-                b = X.t[s:s + block, :G].double()
-                y = b @ Z - mz                                                  # (A Z) rows of the block
-                out.addmm_(b.T, y)
-                out -= torch.outer(mean, y.sum(0))
-            return out
+                Y[s:s + block] = X.t[s:s + block, :G].double() @ Z - mz
+            return ops.gram_tn(X, mean, Y)
         gen = torch.Generator(device=dev).manual_seed(int(self.random_state))
         Z = torch.linalg.qr(torch.randn((G, l), generator=gen, device=dev, dtype=torch.float64))[0]
         prev = None
@@ -251,34 +245,40 @@ class PreprocessMixin:
         except AttributeError:
             pass
 
+    # which score attribute stands behind each switch of filter_genes (set by score_cluster_expression, score_cv_vs_mean,
+    # score_detection_levels respectively)
+    _GENE_FILTERS = (("by_cluster_expression", "clu_avg_selected"), ("by_cv_vs_mean", "cv_mean_selected"),
+                     ("by_detection_levels", "detection_level_selected"))
+
     def filter_genes(self, by_detection_levels: bool = False, by_cluster_expression: bool = False, by_cv_vs_mean: bool = False,
                      by_custom_array: Any = None, keep_unfiltered: bool = False) -> None:
-        """analysis.py:477-533: S, U and ra are cut down to the genes that pass every requested filter."""
-        assert np.any([by_detection_levels, by_cluster_expression, by_cv_vs_mean, (type(by_custom_array) is np.ndarray)]), \
-            "At least one of the filtering methods needs to be True"
-        tmp_filter = np.ones(self.dev("S").G, dtype=bool)
-        if by_cluster_expression:
-            assert hasattr(self, "clu_avg_selected"), "clu_avg_selected was not found"
-            tmp_filter = tmp_filter & self.clu_avg_selected
-        if by_cv_vs_mean:
-            assert hasattr(self, "cv_mean_selected"), "cv_mean_selected was not found"
-            tmp_filter = tmp_filter & self.cv_mean_selected
-        if by_detection_levels:
-            assert hasattr(self, "detection_level_selected"), "detection_level_selected was not found"
-            tmp_filter = tmp_filter & self.detection_level_selected
-        if type(by_custom_array) is np.ndarray:
-            if by_custom_array.dtype == bool:
-                tmp_filter = tmp_filter & by_custom_array
-            elif by_custom_array.dtype == int:
-                tmp_filter[~np.isin(np.arange(len(tmp_filter)), by_custom_array)] = False
+        """analysis.py:441-497: S, U and ra are cut down to the genes that pass every requested filter - the conjunction of the
+        stored score masks that were asked for and of a custom mask (boolean) or gene-number list (integer)."""
+        asked = dict(by_detection_levels=by_detection_levels, by_cluster_expression=by_cluster_expression, by_cv_vs_mean=by_cv_vs_mean)
+        custom = by_custom_array if type(by_custom_array) is np.ndarray else None
+        assert any(asked.values()) or custom is not None, "At least one of the filtering methods needs to be True"
+        n_genes = self.dev("S").G
+        masks = []
+        for switch, attr in self._GENE_FILTERS:
+            if asked[switch]:
+                assert hasattr(self, attr), f"{attr} was not found"
+                masks.append(np.asarray(getattr(self, attr), dtype=bool))
+        if custom is not None:
+            if custom.dtype == bool:
+                masks.append(custom)
+            elif custom.dtype == int:              # gene numbers: everything not listed goes
+                listed = np.zeros(n_genes, dtype=bool)
+                listed[custom[(custom >= 0) & (custom < n_genes)]] = True
+                masks.append(listed)
+        keep = np.logical_and.reduce([np.ones(n_genes, dtype=bool)] + masks)
         if keep_unfiltered:
             if hasattr(self, "U_prefilter"):
                 logging.debug("Attributes *_prefilter are already present and were overwritten")
-            self.U_prefilter = sparse.csr_matrix(self.U)
-            self.S_prefilter = sparse.csr_matrix(self.S)
+            for name in ("U", "S"):
+                setattr(self, name + "_prefilter", sparse.csr_matrix(getattr(self, name)))
             self.ra_prefilter = deepcopy(self.ra)
-        self._subset(("U", "S"), tmp_filter, "genes")
-        self.ra = {k: v[tmp_filter] for k, v in self.ra.items()}
+        self._subset(("U", "S"), keep, "genes")
+        self.ra = {key: values[keep] for key, values in self.ra.items()}
 
     def custom_filter_attributes(self, attr_names: List[str], bool_filter: np.ndarray) -> None:
         """analysis.py:535-571 (numbering of the reference file: the block before _normalize_S)."""
@@ -509,47 +509,49 @@ class PreprocessMixin:
         self.ts = bh_tsne.fit_transform(self.pcs[:, :n_pca_dim])
 
     # ------------------------------------------------------------------ deprecated one-call drivers
+    @staticmethod
+    def _default_thresholds(n_cells: int) -> Dict[str, float]:
+        """The cell-count heuristics of the deprecated one-call drivers (analysis.py:1909-1918, 1959-1960), in one place."""
+        clamp = lambda lo, x, hi: max(lo, min(hi, x))
+        return {"min_expr_counts": clamp(20, n_cells * 2.25e-3, 100), "min_cells_express": clamp(10, n_cells * 1.5e-3, 50),
+                "N": clamp(1000, int((n_cells / 1000) ** (1 / 3) / 0.0008), 5000), "min_avg_U": 0.01, "min_avg_S": 0.08,
+                "k": int(clamp(10, np.ceil(n_cells * 0.02), 1000))}
+
     def default_filter_and_norm(self, min_expr_counts: int = None, min_cells_express: int = None, N: int = None, min_avg_U: float = None,
                                 min_avg_S: float = None) -> None:
-        """analysis.py:1889-1940."""
+        """analysis.py:1889-1940: detection filter -> CV-vs-mean feature selection -> detection filter on the unspliced layer
+        (and per-cluster expression when clusters are set) -> total-count normalisations."""
         logging.warning("DEPRECATION WARNING - the current function is deprecated. Please refer to documentation for default parameters usage")
-        C = self.dev("S").C
-        if min_expr_counts is None:
-            min_expr_counts = max(20, min(100, C * 2.25e-3))
-        if min_cells_express is None:
-            min_cells_express = max(10, min(50, C * 1.5e-3))
-        if N is None:
-            N = max(1000, min(int((C / 1000)**(1 / 3) / 0.0008), 5000))
-        if min_avg_U is None:
-            min_avg_U = 0.01
-        if min_avg_S is None:
-            min_avg_S = 0.08
-        self.normalize("S", size=True, log=False)
-        self.normalize("U", size=True, log=False)
-        self.score_detection_levels(min_expr_counts=min_expr_counts, min_cells_express=min_cells_express)
+        given = dict(min_expr_counts=min_expr_counts, min_cells_express=min_cells_express, N=N, min_avg_U=min_avg_U, min_avg_S=min_avg_S)
+        t = {**self._default_thresholds(self.dev("S").C), **{name: v for name, v in given.items() if v is not None}}
+        for layer in ("S", "U"):                   # (only for the initial cell sizes; the normalised values are recomputed at the end)
+            self.normalize(layer, size=True, log=False)
+        self.score_detection_levels(min_expr_counts=t["min_expr_counts"], min_cells_express=t["min_cells_express"])
         self.filter_genes(by_detection_levels=True)
-        self.score_cv_vs_mean(N=N, max_expr_avg=40)
+        self.score_cv_vs_mean(N=t["N"], max_expr_avg=40)
         self.filter_genes(by_cv_vs_mean=True)
-        self.score_detection_levels(min_expr_counts=0, min_cells_express=0, min_expr_counts_U=int(min_expr_counts / 2) + 1,
-                                    min_cells_express_U=int(min_cells_express / 2) + 1)
-        if hasattr(self, "cluster_labels"):
-            self.score_cluster_expression(min_avg_U=min_avg_U, min_avg_S=min_avg_S)
-            self.filter_genes(by_detection_levels=True, by_cluster_expression=True)
-        else:
-            self.filter_genes(by_detection_levels=True)
+        half = lambda x: int(x / 2) + 1
+        self.score_detection_levels(min_expr_counts=0, min_cells_express=0, min_expr_counts_U=half(t["min_expr_counts"]),
+                                    min_cells_express_U=half(t["min_cells_express"]))
+        clustered = hasattr(self, "cluster_labels")
+        if clustered:
+            self.score_cluster_expression(min_avg_U=t["min_avg_U"], min_avg_S=t["min_avg_S"])
+        self.filter_genes(by_detection_levels=True, by_cluster_expression=clustered)
         self.normalize_by_total()
         self.adjust_totS_totU(normalize_total=True)
 
     def default_fit_preparation(self, k: int = None, n_comps: int = None) -> None:
-        """analysis.py:1942-1964."""
+        """analysis.py:1942-1964: PCA, the number of components from the elbow of the explained variance, balanced kNN pooling with
+        sight 8 k and in-degree cap 4 k, median normalisation."""
         logging.warning("DEPRECATION WARNING - the current function is deprecated. Please refer to documetation for default parameters usage")
-        C = self.dev("S").C
+        n_cells = self.dev("S").C
         self.perform_PCA()
         if n_comps is None:
-            n_comps = int(np.where(np.diff(np.diff(np.cumsum(self.pca.explained_variance_ratio_)) > 0.002))[0][0])
-        if k is None:
-            k = int(min(1000, max(10, np.ceil(C * 0.02))))
-        self.knn_imputation(n_pca_dims=n_comps, k=k, balanced=True, b_sight=int(min(k * 8, C - 1)), b_maxl=int(min(k * 4, C - 1)))
+            gain = np.diff(np.cumsum(self.pca.explained_variance_ratio_))
+            n_comps = int(np.flatnonzero(np.diff(gain > 0.002))[0])       # first component where the 0.2 % gain test flips
+        k = self._default_thresholds(n_cells)["k"] if k is None else k
+        cap = n_cells - 1
+        self.knn_imputation(n_pca_dims=n_comps, k=k, balanced=True, b_sight=int(min(k * 8, cap)), b_maxl=int(min(k * 4, cap)))
         self.normalize_median()
 
     def gene_knn_imputation(self, *args, **kwargs) -> None:
