@@ -31,7 +31,8 @@ CORR_ATOL = {"float64": 1e-10, "float32": 5e-5}
 def _nan_close(got, ref, atol, skip=None):
     got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
     bad = np.isnan(ref) if skip is None else (np.isnan(ref) | skip)
-    assert np.isnan(got[np.isnan(ref) & ~(skip if skip is not None else False)]).all()
+    must_be_nan = np.isnan(ref) if skip is None else (np.isnan(ref) & ~skip)
+    assert np.isnan(got[must_be_nan]).all()
     np.testing.assert_allclose(got[~bad], ref[~bad], atol=atol, rtol=0)
 
 

@@ -10,7 +10,8 @@ import bench
 
 C, G = int(os.environ.get("C", 50000)), int(os.environ.get("G", 30000))
 dev = ops.require_gpu()
-S, U, pcs = bench.synth(C, G, 30, dev)
+DT = {"f32": torch.float32, "f64": torch.float64}[os.environ.get("DTYPE", "f32")]
+cS, cU, fS, fU, pcs = bench.synth_counts(C, G, 30, dev)         # the loom's count layers: the facade pools from them (vcy_knn_pool_counts)
 acc = collections.OrderedDict()
 
 
@@ -33,7 +34,8 @@ for n in ("_permute_rows_nsign", "_fill_diagonal_zero"):
     if hasattr(analysis, n):
         wrap(analysis, n)
 
-vlm = vcy.analysis.VelocytoLoom.from_arrays(S, U)
+vlm = vcy.analysis.VelocytoLoom.from_arrays(cS, cU, dtype=DT)
+del cS, cU
 vlm.pcs = pcs.cpu().numpy(); vlm.ts = vlm.pcs[:, :2].copy()
 
 

@@ -8,7 +8,7 @@ import bench
 
 C, G = int(os.environ.get("C", 10000)), int(os.environ.get("G", 20000))
 dev = ops.require_gpu()
-S, U, pcs = bench.synth(C, G, 30, dev)
+DT = {"f32": torch.float32, "f64": torch.float64}[os.environ.get("DTYPE", "f32")]
 t_all = time.perf_counter()
 
 def timed(name, fn, *a, **k):
@@ -36,7 +36,17 @@ if os.environ.get("PRE", "1") == "1":
     del pre
     torch.cuda.empty_cache()
 
-vlm = vcy.analysis.VelocytoLoom.from_arrays(S, U)       # device matrices go in as they are
+# the loom's count layers go in as they are on disk (uint16 / uint8 device matrices): knn_imputation then pools from the counts
+# (vcy_knn_pool_counts) as long as S_sz / U_sz are still factor x counts; COUNTS=0 hands over f32 matrices instead (vcy_knn_pool2)
+if os.environ.get("COUNTS", "1") == "1":
+    cS, cU, fS, fU, pcs = bench.synth_counts(C, G, 30, dev)
+    vlm = vcy.analysis.VelocytoLoom.from_arrays(cS, cU, dtype=DT)
+    del cS, cU
+else:
+    S, U, pcs = bench.synth(C, G, 30, dev)
+    vlm = vcy.analysis.VelocytoLoom.from_arrays(S, U, dtype=DT)
+    del S, U
+print(f"# facade storage {os.environ.get('DTYPE', 'f32')}, layers as {'counts' if os.environ.get('COUNTS', '1') == '1' else 'float matrices'}")
 vlm.pcs = pcs.cpu().numpy(); vlm.ts = vlm.pcs[:, :2].copy()
 for _pass in range(int(os.environ.get("PASSES", 1))):          # PASSES=2: the second pass is the steady state (buffers come from the allocator's cache)
     if _pass:

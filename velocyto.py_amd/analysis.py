@@ -41,6 +41,9 @@ from .preprocess import PreprocessMixin, colormap_fun  # noqa: F401  (colormap_f
 _MATRIX_ATTRS = frozenset(["S", "U", "A", "S_sz", "U_sz", "S_norm", "U_norm", "Sx", "Ux", "Sx_sz", "Ux_sz", "Sx_norm", "Ux_norm",
                            "Upred", "velocity", "delta_S", "delta_S_rndm", "Sx_sz_t", "Sx_t"])
 _LAZY_DENSE = frozenset(["corrcoef", "corrcoef_random", "transition_prob", "transition_prob_random", "tr", "embedding_knn"])
+# scipy containers of the pooling graph: assembled from the device rows the first time somebody reads them (knn_imputation itself
+# pools from the device rows and needs neither)
+_LAZY_GRAPH = frozenset(["knn", "knn_smoothing_w"])
 
 
 class VelocytoLoom(PreprocessMixin):
@@ -95,6 +98,10 @@ class VelocytoLoom(PreprocessMixin):
                 return h[name]
         elif name in _LAZY_DENSE:
             return self._densify(name)
+        elif name in _LAZY_GRAPH:
+            lazy = object.__getattribute__(self, "__dict__").get("_graph_lazy")
+            if lazy is not None:
+                return self._materialise_graph(name, lazy)
         raise AttributeError(f"'{type(self).__name__}' object has no attribute '{name}'")
 
     def __setattr__(self, name: str, value) -> None:
@@ -130,6 +137,23 @@ class VelocytoLoom(PreprocessMixin):
     def _set_dev(self, name: str, m: CellMatrix) -> None:
         self._host.pop(name, None)
         self._dev[name] = m
+
+    def _materialise_graph(self, name: str, lazy: dict):
+        """`knn` / `knn_smoothing_w` as the scipy matrices the reference stores (analysis.py:1005-1010), built from the device rows
+        knn_imputation kept (lists sorted by cell number - the state (self.knn > 0) leaves the matrix in -, distances all positive):
+        once, on first access; afterwards they are plain attributes."""
+        from .neighbors import weights_from_sorted_knn
+        if "host" not in lazy:
+            lazy["host"] = (lazy["idx_s"].cpu().numpy(), lazy["dist_s"].cpu().numpy())
+        idx_s, dist_s = lazy["host"]
+        n, k = idx_s.shape
+        if name == "knn":
+            m = sparse.csr_matrix((dist_s.ravel(), idx_s.ravel(), np.arange(0, n * k + 1, k)), shape=(n, n))
+            m.has_sorted_indices = True
+        else:
+            m = weights_from_sorted_knn(idx_s, lazy["diag"])
+        self.__dict__[name] = m
+        return m
 
     def _densify(self, name: str):
         """(cells, cells) numpy views of the compact device results (read-only convenience)."""
@@ -274,6 +298,9 @@ class VelocytoLoom(PreprocessMixin):
             b_maxl = np.maximum(int(k * 4), N - 1)
         space = self.pcs[:, :n_pca_dims] if pca_space else self.S_norm.T
         w_direct = False                                          # knn_smoothing_w written out directly (below) instead of through scipy
+        dev_rows = None                                           # ... and kept as device rows (unbalanced graph without duplicate cells)
+        for stale in ("_graph_lazy", "knn", "knn_smoothing_w"):   # a previous graph, lazy or materialised, is gone
+            self.__dict__.pop(stale, None)
         if balanced:
             constraint = None
             if group_constraint is not None:
@@ -301,16 +328,22 @@ class VelocytoLoom(PreprocessMixin):
                 raise ValueError("group_constraint is currently supported only if the argument balanced is set to True")
             if diag != 0:
                 # the graph with its rows sorted by cell number on the device - the state (self.knn > 0) leaves self.knn in, :1006 -
-                # and, when no distance is zero (no duplicate cells), the weights written out directly: the same matrices as the
-                # scipy chain below (tests/test_host_and_abi.py), without its four structure-changing passes over the graph
-                from .neighbors import _kneighbors_device, weights_from_sorted_knn
-                idx_s, dist_s, positive = _kneighbors_device(space, k, metric)
-                n_rows = idx_s.shape[0]
-                self.knn = sparse.csr_matrix((dist_s.ravel(), idx_s.ravel(), np.arange(0, n_rows * k + 1, k)), shape=(n_rows, n_rows))
-                self.knn.has_sorted_indices = True
+                # and, when no distance is zero (no duplicate cells), the weights written out directly ON THE DEVICE: the same
+                # matrices as the scipy chain below (tests/test_host_and_abi.py, tests/test_gpu_facade.py), none of which is built
+                # unless somebody reads `vlm.knn` / `vlm.knn_smoothing_w` (the containers cost 25 ms of host time at 50 000 cells
+                # against 12 ms of kernels)
+                from .neighbors import _kneighbors_rows_device
+                idx_s, dist_s, positive = _kneighbors_rows_device(space, k, metric)
                 if positive:
-                    self.knn_smoothing_w = weights_from_sorted_knn(idx_s, diag)
+                    n_rows = int(idx_s.shape[0])
+                    self.__dict__["_graph_lazy"] = {"idx_s": idx_s, "dist_s": dist_s, "diag": diag}
+                    dev_rows = ops.weight_rows_from_sorted_knn(idx_s, diag, self._dtype)
                     w_direct = True
+                else:
+                    n_rows = int(idx_s.shape[0])
+                    self.knn = sparse.csr_matrix((dist_s.cpu().numpy().ravel(), idx_s.cpu().numpy().ravel(), np.arange(0, n_rows * k + 1, k)),
+                                                 shape=(n_rows, n_rows))
+                    self.knn.has_sorted_indices = True
             else:
                 self.knn = knn_distance_matrix(space, metric=metric, k=k, mode="distance", n_jobs=n_jobs)
         if not w_direct:
@@ -322,7 +355,7 @@ class VelocytoLoom(PreprocessMixin):
         # schedule the pooling along the Hilbert curve of the two leading coordinates of the search space (results do not
         # depend on it; neighbouring cells gather overlapping rows while they are still in L2)
         self.__dict__["_pool_order"] = ops.hilbert_order(np.ascontiguousarray(space[:, :2])) if np.shape(space)[1] >= 2 else None
-        self._pool(self.knn_smoothing_w, maximum and size_norm, "S_sz" if size_norm else "S", "U_sz" if size_norm else "U")
+        self._pool(self.knn_smoothing_w if dev_rows is None else dev_rows, maximum and size_norm, "S_sz" if size_norm else "S", "U_sz" if size_norm else "U")
         if maximum and not size_norm:
             # the reference takes the maximum with the SIZE-NORMALISED layers whatever was pooled (analysis.py:1017-1019:
             # np.maximum(self.S_sz, self.Sx)); reproduced as is
@@ -336,13 +369,19 @@ class VelocytoLoom(PreprocessMixin):
         self.__dict__["_pool_order"] = None
         self._pool(knn_smoothing_w, maximum, "S_sz", "U_sz")
 
-    def _pool(self, w: sparse.spmatrix, maximum: bool, s_name: str, u_name: str) -> None:
-        w = sparse.csr_matrix(w)
-        assert np.allclose(np.asarray(w.sum(1)).ravel(), 1), "weight matrix need to sum to one over the columns"   # neighbors.py:422
-        indptr, indices, vals = w.indptr.astype(np.int64), w.indices.astype(np.int32), np.ascontiguousarray(w.data, dtype=np.float64)
+    def _pool(self, w, maximum: bool, s_name: str, u_name: str) -> None:
+        """w: the weight matrix (scipy sparse, rows summing to one) or its rows already on the device as (indptr, indices, values)."""
+        if isinstance(w, tuple):
+            indptr, indices, vals = w
+            n_rows = int(indptr.numel()) - 1
+        else:
+            w = sparse.csr_matrix(w)
+            assert np.allclose(np.asarray(w.sum(1)).ravel(), 1), "weight matrix need to sum to one over the columns"   # neighbors.py:422
+            indptr, indices, vals = w.indptr.astype(np.int64), w.indices.astype(np.int32), np.ascontiguousarray(w.data, dtype=np.float64)
+            n_rows = w.shape[0]
         counts, scale = self.__dict__.get("_counts", {}), self.__dict__.get("_sz_scale", {})
         order = self.__dict__.get("_pool_order")
-        if order is not None and int(order.numel()) != w.shape[0]:
+        if order is not None and int(order.numel()) != n_rows:
             order = None
         if "S" in counts and "U" in counts and ((s_name, u_name) == ("S", "U") or
                                                 ((s_name, u_name) == ("S_sz", "U_sz") and "S_sz" in scale and "U_sz" in scale)):
@@ -351,7 +390,8 @@ class VelocytoLoom(PreprocessMixin):
                 for n in ("S", "U"):
                     if counts[n].t.dtype == torch.uint8:
                         counts[n] = ops.CountMatrix(counts[n].t.to(torch.int16), counts[n].G)
-            Sx, Ux = ops.knn_pool_counts(counts["S"], counts["U"], sS, sU, indptr, indices, vals, dtype=self._dtype, maximum=maximum, order=order)
+            Sx, Ux = ops.knn_pool_counts(counts["S"], counts["U"], sS, sU, indptr, indices, vals, dtype=self._dtype, maximum=maximum, order=order,
+                                         validate=not isinstance(w, tuple))
         else:
             Sx, Ux = ops.knn_pool2(self.dev(s_name), self.dev(u_name), indptr, indices, vals, maximum=maximum, order=order)
         self._set_dev("Sx", Sx)
@@ -840,6 +880,9 @@ class VelocytoLoom(PreprocessMixin):
         for name in self._dev:
             if name not in exclude:
                 out[name] = np.ascontiguousarray(getattr(self, name))
+        for lazy_name in _LAZY_GRAPH:                                 # the pooling graph's scipy containers, if still only on the device
+            if lazy_name not in exclude:
+                getattr(self, lazy_name, None)
         items = dict(self.__dict__)
         if "_neigh" in items and "embedding_knn" not in exclude:
             items["embedding_knn"] = self.embedding_knn               # assembled on demand; a plain attribute in the reference

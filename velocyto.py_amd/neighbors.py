@@ -59,6 +59,18 @@ def _kneighbors_device(data: np.ndarray, k: int, metric: Optional[str]) -> Tuple
     return idx_s.cpu().numpy(), dist_s.cpu().numpy(), positive
 
 
+def _kneighbors_rows_device(data: np.ndarray, k: int, metric: Optional[str]):
+    """_kneighbors_device without the download: (indices int32 (n, k) sorted by cell number, their distances float64 (n, k),
+    all distances > 0) with the two matrices still on the device (one scalar comes back)."""
+    X, corr = _search_space(data, "correlation" if metric == "correlation" else None)
+    idx, dist = ops.knn_search(X, k, include_self=False)
+    if corr:
+        dist = dist * dist / 2.0
+    idx_s, order = torch.sort(idx, dim=1)
+    dist_s = torch.gather(dist, 1, order)
+    return idx_s.contiguous(), dist_s.contiguous(), bool((dist_s > 0).all())
+
+
 def knn_distance_matrix(data: np.ndarray, metric: str = None, k: int = 40, mode: str = "connectivity", n_jobs: int = 4
                         ) -> sparse.csr_matrix:
     """neighbors.py:363-376: kNN graph (query excluded), k entries per row, nearest first.

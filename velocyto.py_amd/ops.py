@@ -332,6 +332,22 @@ class CsrCounts:
         return (cs[self.indptr[1:]] - cs[self.indptr[:-1]]).double()
 
 
+def weight_rows_from_sorted_knn(idx_sorted: torch.Tensor, diag: float, dtype=None):
+    """Device form of neighbors.weights_from_sorted_knn: the rows of knn_smoothing_w (analysis.py:1006-1010 on a kNN graph without
+    zero distances) as (indptr int64, indices int32, values) - every row the cell itself (`diag`) and its k neighbours (1), in
+    ascending cell number, times the reciprocal of the row sum k + diag: the same fp64 values scipy's chain produces."""
+    dev = idx_sorted.device
+    n, k = idx_sorted.shape
+    me = torch.arange(n, device=dev, dtype=torch.int32)[:, None]
+    cols = torch.cat([me, idx_sorted.to(torch.int32)], 1)
+    vals = torch.ones((n, k + 1), dtype=torch.float64, device=dev)
+    vals[:, 0] = float(diag)
+    vals = vals * (1.0 / (np.float64(k) + np.float64(diag)))
+    cols, vals = canonical_graph_rows(cols, vals)
+    indptr = torch.arange(0, (n + 1) * (k + 1), k + 1, device=dev, dtype=torch.int64)
+    return indptr, cols.reshape(-1).contiguous(), vals.reshape(-1).to(resolve_dtype(dtype)).contiguous()
+
+
 def knn_pool_csr(counts: CsrCounts, scale, indptr, indices, weights, dtype=None, maximum: bool = False, cell0: int = 0,
                  C_out: Optional[int] = None, out: Optional[CellMatrix] = None, order: Optional[torch.Tensor] = None,
                  validate: bool = True) -> CellMatrix:
