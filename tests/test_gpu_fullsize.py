@@ -446,13 +446,14 @@ def test_fullsize_stage_d_reference_default_list_width_against_the_oracle(world,
     indptr = torch.arange(0, (C + 1) * (K + 1), K + 1, device=dev, dtype=torch.int64)
     indices, wrow = ops.canonical_graph_rows(indices, wrow)
     gen = torch.Generator(device=dev).manual_seed(5)
+    d2_f32 = torch.randn((C, ops.padded_ld(G)), generator=gen, device=dev, dtype=torch.float32)       # a control with the shape of dmat_rndm; the
+    d2_f32[:, G:] = 0                                                                                  # same values in both storage types
     got, ref_inputs = {}, None
     for dtype, name in ((torch.float64, "f64"), (torch.float32, "f32")):
         Sx, Ux = ops.knn_pool_counts(cS, cU, fS, fU, indptr, indices, wrow.to(dtype), dtype=dtype, validate=False)
         gam = ops.fit_slope(Ux, Sx)
         gam[~torch.isfinite(gam)] = 0.0
-        d2 = ops.CellMatrix(torch.randn(Sx.t.shape, generator=gen, device=dev, dtype=torch.float32).to(dtype), G)   # a control with the shape of dmat_rndm
-        d2.t[:, G:] = 0
+        d2 = ops.CellMatrix(d2_f32.to(dtype), G)
         if name == "f64":
             ref_inputs = (Sx, Ux, gam.double().cpu().numpy(), d2)
         rule_sets = (("literal", ops.RULES_PARTIAL),) if name == "f64" else (("production", ops.partial_rules_for(Sx, ops.SQRT, 1e-10)), ("literal", ops.RULES_PARTIAL))

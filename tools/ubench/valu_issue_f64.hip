@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cstring>
 #include <algorithm>
 #define ITER 500
 #define REP 4
@@ -83,10 +84,22 @@ __device__ __forceinline__ double sqrt_f32seed2(double x)           // candidate
     d = fma(-g, g, x);
     return fma(d, h, g);
 }
+__device__ __forceinline__ double sqrt_f32prod(double x)            // round 4 (what the kernel runs now): the f32 PRODUCT x_f * rsq(x_f) as a 24-bit seed
+{                                                                    // of the root - its square is exact in f64, so the residual x - s0^2 is exact -
+    const float xf = (float)x;                                       // and two Newton corrections with h = rsq / 2 (exponent decrement, an integer
+    const float yf = __builtin_amdgcn_rsqf(xf);                      // op): 2^-22 -> 2^-44 -> below half an ulp.  One f64 multiply less than the
+    const double s0 = (double)(xf * yf);                             // Goldschmidt form with one correction, and closer to the correctly rounded root
+    const double y = (double)yf;
+    const double h = __hiloint2double(__double2hiint(y) - 0x00100000, __double2loint(y));
+    double d = fma(-s0, s0, x);
+    const double s1 = fma(d, h, s0);
+    d = fma(-s1, s1, x);
+    return fma(d, h, s1);
+}
 template <int MODE> __device__ __forceinline__ double elem(double t, double psc)
 {
     const double a = fabs(t) + psc;
-    const double s = MODE == 0 ? sqrt_lib_iter(a) : (MODE == 1 ? sqrt_f32seed(a) : (MODE == 2 ? sqrt_f32seed2(a) : sqrt(a)));
+    const double s = MODE == 0 ? sqrt_lib_iter(a) : (MODE == 1 ? sqrt_f32seed(a) : (MODE == 2 ? sqrt_f32seed2(a) : (MODE == 4 ? sqrt_f32prod(a) : sqrt(a))));
     return (fabs(t) < 1e-16) ? 0.0 : copysign(s, t);
 }
 template <int MODE>
@@ -115,15 +128,21 @@ __global__ void __launch_bounds__(256) k_elem(double *out, unsigned long long *c
 // accuracy of the candidates against the library square root over a sweep of magnitudes
 __global__ void k_sqrt_err(double *maxrel, int n)
 {
-    double m1 = 0, m2 = 0;
+    double m1 = 0, m2 = 0, m3 = 0;
+    unsigned long long off = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const double x = exp2(-60.0 + 120.0 * (double)i / n) * (1.0 + 1e-3 * (i % 997));
         const double s = sqrt(x);
         m1 = fmax(m1, fabs(sqrt_f32seed(x) - s) / s);
         m2 = fmax(m2, fabs(sqrt_f32seed2(x) - s) / s);
+        const double p = sqrt_f32prod(x);
+        m3 = fmax(m3, fabs(p - s) / s);
+        off += p != s;
     }
     atomicMax((unsigned long long *)&maxrel[0], (unsigned long long)__double_as_longlong(m1));
     atomicMax((unsigned long long *)&maxrel[1], (unsigned long long)__double_as_longlong(m2));
+    atomicMax((unsigned long long *)&maxrel[2], (unsigned long long)__double_as_longlong(m3));
+    atomicAdd((unsigned long long *)&maxrel[3], off);
 }
 
 template <typename F> static void run(const char *name, F k, int wps, double units_per_iter, const char *unit)
@@ -154,10 +173,13 @@ int main()
     run("f64 element, v_rsq_f64 + lib iteration (today)", k_elem<0>, w, 4, "element");
     run("f64 element, f32 seed + 1 step + 1 correction", k_elem<1>, w, 4, "element");
     run("f64 element, f32 seed + 1 step + 2 corrections", k_elem<2>, w, 4, "element");
+    run("f64 element, f32 product seed + 2 Newton corrections (round 4)", k_elem<4>, w, 4, "element");
     run("f64 element, library sqrt()", k_elem<3>, w, 4, "element");
-    double *mr; hipMalloc(&mr, 16); hipMemset(mr, 0, 16);
+    double *mr; hipMalloc(&mr, 32); hipMemset(mr, 0, 32);
     k_sqrt_err<<<1024, 256>>>(mr, 1 << 26);
-    double h[2]; hipMemcpy(h, mr, 16, hipMemcpyDeviceToHost);
-    printf("max relative error against sqrt() over 2^26 arguments in [2^-60, 2^60]: f32 seed + 1 correction %.3g, + 2 corrections %.3g (ulp = 1.1e-16)\n", h[0], h[1]);
+    double h[4]; hipMemcpy(h, mr, 32, hipMemcpyDeviceToHost);
+    unsigned long long noff; memcpy(&noff, &h[3], 8);
+    printf("max relative error against sqrt() over 2^26 arguments in [2^-60, 2^60]: f32 seed + 1 correction %.3g, + 2 corrections %.3g, f32 product seed + 2 Newton "
+           "corrections %.3g with %llu results not equal to sqrt() bit for bit (ulp = 1.1e-16)\n", h[0], h[1], h[2], noff);
     return 0;
 }

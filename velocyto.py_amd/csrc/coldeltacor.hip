@@ -70,21 +70,26 @@ template <> __device__ __forceinline__ float xform<float, VCY_SQRT, VCY_RULES_PA
 // f64 hot variant (partial sqrt; the reference-precision build).  sqrt(double) expands to v_rsq_f64 (12.5 clocks per wave64, measured:
 // profiles/r03_valu_issue_f64.txt) + a coupled Goldschmidt step + two residual corrections, wrapped in a range scaling (inputs below
 // 2^-767) and a 0 / inf fix-up: ~17 f64 instructions, 130 clocks per element with the moments.  The argument here is |t| + psc with
-// |t| >= 1e-16 whenever the result is used, far inside the f32 exponent range, so the seed can come from the f32 unit instead:
-// v_cvt_f32_f64, v_rsq_f32 (8 clocks, 2^-23), 0.5 y in f32, two v_cvt_f64_f32, then one coupled Goldschmidt step (2^-45) and ONE
-// residual correction in f64: 84 clocks per element (the bare v_rsq_f64 iteration with both corrections: 94.5).  Faithfully rounded:
-// largest relative error against sqrt() over 2^26 arguments in [2^-60, 2^60] 2.2e-16 = 2 ulp (same file), against 1e-10 of tolerance
-// on a correlation.  Domain: |t| + psc in [1e-38, 3e38] (a count-derived matrix never leaves it; below 1e-16 the zero rule discards
-// the value).
+// |t| >= 1e-16 whenever the result is used, far inside the f32 exponent range, so the seed comes from the f32 unit instead:
+//     x_f = (float) x,  y_f = v_rsq_f32(x_f) (8 clocks, 2^-23),  s0 = (double)(x_f * y_f): a 24-BIT seed of the root, 2^-22 off;
+//     h   = y_f / 2 as a double: one conversion and an exponent decrement (an integer subtract on the high word, full rate);
+//     d = x - s0^2 (exact: the square of a 24-bit number fits a double, the fma rounds once), s1 = s0 + d h   -> 2^-44;
+//     d = x - s1^2 (one rounding),                                                       s  = s1 + d h   -> below half an ulp.
+// Four f64 FMAs where round 3's Goldschmidt form (g = x y, r = 1/2 - h g, g += g r, one correction) took a multiply and four, and a
+// result that is the correctly rounded root in all but near-tie cases (round 3: up to 2 ulp; tools/ubench/valu_issue_f64.hip counts
+// both over 2^26 arguments in [2^-60, 2^60], profiles/r04_valu_issue_f64.txt).  Domain: |t| + psc in [1e-38, 3e38] - a count-derived
+// matrix never leaves it, ops.check_f64_sqrt_domain refuses one that does, below 1e-16 the zero rule discards the value.
 __device__ __forceinline__ double sqrt_normal_f64(double x)
 {
-    const float yf = __builtin_amdgcn_rsqf((float)x);
-    const double y = (double)yf, h = (double)(0.5f * yf);
-    double g = x * y;
-    const double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    const double d = fma(-g, g, x);
-    return fma(d, h, g);
+    const float xf = (float)x;
+    const float yf = __builtin_amdgcn_rsqf(xf);
+    const double s0 = (double)(xf * yf);
+    const double y = (double)yf;
+    const double h = __hiloint2double(__double2hiint(y) - 0x00100000, __double2loint(y));
+    double d = fma(-s0, s0, x);
+    const double s1 = fma(d, h, s0);
+    d = fma(-s1, s1, x);
+    return fma(d, h, s1);
 }
 template <> __device__ __forceinline__ double xform<double, VCY_SQRT, VCY_RULES_PARTIAL>(double t, double psc)
 {
