@@ -34,8 +34,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cells", type=int, default=50000)
 ap.add_argument("--genes", type=int, default=30000)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--dtype", choices=["f32", "f64"], default="f64", help="arithmetic of the modelled run (f64 = bench.py's headline)")
 a0 = ap.parse_args()
-sys.argv = ["bench.py", "--cells", str(a0.cells), "--genes", str(a0.genes)]
+DT = torch.float64 if a0.dtype == "f64" else torch.float32
+ES = 8 if a0.dtype == "f64" else 4
+sys.argv = ["bench.py", "--cells", str(a0.cells), "--genes", str(a0.genes), "--dtype", a0.dtype]
 a = bench.parse()
 dev = ops.require_gpu()
 C, G, k = a.cells, a.genes, a.k
@@ -62,18 +65,18 @@ def timed(fn):
 
 # the whole pooled matrices once (every rank's e rows and halo rows are rows of these), gamma, the branch rule
 idx, dist_ = ops.knn_search(space, k, include_self=False)
-conn = (dist_ > 0).float()
-wrow = torch.cat([torch.ones((C, 1), device=dev), conn], 1)
+conn = (dist_ > 0).to(DT)
+wrow = torch.cat([torch.ones((C, 1), device=dev, dtype=DT), conn], 1)
 wrow = wrow / wrow.sum(1, keepdim=True)
 rows_g = torch.cat([torch.arange(C, device=dev, dtype=torch.int32)[:, None], idx], 1)
 rows_g, wrow = ops.canonical_graph_rows(rows_g, wrow)
 indptr_all = torch.arange(0, (C + 1) * (k + 1), k + 1, device=dev, dtype=torch.int64)
-Sx, Ux = ops.knn_pool_counts(cS, cU, fS, fU, indptr_all, rows_g, wrow, dtype=torch.float32, validate=False)
+Sx, Ux = ops.knn_pool_counts(cS, cU, fS, fU, indptr_all, rows_g, wrow, dtype=DT, validate=False)
 gamma = ops.fit_slope_from_moments(ops.fit_slope_moments(Ux, Sx))
 gamma[~torch.isfinite(gamma)] = 0.0
 rules = ops.partial_rules_for(Sx, ops.SQRT, 1e-10)
 
-out = {"workload": {"cells": C, "genes": G, "k": k, "nrndm": nr}, "assumptions": {"xgmi_link_Bps": LINK, "link_efficiency": EFF, "collective_latency_s": LAT},
+out = {"workload": {"cells": C, "genes": G, "k": k, "nrndm": nr, "dtype": a0.dtype}, "assumptions": {"xgmi_link_Bps": LINK, "link_efficiency": EFF, "collective_latency_s": LAT},
        "worlds": {}}
 for N in (1, 2, 4, 8):
     ranks = []
@@ -85,9 +88,9 @@ for N in (1, 2, 4, 8):
         t_knn = timed(lambda: ops.knn_search(space, k, include_self=False, q0=c0, Q=nloc))
         ip = indptr_all[: nloc + 1]
         rg, ww = rows_g[c0:c1].contiguous().reshape(-1), wrow[c0:c1].contiguous().reshape(-1)
-        Sx_l, Ux_l = ops.CellMatrix.empty(nloc, G, torch.float32), ops.CellMatrix.empty(nloc, G, torch.float32)
+        Sx_l, Ux_l = ops.CellMatrix.empty(nloc, G, DT), ops.CellMatrix.empty(nloc, G, DT)
         order_p = ops.hilbert_order(space[c0:c1])
-        t_pool = timed(lambda: ops.knn_pool_counts(cS, cU, fS, fU, ip, rg, ww, dtype=torch.float32, cell0=c0, C_out=nloc, out=Sx_l, out2=Ux_l,
+        t_pool = timed(lambda: ops.knn_pool_counts(cS, cU, fS, fU, ip, rg, ww, dtype=DT, cell0=c0, C_out=nloc, out=Sx_l, out2=Ux_l,
                                                    validate=False, order=order_p))
         # ---- B
         t_fit = timed(lambda: ops.fit_slope_moments(Ux_l, Sx_l))
@@ -101,8 +104,8 @@ for N in (1, 2, 4, 8):
         ixs = ops.localize_rows(nl, c0, c1, halo)
         base = ops.hilbert_order(emb[c0:c1]).long()
         inter = ((nl >= c0) & (nl < c1)).all(1)
-        s_in, s_out = distributed.overlap_schedules(base, inter, torch.cuda.get_device_properties(dev).multi_processor_count * 8)
-        corr = torch.empty((nloc, nr), dtype=torch.float32, device=dev)
+        s_in, s_out = distributed.overlap_schedules(base, inter, torch.cuda.get_device_properties(dev).multi_processor_count * (6 if ES == 8 else 8))
+        corr = torch.empty((nloc, nr), dtype=DT, device=dev)
         Ux_r = Ux.rows(c0, c1)
         Ux_r = ops.CellMatrix(Ux_r.t.contiguous(), G)
 
@@ -115,10 +118,10 @@ for N in (1, 2, 4, 8):
         else:
             t_in, t_out = timed(lambda: d(s_in)), timed(lambda: d(s_out))
         # ---- transfers: bytes per peer link of the halo all-to-all (rows of this rank's need mask owned by each peer)
-        per_peer = [int(((halo >= b0) & (halo < b1)).sum()) * ld * 4 for (b0, b1) in distributed.all_shard_bounds(C, N)]
+        per_peer = [int(((halo >= b0) & (halo < b1)).sum()) * ld * ES for (b0, b1) in distributed.all_shard_bounds(C, N)]
         t_halo = (max(per_peer) / (LINK * EFF) + LAT) if N > 1 else 0.0
         t_ar = (2 * LAT + 3 * G * 8 / (LINK * EFF)) if N > 1 else 0.0                     # 720 KB: latency-bound
-        t_ag = (LAT + (C - nloc) * nr * 4 / (7 * LINK * EFF) * (7.0 / max(1, N - 1))) if N > 1 else 0.0     # (N - 1) peers over their own links
+        t_ag = (LAT + (C - nloc) * nr * ES / (7 * LINK * EFF) * (7.0 / max(1, N - 1))) if N > 1 else 0.0     # (N - 1) peers over their own links
         total = t_knn + t_pool + t_fit + t_ar * 1e3 + max(t_in, t_halo * 1e3) + t_out + t_ag * 1e3
         ranks.append({"rank": r, "cells": nloc, "halo_rows": n_halo, "interior_cells": int(inter.sum()), "cells_in_first_launch": int(s_in.numel()), "halo_bytes_per_peer": per_peer,
                       "ms": {"A_knn_search": t_knn, "A_pooling": t_pool, "B_fit_moments": t_fit, "B_all_reduce_model": t_ar * 1e3,

@@ -354,6 +354,7 @@ constexpr int GRP_NV = 6;
 constexpr int GRP_GC_DUAL = 6, GRP_NV_DUAL = 6;                 // dual control: three staged arrays per member -> 6 cells at the single kernel's chunk length
 constexpr int GRP_GC = 8;
 constexpr int GRP_GC_F64 = 6, GRP_NV_F64 = 8;                   // f64, single control: 6 cells, chunks of 8 vectors per lane (1024 genes)
+constexpr int GRP_GC_DUAL_F64 = 4;                              // f64, dual control: 4 cells at the same chunk length
 
 // dynamic LDS of one workgroup: staged rows, sort keys, per-pair accumulators, segment heads, scalars (also used by the host)
 template <typename T> __host__ __device__ inline size_t grouped_lds_bytes(int gc, int nv, bool dual, int64_t maxpairs, int npad)
@@ -835,9 +836,18 @@ static int launch_partial(const void *e, const void *d, const void *d2, const in
     if (rc) return rc;
     if (env_int("VCY_CDC_GROUP", GRP_GC) == GRP_GC) {            // VCY_CDC_GROUP=0: one cell per workgroup (A/B testing)
         bool done = false;
-        if (d2)
-            rc = launch_grouped<T, TR, RULES, GRP_GC_DUAL, GRP_NV_DUAL, true>(e, d, d2, ixs, out, out2, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st, fuse, dev, &done);
-        else if constexpr (sizeof(T) == 8)      // f64: 6 cells x 1024 genes (8 vectors per lane) measured 4.5 % faster than 8 x 768
+        if (d2) {
+            if constexpr (sizeof(T) == 8) {
+                // f64 dual control: 4 cells x 1024-gene chunks (three staged arrays of 8-byte elements: 96 KiB) - the single kernel's chunk
+                // length, hence its order of summation (real correlations bit-identical to the single launch) and its ratio of
+                // reduction work per element; 6 cells x 768 (VCY_CDC_DUAL_F64=0) shares rows better but pays 12-element chunks
+                if (env_int("VCY_CDC_DUAL_F64", 1) == 1)
+                    rc = launch_grouped<T, TR, RULES, GRP_GC_DUAL_F64, GRP_NV_F64, true>(e, d, d2, ixs, out, out2, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st, fuse, dev, &done);
+                else
+                    rc = launch_grouped<T, TR, RULES, GRP_GC_DUAL, GRP_NV_DUAL, true>(e, d, d2, ixs, out, out2, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st, fuse, dev, &done);
+            } else
+                rc = launch_grouped<T, TR, RULES, GRP_GC_DUAL, GRP_NV_DUAL, true>(e, d, d2, ixs, out, out2, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st, fuse, dev, &done);
+        } else if constexpr (sizeof(T) == 8)      // f64: 6 cells x 1024 genes (8 vectors per lane) measured 4.5 % faster than 8 x 768
             rc = launch_grouped<T, TR, RULES, GRP_GC_F64, GRP_NV_F64, false>(e, d, nullptr, ixs, out, nullptr, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st, fuse, dev, &done);
         else
             rc = launch_grouped<T, TR, RULES, GRP_GC, GRP_NV, false>(e, d, nullptr, ixs, out, nullptr, order, G, ld, cell0, C_out, d_row0, nrndm, psc, st, fuse, dev, &done);

@@ -693,6 +693,8 @@ extern "C" int vcy_gene_quantiles(const void *M, const void *M2, const double *s
         else if (reg && C <= 1024 * 16) VCY_QREG(double, 16);
         else if (reg && C <= 1024 * 24) VCY_QREG(double, 24);
         else if (reg && C <= 1024 * 32) VCY_QREG(double, 32);
+        else if (reg && C <= 1024 * 40) VCY_QREG(double, 40);
+        else if (reg && C <= 1024 * 50) VCY_QREG(double, 50);          // 100 of the 128 VGPRs a 1024-thread workgroup may use hold keys
         else hipLaunchKernelGGL(k_gene_quantiles<double>, dim3((unsigned)G), dim3(256), 0, st, (const double *)Z, qs_dev, nq, out, (int)C, (int)G, mask_mode != 0);
     }
     VCY_LAUNCH_CHECK();

@@ -202,6 +202,13 @@ __global__ __launch_bounds__(256) void k_knn_pool_counts(const CT *__restrict__ 
         // through LDS so that every store instruction covers a contiguous 1 KiB measured SLOWER - uint8 8.1 -> 10.1 ms,
         // uint16 10.9 -> 15.5 ms: the 64-byte lane stride already fills whole lines over a lane's four stores.)  Output rows are padded to a multiple of 64
         // elements, so a vector that starts inside a row ends inside it; elements past G are written as zeros.
+        // (Round 4, same experiment on the kernel as it is now, XOR-swizzled and conflict-free both ways: the ONE-neighbour floor
+        // drops - f32 4.3 -> 3.0 ms, f64 10.1 -> 5.5 ms for both layers - but the 31-neighbour kernel does not move, f32 8.02 -> 8.03,
+        // f64 13.8 -> 14.0 ms: with 31 gathers per output the stores hide behind the instruction stream.  Counters of the launch,
+        // profiles/r04_pool_pmc.txt: 8.0 resident waves per SIMD, a wave issues 14 % of its time, waits to issue 43 % and is
+        // parked at s_waitcnt 43 %; 1.5e9 VALU (2.1 per gathered element: v_cvt_f32_ubyte + half a v_pk_fma_f32) + 0.7e9 SALU
+        // (the 64-bit row addresses, 15 per neighbour) + 4.7e7 gathers per layer = 3.8 clocks per issued instruction and SIMD.
+        // Nontemporal stores: 8.0 -> 10.7 ms (f64: 13.8 -> 28 ms).)
         using OV = typename Vec<T>::type;
         constexpr int ON = Vec<T>::N;
         if (g0 + v * NE < ld_out) {
