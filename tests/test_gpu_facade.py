@@ -329,6 +329,30 @@ def test_facade_randomized_control_is_statistical(vcy, golden):
     assert vlm.corrcoef.shape == ref_knn.shape
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_facade_randomized_control_values_follow_from_the_permuted_matrix(vcy, golden, oracle, dtype):
+    """The shuffle of the randomised control cannot be value-pinned (the reference draws it from numba's RNG, analysis.py:2407-2420),
+    but everything DOWNSTREAM of the permuted matrix can: take the build's own delta_S_rndm and run the oracle's restatement of
+    analysis.py:1538-1607 and 1670-1733 on it with the same sampled neighbours - corrcoef_random, transition_prob_random,
+    delta_embedding_random and scaling_rndm must come out as the facade's dual-control launch and two-weight pooling produced them."""
+    g = golden("pipeline")
+    vlm = _prep_for_transition(vcy, g, dtype)
+    vlm.estimate_transition_prob(hidim="Sx_sz", embed="ts", transform="sqrt", n_neighbors=40, knn_random=True, sampled_fraction=0.5)
+    vlm.calculate_embedding_shift()
+    hi, dr = np.asarray(vlm.Sx_sz, dtype=np.float64), np.asarray(vlm.delta_S_rndm, dtype=np.float64)
+    neigh = vlm.embedding_knn.indices.reshape(hi.shape[1], -1)
+    cc_o, _ = oracle.estimate_transition_prob(hi, dr, vlm.embedding, used_delta_t=vlm.used_delta_t, transform="sqrt", neigh_ixs=neigh)
+    tol = TOL[dtype]["corr"]
+    np.testing.assert_allclose(vlm.corrcoef_random, cc_o, atol=tol)
+    tp_o, de_o, sc_o = oracle.calculate_embedding_shift(cc_o, neigh, vlm.embedding, hi_dim=hi, delta_S=dr)
+    f64 = dtype == "float64"
+    np.testing.assert_allclose(vlm.transition_prob_random, tp_o, rtol=1e-7 if f64 else 5e-2, atol=1e-12 if f64 else 1e-5)
+    np.testing.assert_allclose(vlm.delta_embedding_random, de_o, rtol=1e-7 if f64 else 5e-2, atol=1e-10 if f64 else 2e-4)
+    close(vlm.scaling_rndm, sc_o, 1e-7 if f64 else 5e-2, 1e-10 if f64 else 2e-4)
+    # and the real outputs of the same dual launch are the ones the golden pipeline pins
+    np.testing.assert_allclose(vlm.corrcoef, g["corrcoef_sqrt"], atol=tol)
+
+
 def test_estimation_module_api(vcy, golden):
     est = vcy.estimation
     g = golden("coldeltacor")

@@ -42,8 +42,9 @@ for C, G in shapes:
         name = "f64" if dt == torch.float64 else "f32"
         if only in ("", "gram"):
             ms, g = best(lambda: ops.gram(X, mean))
-            fl_sym, fl_full = float(C) * G * (G + 128), 2.0 * C * G * G           # multiply-adds done on the upper tiles x 2; the full product
-            line = f"gram   C {C:6d} G {G:6d} {name}: {ms:9.2f} ms  {2 * fl_sym / ms / 1e9:7.1f} Tflop/s executed = {2 * fl_sym / (ms * 1e-3) / PEAK:5.3f} of the f64 matrix peak; " \
+            nt = (G + 127) // 128
+            fl_exec, fl_full = 2.0 * C * (nt * (nt + 1) // 2) * 128 * 128, 2.0 * C * G * G       # flops on the upper-triangle tiles; of the full product
+            line = f"gram   C {C:6d} G {G:6d} {name}: {ms:9.2f} ms  {fl_exec / ms / 1e9:7.1f} Tflop/s executed = {fl_exec / (ms * 1e-3) / PEAK:5.3f} of the f64 matrix peak; " \
                    f"as a full product {fl_full / ms / 1e9:7.1f} Tflop/s"
             if G <= 12000 and not only:
                 ms_l, gl = best(lambda: library_gram(X, mean), 2)

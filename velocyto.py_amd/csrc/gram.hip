@@ -213,15 +213,30 @@ constexpr int GM_MEAN_BLOCKS = 64;
 
 static int gram_ksplit(int64_t ntile, int64_t C, int64_t Ga, int64_t Gb, int cus)
 {
-    // at least ~4 workgroups per CU slot pair, at least 1024 cells per split, partials within 2 GiB
-    int64_t want = (4LL * 2 * (cus > 0 ? cus : 256) + ntile - 1) / ntile;
+    // Two workgroups are resident per CU and every workgroup of a launch costs the same, so a launch runs in ROUNDS of 2 x CUs
+    // workgroups and its last round should be full: among the splits that leave at least 1024 cells per workgroup, keep the
+    // partial tiles within 2 GiB and give at most ~8 rounds, take the largest whose last round is at least 93 % full (else the
+    // fullest).  300 tiles (3000 genes) on 256 CUs: 5 splits = 2.93 rounds, where 7 splits were 4.1 rounds = 5 rounds of time.
+    const int64_t slots = 2LL * (cus > 0 ? cus : 256);
+    if (ntile >= 8 * slots) return 1;
+    int64_t kmax = (8 * slots + ntile - 1) / ntile;
     const int64_t by_cells = C / 1024 > 0 ? C / 1024 : 1;
-    if (want > by_cells) want = by_cells;
+    if (kmax > by_cells) kmax = by_cells;
     const int64_t by_mem = (int64_t)(2LL << 30) / (Ga * Gb * 8 > 0 ? Ga * Gb * 8 : 1);
-    if (want > by_mem) want = by_mem;
-    if (want < 1) want = 1;
-    if (ntile >= 4LL * 2 * (cus > 0 ? cus : 256)) want = 1;
-    return (int)want;
+    if (kmax > by_mem) kmax = by_mem;
+    if (kmax < 1) kmax = 1;
+    auto fill = [&](int64_t ks) {
+        const double rounds = (double)(ntile * ks) / (double)slots;
+        return rounds / (double)(int64_t)(rounds + 0.999999);
+    };
+    int64_t best = 1;
+    double best_fill = fill(1);
+    for (int64_t ks = 2; ks <= kmax; ++ks) {
+        const double f = fill(ks);
+        if (f >= 0.93) { best = ks; if (f > best_fill) best_fill = f; }           // the largest split with a full last round
+        else if (best_fill < 0.93 && f > best_fill) { best = ks; best_fill = f; }  // none so far: the fullest
+    }
+    return (int)best;
 }
 
 static inline int gram_tile_cols(int64_t Gb, bool sym) { return (!sym && Gb <= 64) ? 64 : 128; }
