@@ -58,7 +58,7 @@ typedef enum {
 typedef void *vcy_stream;  /* hipStream_t */
 
 const char *vcy_last_error(void);
-/* 2 (round 4).  History: 1 -> 2: vcy_diffuse_step_factored gained `int prepared` before compute_dtype; vcy_gram added;
+/* 2 (round 4).  History: 1 -> 2: vcy_diffuse_step_factored gained `int prepared` before compute_dtype; vcy_gram and vcy_embedding_scaling added;
  * vcy_knn_pool_csr requires >= 4 stored elements.  A binder refuses a library whose version it was not built against. */
 int vcy_abi_version(void);
 /* Number of CUs / LDS bytes per workgroup of the current device (host query). */
@@ -386,6 +386,20 @@ int vcy_transition_prob(const void *corr, const int32_t *ixs, const double *embe
                         double *delta_embedding, int64_t cell0, int64_t C_out, int64_t n, double sigma_corr, int dtype,
                         vcy_stream stream);
 int vcy_row_cosproj(const void *A, const void *B, double *out, int64_t C, int64_t G, int64_t ld, int dtype, vcy_stream stream);
+/* The expression scaling of calculate_embedding_shift in ONE launch and without the (genes, cells) estimates
+ * (analysis.py:1714-1719 and, with the *_rndm arguments, :1726-1731 for the randomised control):
+ *   estim[c, :]   = sum_k wdiff[c, k] * hi_dim[ixs[c, k], :]                     (hi_dim @ transition_prob.T - hi_dim @ (knn / n).T)
+ *   cos_proj[c]   = <delta_S[c, :], estim[c, :]> / |estim[c, :]|                 (0 / 0 = NaN as in the reference)
+ * hi_dim, delta_S[, delta_S_rndm]: (C, ld) cells-major of `dtype`; ixs, wdiff[, wdiff_rndm]: (C_out, n) - the outputs of
+ * vcy_transition_prob for the real [and the control] correlations over the same neighbour lists; order: schedule of the C_out
+ * cells (NULL = natural; results do not depend on it, cells adjacent in it share the gathers of their common neighbours);
+ * cos_proj[, cos_proj_rndm]: (C_out) fp64.  n <= vcy_embedding_scaling_max_neighbors() (256); wider lists return
+ * VCY_ERR_UNSUPPORTED and are handled by vcy_knn_pool_w2 + vcy_row_cosproj.  A member's neighbours are added in ascending
+ * cell number, the sums over genes in a fixed order: reproducible run to run.                                                    */
+int vcy_embedding_scaling_max_neighbors(void);
+int vcy_embedding_scaling(const void *hi_dim, const void *delta_S, const void *delta_S_rndm, const int32_t *ixs, const void *wdiff,
+                          const void *wdiff_rndm, const int32_t *order, double *cos_proj, double *cos_proj_rndm, int64_t C, int64_t G,
+                          int64_t ld, int64_t C_out, int64_t n, int dtype, vcy_stream stream);
 
 /* ---------------------------------------------------------------- stage F: prepare_markov
  * VelocytoLoom.prepare_markov (analysis.py:1818-1863) with cells_ixs=None: dense (n, n) Markov

@@ -1109,3 +1109,54 @@ def test_f64_sqrt_element_accuracy_and_domain(ops, oracle):
     with pytest.raises(ValueError, match="outside the supported range"):
         ops.partial_rules_for(E, ops.SQRT, 1e-10)
     ops.coldeltacor_partial(E, Dm, ixs, ops.LINEAR, ops.RULES_PARTIAL, 0.0)                  # other transforms have no such limit
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("C,G,n", [(9, 70, 3), (100, 1003, 17), (333, 4100, 64), (70, 515, 256)])
+def test_embedding_scaling_against_the_two_step_route(ops, dtype, C, G, n):
+    """vcy_embedding_scaling (calculate_embedding_shift's expression scaling, analysis.py:1714-1719, 1726-1731, in one launch with the
+    (genes, cells) estimates kept in registers) against (1) numpy in fp64 on the stored values and (2) the two-step route it replaces
+    (vcy_knn_pool_w2 + vcy_row_cosproj): ragged last group, repeated neighbours in a list, a cell that lists itself, a zero estimate
+    (NaN, like the reference's 0 / 0), single and dual control, natural and permuted schedules (same numbers), run-to-run identical."""
+    rng = np.random.default_rng(C + n)
+    tdt = getattr(torch, dtype)
+    hi = ops.CellMatrix.from_genes_major(rng.gamma(1.0, 2.0, (G, C)), dtype)
+    dS = ops.CellMatrix.from_genes_major(rng.normal(size=(G, C)), dtype)
+    dR = ops.CellMatrix.from_genes_major(rng.normal(size=(G, C)), dtype)
+    ixs = np.stack([rng.choice(C, n, replace=n > C) for _ in range(C)]).astype(np.int32)
+    ixs[0, :min(n, 2)] = 0                                    # a repeated neighbour, and the cell itself
+    w = rng.normal(size=(C, n)) * 0.1
+    w2 = rng.normal(size=(C, n)) * 0.1
+    w[1] = 0.0                                                # estim of cell 1 is exactly zero -> 0 / 0
+    dev = hi.t.device
+    W, W2 = torch.as_tensor(w, device=dev).to(tdt), torch.as_tensor(w2, device=dev).to(tdt)
+    cos, cos2 = ops.embedding_scaling(hi, dS, ixs, W, dR, W2)
+    Hs, Ds, Rs = hi.to_genes_major().T, dS.to_genes_major().T, dR.to_genes_major().T             # stored values, (C, G) fp64
+    for got, ww, dd, zero_row in ((cos, W.double().cpu().numpy(), Ds, True), (cos2, W2.double().cpu().numpy(), Rs, False)):
+        est = np.einsum("ck,ckg->cg", ww, Hs[ixs])
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ref = (dd * est).sum(1) / np.sqrt((est ** 2).sum(1))
+        g = got.cpu().numpy()
+        assert bool(np.isnan(ref[1])) == zero_row and np.array_equal(np.isnan(g), np.isnan(ref))
+        ok = ~np.isnan(ref)
+        np.testing.assert_allclose(g[ok], ref[ok], rtol=1e-10 if dtype == "float64" else 2e-4, atol=1e-12 if dtype == "float64" else 2e-5)
+    # the route it replaces
+    indptr = torch.arange(0, (C + 1) * n, n, dtype=torch.int64, device=dev)
+    e1, e2 = ops.knn_pool_w2(hi, indptr, ixs.reshape(-1), W.reshape(-1), W2.reshape(-1))
+    old1, old2 = ops.row_cosproj(dS, e1).cpu().numpy(), ops.row_cosproj(dR, e2).cpu().numpy()
+    tol = dict(rtol=1e-10, atol=1e-12) if dtype == "float64" else dict(rtol=2e-4, atol=2e-5)
+    ok = ~np.isnan(old1)
+    np.testing.assert_allclose(cos.cpu().numpy()[ok], old1[ok], **tol)
+    np.testing.assert_allclose(cos2.cpu().numpy(), old2, **tol)
+    # single control, a permuted schedule, determinism
+    (c_single,) = ops.embedding_scaling(hi, dS, ixs, W)
+    assert torch.equal(torch.nan_to_num(c_single, nan=7.0), torch.nan_to_num(cos, nan=7.0))
+    perm = torch.as_tensor(rng.permutation(C).astype(np.int32), device=dev)
+    c_perm, c2_perm = ops.embedding_scaling(hi, dS, ixs, W, dR, W2, order=perm)
+    np.testing.assert_allclose(torch.nan_to_num(c_perm, nan=7.0).cpu().numpy(), torch.nan_to_num(cos, nan=7.0).cpu().numpy(), **tol)
+    again = ops.embedding_scaling(hi, dS, ixs, W, dR, W2, order=perm)
+    assert torch.equal(torch.nan_to_num(again[0], nan=7.0), torch.nan_to_num(c_perm, nan=7.0)) and torch.equal(again[1], c2_perm)
+    # lists wider than one workgroup sorts: the caller is told to take the two-step route
+    if n == 256:
+        wide = np.concatenate([ixs, ixs[:, :1]], 1)
+        assert ops.embedding_scaling(hi, dS, wide, torch.zeros((C, n + 1), dtype=tdt, device=dev)) is None

@@ -91,6 +91,8 @@ SIGNATURES = {
     "vcy_corr_fixup": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_dbl, c_vp, c_int, c_vp]),
     "vcy_transition_prob": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_dbl, c_int, c_vp]),
     "vcy_row_cosproj": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]),
+    "vcy_embedding_scaling_max_neighbors": (c_int, []),
+    "vcy_embedding_scaling": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_vp]),
     "vcy_diffuse_workspace_bytes": (c_sz, [c_i64]),
     "vcy_diffuse_step_dense": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),
     "vcy_diffuse_step_csc": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),

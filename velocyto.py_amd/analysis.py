@@ -735,16 +735,21 @@ class VelocytoLoom(PreprocessMixin):
             parts.append(ops.transition_prob(c.contiguous(), neigh, self.embedding, sigma_corr))       # (tp, P - knn/n, delta_embedding)
         scalings = [None] * len(names)
         if expression_scaling:
-            # hi_dim @ (P - knn/n).T (:1716, and :1728 for the control): both products gather the same rows of hi_dim
-            indptr = torch.arange(0, (neigh.shape[0] + 1) * n, n, dtype=torch.int64, device=dev)
-            if len(names) == 2:
-                estims = ops.knn_pool_w2(hi, indptr, neigh.reshape(-1), parts[0][1].reshape(-1), parts[1][1].reshape(-1), validate=False, order=order)
-            else:
-                estims = (ops.knn_pool(hi, indptr, neigh.reshape(-1), parts[0][1].reshape(-1), validate=False, order=order),)
-            for i, (_, dS_name) in enumerate(names):
-                cos_proj = ops.row_cosproj(self.dev(dS_name), estims[i])                                 # :1717
-                scalings[i] = torch.clamp(cos_proj / scaling_penalty, 0, 1)                              # NaN stays NaN, like np.clip
-            del estims
+            # hi_dim @ (P - knn/n).T (:1716, and :1728 for the control) and the cosine projection of :1717 / :1729.  One launch
+            # (vcy_embedding_scaling): groups of schedule-adjacent cells gather the rows of their common neighbours once, the
+            # (genes, cells) estimates stay in registers.  Lists wider than it sorts in one workgroup take the two-step route.
+            dS_r = self.dev(names[1][1]) if len(names) == 2 else None
+            cos = ops.embedding_scaling(hi, self.dev(names[0][1]), neigh, parts[0][1], dS_r, parts[1][1] if len(names) == 2 else None, order=order)
+            if cos is None:
+                indptr = torch.arange(0, (neigh.shape[0] + 1) * n, n, dtype=torch.int64, device=dev)
+                if len(names) == 2:
+                    estims = ops.knn_pool_w2(hi, indptr, neigh.reshape(-1), parts[0][1].reshape(-1), parts[1][1].reshape(-1), validate=False, order=order)
+                else:
+                    estims = (ops.knn_pool(hi, indptr, neigh.reshape(-1), parts[0][1].reshape(-1), validate=False, order=order),)
+                cos = [ops.row_cosproj(self.dev(dS_name), estims[i]) for i, (_, dS_name) in enumerate(names)]                # :1717
+                del estims
+            for i in range(len(names)):
+                scalings[i] = torch.clamp(cos[i] / scaling_penalty, 0, 1)                              # NaN stays NaN, like np.clip
         res = [(tp, de if sc is None else de * sc[:, None], sc) for (tp, _, de), sc in zip(parts, scalings)]
 
         tp, de, sc = res[0]

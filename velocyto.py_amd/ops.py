@@ -1481,6 +1481,34 @@ def row_cosproj(A: CellMatrix, B: CellMatrix) -> torch.Tensor:
     return out
 
 
+def embedding_scaling(hi: CellMatrix, dS: CellMatrix, ixs, wdiff: torch.Tensor, dS_rndm: Optional[CellMatrix] = None,
+                      wdiff_rndm: Optional[torch.Tensor] = None, order: Optional[torch.Tensor] = None):
+    """cos_proj (C_out) fp64 [and the control's] of calculate_embedding_shift's expression scaling (analysis.py:1714-1719, 1726-1731) in one
+    launch, the (genes, cells) estimates never written (vcy_embedding_scaling).  Returns None when the neighbour lists are wider than
+    the kernel sorts in one workgroup - the caller then pools with knn_pool[_w2] + row_cosproj."""
+    dev = hi.t.device
+    ix = _as_i32(ixs, dev)
+    C_out, n = ix.shape
+    L = _lib.lib()
+    if n > int(L.vcy_embedding_scaling_max_neighbors()) or n == 0 or C_out == 0:
+        return None
+    assert dS.t.shape == hi.t.shape and dS.dtype == hi.dtype and C_out <= hi.C
+    w = wdiff.to(device=dev, dtype=hi.dtype).contiguous()
+    assert tuple(w.shape) == (C_out, n)
+    dual = dS_rndm is not None
+    w2 = None
+    if dual:
+        assert wdiff_rndm is not None and dS_rndm.t.shape == hi.t.shape and dS_rndm.dtype == hi.dtype
+        w2 = wdiff_rndm.to(device=dev, dtype=hi.dtype).contiguous()
+    cos = torch.empty(C_out, dtype=torch.float64, device=dev)
+    cos2 = torch.empty(C_out, dtype=torch.float64, device=dev) if dual else None
+    order, n_sched = _sched(order, dev, C_out)
+    assert n_sched == C_out, "embedding_scaling: the schedule must cover every cell"
+    _lib.check(L.vcy_embedding_scaling(hi.t.data_ptr(), dS.t.data_ptr(), None if not dual else dS_rndm.t.data_ptr(), ix.data_ptr(), w.data_ptr(),
+                                       _p(w2), _p(order), cos.data_ptr(), _p(cos2), hi.C, hi.G, hi.ld, C_out, n, hi.code, _stream()), "embedding_scaling")
+    return (cos, cos2) if dual else (cos,)
+
+
 def _run_steps(step, x: torch.Tensor, y: torch.Tensor, n_steps: int) -> torch.Tensor:
     """n_steps of step(src, dst) ping-ponging between x and y; returns the buffer that holds the last iterate.  Long loops are
     launch-bound (a few tiny kernels per step, thousands of steps): an x -> y -> x pair of steps is captured into a hipGraph once
