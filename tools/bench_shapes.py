@@ -10,9 +10,14 @@ import bench
 
 dev = ops.require_gpu()
 C, G = int(os.environ.get("C", 50000)), int(os.environ.get("G", 30000))
+DT = torch.float64 if os.environ.get("DTYPE", "f32") == "f64" else torch.float32
 S, U, pcs = bench.synth(C, G, 30, dev)
+del U
+if DT == torch.float64:
+    S = ops.CellMatrix(S.t.double(), G)
 emb = pcs[:, :2].contiguous()
 d = ops.CellMatrix(torch.randn_like(S.t), G)
+print("storage:", os.environ.get("DTYPE", "f32"))
 rules = ops.partial_rules_for(S, ops.SQRT, 1e-10)
 print("rule:", ops.RULE_NAMES[rules])
 
@@ -28,12 +33,12 @@ neigh, _ = bench.sample_neighbors_device(emb, 500, 0.5, dev)
 perm = ops.hilbert_order(emb).long()                     # a rank's cells are a contiguous piece of the curve
 for n in (C // 8, C // 4, C // 2, C):
     cells = perm[:n].to(torch.int32).contiguous()        # schedule over a subset: only those rows are written
-    out = torch.empty((C, neigh.shape[1]), dtype=torch.float32, device=dev)
+    out = torch.empty((C, neigh.shape[1]), dtype=DT, device=dev)
     ms = best(lambda: ops.coldeltacor_partial(S, d, neigh, ops.SQRT, rules, 1e-10, order=cells, out=out, validate=False))
     print(f"nrndm {neigh.shape[1]:5d}  cells {n:6d}  {ms:8.2f} ms  {ms / n * 1e3:6.3f} us per cell")
 if not os.environ.get("SKIP_WIDE"):
     wide, _ = bench.sample_neighbors_device(emb, C // 5, 0.3, dev)
-    out = torch.empty((C, wide.shape[1]), dtype=torch.float32, device=dev)
+    out = torch.empty((C, wide.shape[1]), dtype=DT, device=dev)
     order = ops.hilbert_order(emb)
     ms = best(lambda: ops.coldeltacor_partial(S, d, wide, ops.SQRT, rules, 1e-10, order=order, out=out, validate=False), reps=2)
     print(f"nrndm {wide.shape[1]:5d}  cells {C:6d}  {ms:8.2f} ms  {ms / C * 1e3:6.3f} us per cell")

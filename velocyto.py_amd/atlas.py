@@ -366,12 +366,12 @@ def size_factors(totS: torch.Tensor, totU: torch.Tensor, C: int) -> Tuple[torch.
     return (sums[0] / C) / totS.clamp(min=1.0), (sums[1] / C) / totU.clamp(min=1.0)
 
 
-def auto_block_cells(nloc: int, C: int, G: int, dev) -> int:
-    """Cells per streamed block chosen from the free HBM: as many as fit beside the CSR layers - a block holds ~2.6 dense f32
-    rows per cell (Sx + the e rows it reads outside itself, Ux); the kNN workspace of 8192 queries x C distances and 6 GB of
-    headroom stay free.  On 288 GB: 1M cells x 30k genes walk in three blocks of ~366 000 cells."""
+def auto_block_cells(nloc: int, C: int, G: int, dev, elem_bytes: int = 4) -> int:
+    """Cells per streamed block chosen from the free HBM: as many as fit beside the CSR layers - a block holds ~2.6 dense
+    rows per cell (Sx + the e rows it reads outside itself, Ux) of `elem_bytes` per element; the kNN workspace of 8192 queries x C
+    distances and 6 GB of headroom stay free.  On 288 GB: 1M cells x 30k genes walk in three blocks of ~366 000 cells in f32."""
     free = torch.cuda.mem_get_info(dev)[0] - 8192 * C * 4 - (6 << 30)
-    return int(max(4096, min(nloc, free * 0.6 // (2.6 * ops.padded_ld(G) * 4))))
+    return int(max(4096, min(nloc, free * 0.6 // (2.6 * ops.padded_ld(G) * elem_bytes))))
 
 
 def bench_main(a, dev, rank: int, world: int) -> Optional[dict]:
@@ -382,9 +382,11 @@ def bench_main(a, dev, rank: int, world: int) -> Optional[dict]:
     cS, cU, totS, totU, pcs, emb = synth_atlas(C, G, a.pca_dims, dev, density=a.density, c0=c0, c1=c1)
     fS, fU = size_factors(totS, totU, C)
     nloc = c1 - c0
-    block = a.block_cells if a.block_cells > 0 else auto_block_cells(nloc, C, G, dev)
+    dt_name = getattr(a, "dtype", "f32")                 # bench.py --dtype: f64 = the reference's arithmetic (the default), f32 = production mode
+    tdt = torch.float64 if dt_name == "f64" else torch.float32
+    block = a.block_cells if a.block_cells > 0 else auto_block_cells(nloc, C, G, dev, 8 if dt_name == "f64" else 4)
     path = AtlasPath(cS, cU, fS, fU, pcs, emb, c0=c0, C_total=C, k=a.k, n_neighbors=a.n_neighbors, sampled_fraction=a.sampled_fraction,
-                     block_cells=block, dtype=torch.float32, knn=getattr(a, "knn", "auto"))
+                     block_cells=block, dtype=tdt, knn=getattr(a, "knn", "auto"))
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
     for _ in range(a.warmup):
@@ -417,11 +419,11 @@ def bench_main(a, dev, rank: int, world: int) -> Optional[dict]:
     st = path.stage_ms / a.steps
     nnz = cS.nnz / max(1, nloc)
     plan_1m = memory_plan(1_000_000, G, nnz, 8, 0, nrndm=path.nrndm, k=a.k, count_bytes=cS.data.element_size(),
-                          halo_e=path.n_e_halo / nloc, halo_k=path.n_count_halo / nloc)
+                          elem_bytes=8 if dt_name == "f64" else 4, halo_e=path.n_e_halo / nloc, halo_k=path.n_count_halo / nloc)
     return {
         "metric": f"cells/sec through knn_imputation->fit_slope->colDeltaCor, {C} cells x {G} genes (cfg5: CSR layers, streamed blocks)",
         "value": C / (ms * 1e-3), "unit": "cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dt_name, "data": "synthetic",
         "rccl_ranks": dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0,
         "config": {"workload": f"cfg5 (BASELINE.json configs[4], scaled to what one run holds): synthetic {C} cells x {G} genes, CSR count layers at "
                                f"{100.0 * cS.nnz / max(1, nloc) / G:.1f} % density ({nnz:.0f} non-zeros per cell, {'uint8' if cS.data.dtype == torch.uint8 else 'uint16'} counts), "
