@@ -61,10 +61,10 @@ VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
 #   2 pseudocount dropped (VCY_RULES_PARTIAL_NOPSC, f32): v_sub, v_rsq_f32, v_mul_legacy_f32, v_add, two v_fmac -
 #     "cdc no-psc element" 3.89 clocks x 6 instructions (the parts alone sum to 19.8: a transcendental between plain ops costs more)
 MIX_CLK_PER_ELEMENT = {1: 27.7, 2: 23.3}
-# f64 (the reference's arithmetic): literal element = v_add_f64 (sub), v_add_f64 (|t| + psc), v_cvt_f32_f64, v_rsq_f32, v_mul_f32, 2 x v_cvt_f64_f32,
-# v_mul_f64, 4 x v_fma_f64 (square root), v_cmp_lt_f64 + v_cndmask / v_bfi (zero rule, sign), v_add_f64 + 2 x v_fma_f64 (moments): measured as a
-# mix by tools/ubench/valu_issue_f64.hip (profiles/r03_valu_issue_f64.txt: "f64 element, f32 seed + 1 step + 1 correction", wall-clock column)
-MIX_CLK_PER_ELEMENT_F64 = 83.8
+# f64 (the reference's arithmetic): literal element = v_add_f64 (sub), v_add_f64 (|t| + psc), v_cvt_f32_f64, v_rsq_f32, v_mul_f32 (the 24-bit seed), 2 x v_cvt_f64_f32,
+# v_add_u32 (h = y / 2), 4 x v_fma_f64 (two Newton corrections), v_cmp_lt_f64 + 2 x v_cndmask (zero rule), v_bfi (sign), v_add_f64 + 2 x v_fma_f64 (moments): measured as a
+# mix by tools/ubench/valu_issue_f64.hip (profiles/r04_valu_issue_f64.txt: "f64 element, f32 product seed + 2 Newton corrections (round 4)", wall-clock column)
+MIX_CLK_PER_ELEMENT_F64 = 83.2
 F64_ISSUE_CLK = 4.1               # clocks per wave64 v_add_f64 / v_mul_f64 / v_fma_f64 per SIMD (same file): the f64 issue peak is 1 instruction / 4 clocks
 COUNTERS_FILE = os.path.join(ROOT, "profiles", "r04_cdc_counters.json")     # written by tools/summarize_profiles.py from the rocprofv3 passes
 COUNTERS_FALLBACK = os.path.join(ROOT, "profiles", "r03_cdc_counters.json")
@@ -85,7 +85,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass of THIS command; without it "
-                         "the figure recorded for the default workload in profiles/r02_cdc_counters.json is reported (named in "
+                         "the figure recorded for the default workload in profiles/r04_cdc_counters.json is reported (named in "
                          "roofline.counters_from), null for any other workload")
     ap.add_argument("--workload", choices=["cfg3", "cfg5"], default="cfg3",
                     help="cfg3: dense count layers, everything resident (the headline); cfg5: CSR layers, block-streamed (atlas.py)")
@@ -515,7 +515,7 @@ def dominant_roofline(a, pipe, d_ms, dtype):
             "branch_rule": rule_name, "dtype": dtype,
             "unit": "Ginstr/s", "peak": VALU_ISSUE_PEAK / 1e9, "avg_launch_ms": d_ms,
             "peak_is": "VALU issue: 1024 SIMD-32 x 2.4 GHz / 2 clocks per wave64 instruction (MI355X_MICROARCH.md); f32 plain ops measure 2.25 clocks" +
-                       (f", f64 add / mul / fma {F64_ISSUE_CLK} (profiles/r03_valu_issue_f64.txt) - see frac_of_f64_issue_peak" if s == 8 else "")}
+                       (f", f64 add / mul / fma {F64_ISSUE_CLK} (profiles/r04_valu_issue_f64.txt) - see frac_of_f64_issue_peak" if s == 8 else "")}
     if instr is not None:
         achieved = instr * pair_chunks / (d_ms * 1e-3)
         roof.update({"achieved": achieved / 1e9, "frac": achieved / VALU_ISSUE_PEAK,
