@@ -208,3 +208,28 @@ def test_array_valued_root_attributes(loom_io, tmp_path):
     np.testing.assert_array_equal(fa["big_float_array"], vals)
     np.testing.assert_array_equal(fa["int_matrix"], ints)
     assert list(fa["fixed_strings"]) == ["alpha", "be", "gamma!"]
+
+
+def test_serialization_container_of_any_object(loom_io, tmp_path):
+    """serialization.dump_hdf5 (serialization.py:44-97) walks the attributes of ANY object: numeric arrays become datasets of their
+    own name, everything else a pickled + zlib-compressed uint8 dataset "&name" (the reference's container format); exclusion,
+    compression and pickle protocol are honoured.  (load_hdf5 instantiates a VelocytoLoom and needs the device: GPU suite.)"""
+    import types
+    from scipy import sparse
+    from velocyto_amd import serialization
+    rng = np.random.default_rng(5)
+    obj = types.SimpleNamespace(mat=rng.normal(size=(40, 70)), vec=np.arange(9, dtype=np.int64), mask=rng.random(12) > 0.5,
+                                names=np.array(["a", "bc", "def"]), ca={"CellID": np.arange(3)}, knn=sparse.random(8, 8, 0.3, format="csr", random_state=1),
+                                note="hello", skipped=np.ones(3))
+    path = str(tmp_path / "any.hdf5")
+    serialization.dump_hdf5(obj, path, data_compression=4, chunks=(16, 16), pickle_protocol=4, exclude_attributes=["skipped"])
+    raw = loom_io.hdf5_load(path)
+    assert set(raw) == {"mat", "vec", "mask", "&names", "&ca", "&knn", "&note"}
+    np.testing.assert_array_equal(raw["mat"], obj.mat)
+    np.testing.assert_array_equal(raw["vec"], obj.vec)
+    assert raw["mask"].dtype == np.bool_ and np.array_equal(raw["mask"], obj.mask)
+    assert raw["&note"].dtype == np.uint8 and serialization._uint2obj(raw["&note"]) == "hello"
+    assert list(serialization._uint2obj(raw["&names"])) == ["a", "bc", "def"]
+    assert (serialization._uint2obj(raw["&knn"]) != obj.knn).nnz == 0
+    assert np.array_equal(serialization._uint2obj(raw["&ca"])["CellID"], np.arange(3))
+    assert serialization._uint2obj(serialization._obj2uint({"x": 1}, compression=1, protocol=2)) == {"x": 1}

@@ -873,41 +873,45 @@ class VelocytoLoom(PreprocessMixin):
 
     # ------------------------------------------------------------------ bookkeeping kept from the reference
     def to_hdf5(self, filename: str, **kwargs) -> None:
-        """analysis.py:76-94 + serialization.dump_hdf5 (serialization.py:44-92): checkpoint of the whole object.
-        Every ndarray attribute (device matrices are downloaded) becomes a dataset under its name, everything else is
-        pickled (protocol 2) + zlib-compressed into a uint8 dataset called "&name" - the reference's container format
-        (written uncompressed here; `load_velocyto_hdf5` reads both)."""
-        from .loom_io import hdf5_dump
-        from .serialization import _obj2uint
-        exclude = set(kwargs.get("exclude", ()) or ())
-        noarray_compression, protocol = int(kwargs.get("noarray_compression", 9)), int(kwargs.get("pickle_protocol", 2))
-        out = {}
+        """analysis.py:76-94: checkpoint of the whole object through serialization.dump_hdf5 (keyword arguments are handed on:
+        data_compression, chunks, noarray_compression, pickle_protocol, exclude_attributes)."""
+        from .serialization import dump_hdf5
+        if "exclude" in kwargs:                                       # round-3 spelling
+            kwargs["exclude_attributes"] = kwargs.pop("exclude")
+        kwargs.setdefault("data_compression", 0)                      # (the reference's default of 7 costs minutes at 50 000 x 30 000)
+        dump_hdf5(self, filename, **kwargs)
+
+    def _export_state(self, exclude) -> Dict[str, Any]:
+        """What a checkpoint holds for this object, as {attribute name: host value} (serialization.dump_hdf5 asks for it): the
+        device matrices downloaded under their names as the reference's (genes, cells) float64 arrays, the pooling graph's scipy
+        containers (assembled now if they still live on the device only), the plain attributes, and - where the reference
+        persists dense (cells, cells) corrcoef / transition_prob, 20 GB each at 50 000 cells - the compact neighbour-list
+        state under public names with the settings of the velocity chain."""
+        out: Dict[str, Any] = {}
         for name in self._dev:
             if name not in exclude:
                 out[name] = np.ascontiguousarray(getattr(self, name))
-        for lazy_name in _LAZY_GRAPH:                                 # the pooling graph's scipy containers, if still only on the device
+        for lazy_name in _LAZY_GRAPH:
             if lazy_name not in exclude:
                 getattr(self, lazy_name, None)
         items = dict(self.__dict__)
         if "_neigh" in items and "embedding_knn" not in exclude:
-            items["embedding_knn"] = self.embedding_knn               # assembled on demand; a plain attribute in the reference
-        # what the reference persists as the dense (cells, cells) corrcoef / transition_prob (20 GB each at 50k cells) is kept
-        # in its compact neighbour-list form, under public names, together with the settings of the velocity chain
+            out["embedding_knn"] = self.embedding_knn                 # assembled on demand; a plain attribute in the reference
         for key, pub in _COMPACT_STATE.items():
             if key in items and pub not in exclude:
                 out[pub] = items[key].cpu().numpy()
         chain = {k: items[k] for k in _CHAIN_SETTINGS if k in items}
         if chain:
-            items["chain_settings"] = chain
+            out["chain_settings"] = chain
         for name, val in items.items():
             if name.startswith("_") or name in exclude or isinstance(val, torch.Tensor):
                 continue                                              # device-side caches are rebuilt on demand
-            if isinstance(val, np.ndarray) and val.dtype.kind in "fiub":
-                out[name] = val
-            else:
-                out["&" + name] = _obj2uint(val, compression=noarray_compression, protocol=protocol)
-        hdf5_dump(filename, out, compression=int(kwargs.get("data_compression", 0)), chunks=tuple(kwargs.get("chunks", (2048, 2048))))
+            out[name] = val
+        return out
 
+    def _import_state(self) -> None:
+        """After serialization.load_hdf5 has set the attributes of a checkpoint: rebuild the device-side state."""
+        _restore_device_state(self)
 
     def reload_raw(self, substitute: bool = False) -> None:
         """analysis.py:2314-2342: read the layers of ``loom_filepath`` again, either over S, U, A, ca, ra (substitute) or
@@ -1017,18 +1021,7 @@ def _restore_device_state(vlm: "VelocytoLoom") -> None:
 
 
 def load_velocyto_hdf5(filename: str, dtype=None, obj_class: type = None) -> VelocytoLoom:
-    """analysis.py:2454-2470 + serialization.load_hdf5 (serialization.py:95-115): rebuild a VelocytoLoom from a
-    checkpoint written by `to_hdf5` (or by the reference's dump_hdf5: same layout)."""
-    import pickle
-    import zlib
-    from .loom_io import hdf5_load
-    if obj_class is not None and not (isinstance(obj_class, type) and issubclass(obj_class, VelocytoLoom)):
-        raise TypeError("obj_class must be VelocytoLoom or a subclass of it")
-    vlm = (obj_class or VelocytoLoom)(None, dtype=dtype)
-    for name, arr in hdf5_load(filename).items():
-        if name.startswith("&"):
-            setattr(vlm, name[1:], pickle.loads(zlib.decompress(np.asarray(arr, dtype=np.uint8).tobytes())))
-        else:
-            setattr(vlm, name, arr)
-    _restore_device_state(vlm)
-    return vlm
+    """analysis.py:2454-2470: rebuild a VelocytoLoom from a checkpoint written by `to_hdf5` (or by the reference's dump_hdf5:
+    same layout) through serialization.load_hdf5."""
+    from .serialization import load_hdf5
+    return load_hdf5(filename, obj_class=obj_class, dtype=dtype)

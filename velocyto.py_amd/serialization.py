@@ -1,11 +1,18 @@
-"""``velocyto/serialization.py`` call surface: ``dump_hdf5`` / ``load_hdf5`` (serialization.py:44-115) on top of the
-ctypes-bound libhdf5 of ``loom_io`` (no h5py in the image).  Device matrices are written as the reference's
-(genes, cells) float64 datasets, so files round-trip between the two implementations."""
+"""``velocyto/serialization.py``: the checkpoint container of a VelocytoLoom (serialization.py:9-115), on top of the ctypes-bound
+libhdf5 of ``loom_io`` (no h5py in the image).
+
+Format, as the reference writes it: one HDF5 dataset per attribute - numeric ndarrays under their own name (2-d ones chunked and
+gzip-compressed when asked), every other object pickled (`pickle_protocol`, default 2), zlib-compressed (`noarray_compression`)
+and stored as a uint8 dataset called ``"&" + name`` (`_obj2uint` / `_uint2obj`).  ``dump_hdf5`` walks the attributes of ANY object;
+an object that keeps part of its state elsewhere - this package's VelocytoLoom: device matrices, compact neighbour-list results -
+says what to write through ``_export_state(exclude)`` and rebuilds what it needs through ``_import_state()`` after ``load_hdf5``
+has set the attributes.  Device matrices go out as the reference's (genes, cells) float64 arrays, so files round-trip between the
+two implementations."""
 from __future__ import annotations
 
 import pickle
 import zlib
-from typing import Any
+from typing import Any, Dict, Iterable, Optional
 
 import numpy as np
 
@@ -22,16 +29,44 @@ def _uint2obj(uint: np.ndarray) -> object:
     return pickle.loads(zlib.decompress(np.asarray(uint, dtype=np.uint8).tobytes()))
 
 
+def _is_plain_array(val: Any) -> bool:
+    """What goes into a dataset of its own: numeric / boolean ndarrays (the reference tests `type(v) is np.ndarray` and lets h5py
+    refuse object arrays; strings and object arrays are pickled here like any other object)."""
+    return isinstance(val, np.ndarray) and val.dtype.kind in "fiub"
+
+
 def dump_hdf5(obj: Any, filename: str, data_compression: int = 7, chunks=(2048, 2048), noarray_compression: int = 9, pickle_protocol: int = 2,
-              exclude_attributes=None) -> None:
-    """serialization.py:44-97 for a VelocytoLoom of this package: 2-d datasets chunked + gzip (`data_compression`, `chunks`),
-    everything that is not an array pickled with `pickle_protocol` and zlib level `noarray_compression`
-    (`exclude_attributes` is an extension)."""
-    obj.to_hdf5(filename, exclude=set(exclude_attributes or ()), data_compression=data_compression, chunks=chunks,
-                noarray_compression=noarray_compression, pickle_protocol=pickle_protocol)
+              exclude_attributes: Optional[Iterable[str]] = None) -> None:
+    """serialization.py:44-97: every attribute of `obj` into one HDF5 file.  2-d datasets chunked + gzip (`data_compression`,
+    `chunks`; 0 = stored as they are), everything that is not a numeric array pickled with `pickle_protocol` and zlib level
+    `noarray_compression` under "&name".  `exclude_attributes` (an extension) leaves attributes out."""
+    from .loom_io import hdf5_dump
+    exclude = set(exclude_attributes or ())
+    state: Dict[str, Any] = obj._export_state(exclude) if hasattr(obj, "_export_state") else \
+        {k: v for k, v in vars(obj).items() if k not in exclude}
+    out: Dict[str, np.ndarray] = {}
+    for name, val in state.items():
+        if _is_plain_array(val):
+            out[name] = val
+        else:
+            out["&" + name] = _obj2uint(val, compression=int(noarray_compression), protocol=int(pickle_protocol))
+    hdf5_dump(filename, out, compression=int(data_compression), chunks=tuple(chunks))
 
 
 def load_hdf5(filename: str, obj_class: type = None, dtype=None):
-    """serialization.py:100-115: `obj_class` (VelocytoLoom or a subclass) is the class that is instantiated."""
-    from .analysis import load_velocyto_hdf5
-    return load_velocyto_hdf5(filename, dtype=dtype, obj_class=obj_class)
+    """serialization.py:100-115: an instance of `obj_class` (default: this package's VelocytoLoom; it must be that class or a
+    subclass of it, as the reference asks for `vcy.VelocytoLoom`) with every dataset of the file set as an attribute - "&name"
+    datasets decoded back into the objects they held.  `dtype` (an extension) is the device storage type of the new object."""
+    from .analysis import VelocytoLoom
+    from .loom_io import hdf5_load
+    if obj_class is not None and not (isinstance(obj_class, type) and issubclass(obj_class, VelocytoLoom)):
+        raise TypeError("obj_class must be VelocytoLoom or a subclass of it")
+    obj = (obj_class or VelocytoLoom)(None, dtype=dtype)
+    for name, arr in hdf5_load(filename).items():
+        if name.startswith("&"):
+            setattr(obj, name[1:], _uint2obj(arr))
+        else:
+            setattr(obj, name, arr)
+    if hasattr(obj, "_import_state"):
+        obj._import_state()
+    return obj
