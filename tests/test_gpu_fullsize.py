@@ -504,3 +504,68 @@ def test_fullsize_stage_d_reference_default_list_width_against_the_oracle(world,
         del e_sub
     for key, v in worst.items():
         assert v <= tol[key[0]], worst
+
+
+def test_fullsize_headline_arithmetic_against_the_oracle(world, oracle):
+    """The bench's HEADLINE path at its full size - count layers -> vcy_knn_pool_counts in f64 -> fit_slope -> the fused f64 stage-D launch
+    with the literal rule, scheduled along the Hilbert curve (bench.Pipeline with --dtype f64) - against the fp64 oracle on 128 whole
+    cells x 250 neighbours x 30 000 genes: every pooled value of those cells and of the rows they touch to 1e-12, their gammas' inputs
+    by construction, all 32 000 correlations to 1e-9 (measured 2e-13), NaN pattern equal; 64 of the cells come from the groups beyond
+    the last full round of the launch (6-cell groups: the tiled tail)."""
+    w, ops = world, world["ops"]
+    dev = w["dev"]
+    pcs, neigh = w["pcs"], w["neigh"]
+    rng = np.random.default_rng(41)
+    idx, dist = ops.knn_search(pcs, K)
+    cS, cU, fS, fU, _ = bench_counts()
+    wrow = torch.cat([torch.ones((C, 1), device=dev, dtype=torch.float64), (dist > 0).double()], 1)
+    wrow = (wrow / wrow.sum(1, keepdim=True)).contiguous()
+    indices = torch.cat([torch.arange(C, device=dev, dtype=torch.int32)[:, None], idx], 1).contiguous()
+    indptr = torch.arange(0, (C + 1) * (K + 1), K + 1, device=dev, dtype=torch.int64)
+    indices, wrow = ops.canonical_graph_rows(indices, wrow)
+    Sx, Ux = ops.knn_pool_counts(cS, cU, fS, fU, indptr, indices, wrow, dtype=torch.float64, validate=False)
+    gam = ops.fit_slope(Ux, Sx)
+    gam[~torch.isfinite(gam)] = 0.0
+    g64 = gam.double().cpu().numpy()
+    order = ops.hilbert_order(pcs[:, :2].contiguous())
+    assert ops.partial_rules_for(Sx, ops.SQRT, 1e-10) == ops.RULES_PARTIAL          # f64: the literal rule, always
+    corr = ops.coldeltacor_partial_fused(Sx, Ux, gam, None, neigh, ops.SQRT, ops.RULES_PARTIAL, 1e-10, order=order, validate=False)
+    tail0 = (-(-C // 6) // 256) * 256 * 6                   # first schedule position of the tiled tail (6-cell groups, 256 CUs)
+    assert 0 < C - tail0 < 1536
+    pos = np.concatenate([rng.choice(tail0, 64, replace=False), rng.choice(np.arange(tail0, C), 64, replace=False)])
+    cells = order.cpu().numpy()[pos].astype(np.int64)
+    worst_corr, worst_pool = 0.0, 0.0
+    for b in range(0, len(cells), 64):
+        cs = cells[b:b + 64]
+        nb = neigh[torch.as_tensor(cs, device=dev)].long().cpu().numpy()
+        others = np.setdiff1d(np.unique(nb.ravel()), cs)
+        rows = np.concatenate([cs, others])
+        col = np.full(C, -1, dtype=np.int64)
+        col[rows] = np.arange(len(rows))
+        rows_t = torch.as_tensor(rows, device=dev)
+        e_sub = Sx.t[rows_t, :G].cpu().numpy().T.copy()
+        # the pooled rows themselves, recomputed in fp64 from the count layers in the reference's order (ascending cell number)
+        probe = rows[:: max(1, len(rows) // 24)][:24]
+        for r in probe:
+            js, ws = indices[r].long(), wrow[r].cpu().numpy()
+            raw = cS.t[js, :G]
+            raw = raw.double() if raw.dtype == torch.uint8 else (raw.to(torch.int32) & 0xFFFF).double()
+            src = raw.cpu().numpy() * fS[js].cpu().numpy()[:, None]
+            ref_row = np.zeros(G)
+            for t in range(len(ws)):                        # the kernel's own order of summation: ascending cell number
+                ref_row += ws[t] * src[t]
+            got_row = Sx.t[r, :G].cpu().numpy()
+            worst_pool = max(worst_pool, float(np.abs(got_row - ref_row).max() / max(1e-300, np.abs(ref_row).max())))
+        s, u = e_sub[:, :len(cs)], Ux.t[torch.as_tensor(cs, device=dev), :G].cpu().numpy().T
+        Dv = (s + (u - g64[:, None] * s)) - s
+        d_sub = np.zeros_like(e_sub)
+        d_sub[:, :len(cs)] = np.sign(Dv) * np.sqrt(np.abs(Dv) + 1e-10)
+        ixs = np.zeros((len(rows), nb.shape[1]), dtype=np.int64)
+        ixs[:len(cs)] = col[nb]
+        ref = oracle.coldeltacor_partial_compact(e_sub, d_sub, ixs, "sqrt", 1e-10, c0=0, c1=len(cs))[:len(cs)]
+        got = corr[torch.as_tensor(cs, device=dev)].cpu().numpy()
+        ok = np.isfinite(ref)
+        assert np.array_equal(np.isnan(got), ~ok)
+        worst_corr = max(worst_corr, float(np.abs(got[ok] - ref[ok]).max()))
+        del e_sub, d_sub
+    assert worst_pool <= 1e-12 and worst_corr <= 1e-9, (worst_pool, worst_corr)
