@@ -739,7 +739,8 @@ class VelocytoLoom(PreprocessMixin):
             # (vcy_embedding_scaling): groups of schedule-adjacent cells gather the rows of their common neighbours once, the
             # (genes, cells) estimates stay in registers.  Lists wider than it sorts in one workgroup take the two-step route.
             dS_r = self.dev(names[1][1]) if len(names) == 2 else None
-            cos = ops.embedding_scaling(hi, self.dev(names[0][1]), neigh, parts[0][1], dS_r, parts[1][1] if len(names) == 2 else None, order=order)
+            cos = ops.embedding_scaling(hi, self.dev(names[0][1]), neigh, parts[0][1], dS_r, parts[1][1] if len(names) == 2 else None, order=order,
+                                        validate=False)
             if cos is None:
                 indptr = torch.arange(0, (neigh.shape[0] + 1) * n, n, dtype=torch.int64, device=dev)
                 if len(names) == 2:

@@ -1482,7 +1482,7 @@ def row_cosproj(A: CellMatrix, B: CellMatrix) -> torch.Tensor:
 
 
 def embedding_scaling(hi: CellMatrix, dS: CellMatrix, ixs, wdiff: torch.Tensor, dS_rndm: Optional[CellMatrix] = None,
-                      wdiff_rndm: Optional[torch.Tensor] = None, order: Optional[torch.Tensor] = None):
+                      wdiff_rndm: Optional[torch.Tensor] = None, order: Optional[torch.Tensor] = None, validate: bool = True):
     """cos_proj (C_out) fp64 [and the control's] of calculate_embedding_shift's expression scaling (analysis.py:1714-1719, 1726-1731) in one
     launch, the (genes, cells) estimates never written (vcy_embedding_scaling).  Returns None when the neighbour lists are wider than
     the kernel sorts in one workgroup - the caller then pools with knn_pool[_w2] + row_cosproj."""
@@ -1493,6 +1493,8 @@ def embedding_scaling(hi: CellMatrix, dS: CellMatrix, ixs, wdiff: torch.Tensor, 
     if n > int(L.vcy_embedding_scaling_max_neighbors()) or n == 0 or C_out == 0:
         return None
     assert dS.t.shape == hi.t.shape and dS.dtype == hi.dtype and C_out <= hi.C
+    if validate and (int(ix.min()) < 0 or int(ix.max()) >= hi.C):
+        raise ValueError("neighbour index out of range")
     w = wdiff.to(device=dev, dtype=hi.dtype).contiguous()
     assert tuple(w.shape) == (C_out, n)
     dual = dS_rndm is not None
