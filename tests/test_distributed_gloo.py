@@ -220,7 +220,7 @@ def _self_check_worker(rank, world, port, inject, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,inject", [(2, ""), (3, ""), (3, "all_to_all_uneven@1")])
+@pytest.mark.parametrize("world,inject", [(2, ""), (4, ""), (3, "all_to_all_uneven@1")])      # 4 ranks: empty segments between different ranks
 def test_collective_self_check(world, inject):
     """distributed.self_check: every collective shape of the sharded path on tiny tensors (uneven all-to-all with empty
     segments, ragged and equal all-gathers, SUM / MIN all-reduces, the halo masks).  A failure on ONE rank becomes the same

@@ -371,7 +371,8 @@ def self_check(device: torch.device, group=None) -> dict:
         assert st.tolist() == [float(ws), 10.0, 2.0 * ws], st.tolist()
 
     def a2a():
-        # rank r sends (r + 2 p) % 3 rows to peer p: lengths 0, 1 and 2 all occur from 3 ranks up, the self segment is always empty
+        # rank r sends (r + 2 p) % 3 rows to peer p: lengths 1 and 2 always occur, empty segments between different ranks from 4 ranks up
+        # (0 -> 3, 1 -> 4, ...), the self segment is always empty
         n_to = lambda src, dst: 0 if src == dst else (src + 2 * dst) % 3
         send_splits = [n_to(rank, p) for p in range(ws)]
         recv_splits = [n_to(p, rank) for p in range(ws)]
