@@ -32,8 +32,10 @@ per-stage rooflines.  `extra` holds the other lines SURVEY.md 8(d) asks for, all
 E calculate_embedding_shift, F prepare_markov + run_markov, B fit_gammas with its defaults, D at the reference's default list
 width (n_neighbors = C/5, sampled_fraction = 0.3 => nrndm = 3000), the randomised control, and cfg2 (BASELINE.json
 configs[1]: 10 000 x 20 000, stages A + B, unbalanced and balanced kNN); their key numbers are repeated as scalars in `config`.
-`cpu_baseline` times the oracle restatement (oracle/libvelocyto_oracle.so + oracle.py) on a bounded closed sub-problem on
-the host cores and reports, as `parity`, how far the HIP path is from it on that same sub-problem in all three modes.
+`cpu_baseline` times the CPU side on a bounded closed sub-problem on the host cores: stage D - 98 % of it - by the reference's
+own Cython kernel where oracle/_ref travelled with the snapshot (`kind: "reference"`; built from /root/reference in the build
+container by oracle/build_ref.py), else by the oracle restatement (`kind: "port"`, oracle/libvelocyto_oracle.so + oracle.py);
+`parity` says how far the HIP path is from the restatement on that same sub-problem in all three modes.
 """
 import argparse
 import json
@@ -449,6 +451,20 @@ def cpu_baseline(pipe, args):
     corr = oracle.coldeltacor_partial_compact(Sx, dmat, ixs, "sqrt", 1e-10, threads=cores)
     tD = time.perf_counter() - t0
     total = tA + tB + tC + tD
+    # ---- stage D by the REFERENCE'S OWN kernel where oracle/_ref travelled with the snapshot (speedboosted.pyx built with the
+    #      reference's flags by oracle/build_ref.py; run in a subprocess, see oracle.reference_coldeltacor).  Its threads hold 60 MB
+    #      of scratch each (G x nrndm fp64): at most 64 of them.
+    ref = None
+    if oracle.reference_module_path() is not None:
+        try:
+            rthreads = min(cores, 64)
+            corr_ref, tD_ref = oracle.reference_coldeltacor(Sx, dmat, ixs, "sqrt", 1e-10, threads=rthreads)
+            okr = np.isfinite(corr_ref) & np.isfinite(corr)
+            ref = {"D_s": tD_ref, "threads": rthreads, "kernel": "velocyto/speedboosted.pyx _colDeltaCorSqrtpartial, built with the reference's flags (oracle/build_ref.py)",
+                   "max_abs_dcorr_restatement_vs_reference": float(np.abs(corr_ref[okr] - corr[okr]).max()),
+                   "nan_pattern_equal": bool(np.array_equal(np.isnan(corr_ref), np.isnan(corr)))}
+        except Exception as e:                                                  # noqa: BLE001 - the baseline falls back to the restatement
+            ref = {"error": f"{type(e).__name__}: {e}"[:300]}
     # ---- parity of the HIP path against these numbers, same inputs, three arithmetic modes
     parity = {"pairs": int(Cs * nr), "genes": G, "against": "the fp64 oracle restatement on the same closed sub-problem (all four stages)"}
     ok = np.isfinite(corr)
@@ -468,12 +484,20 @@ def cpu_baseline(pipe, args):
                         "max_rel_dgamma": float((np.abs(hg[pos] - gam0[pos]) / gam0[pos]).max()),
                         "max_rel_dSx": float((np.abs(sx - Sx) / np.maximum(np.abs(Sx), 1e-30))[Sx != 0].max())}
         del hSx, hg, hc, sx
+    port = {"value": Cs / total, "cores": cores, "stage_s": {"A": tA, "B": tB, "C": tC, "D": tD}}
+    if ref is not None and "D_s" in ref:
+        total_ref = tA + tB + tC + ref["D_s"]
+        return {"value": Cs / total_ref, "unit": "cells/s", "cores": ref["threads"], "kind": "reference",
+                "sample": f"closed sub-problem of {Cs} cells x {G} genes, k={min(args.k, Cs - 1)}, nrndm={nr}: stage D ({100.0 * ref['D_s'] / total_ref:.0f} % of the "
+                          f"CPU time) by the reference's own Cython kernel on {ref['threads']} threads ({ref['D_s']:.2f} s), stages A-C by the oracle "
+                          f"restatement (A {tA:.2f} s, B {tB:.2f} s, C {tC:.2f} s); the restatement's stage D on {cores} threads: {tD:.2f} s",
+                "stage_s": {"A": tA, "B": tB, "C": tC, "D": ref["D_s"]}, "reference_kernel": ref, "restatement": port, "parity": parity}
     return {"value": Cs / total, "unit": "cells/s", "cores": cores, "kind": "port",
             "sample": f"closed sub-problem of {Cs} cells x {G} genes, k={min(args.k, Cs - 1)}, nrndm={nr}, all four stages by the oracle "
                       f"restatement (C + OpenMP on {cores} threads for pooling and stage D, NumPy/SciPy for the rest): A {tA:.2f} s, B {tB:.2f} s, "
                       f"C {tC:.2f} s, D {tD:.2f} s; the per-cell cost of D does not depend on the number of cells, the O(C^2) kNN is cheaper at this "
                       "size (favours the CPU)",
-            "stage_s": {"A": tA, "B": tB, "C": tC, "D": tD}, "parity": parity}
+            "stage_s": {"A": tA, "B": tB, "C": tC, "D": tD}, "parity": parity, **({"reference_kernel": ref} if ref is not None else {})}
 
 
 def load_counters(dtype="f32"):

@@ -9,11 +9,12 @@ and compiles it with the reference's own flags.  The resulting extension module
 
     oracle/_ref/speedboosted.cpython-310-x86_64-linux-gnu.so
 
-stays in the build container (oracle/_ref/ is listed in .gitignore AND .gpurunignore: nothing built from the
-reference travels to the GPU box) and is used only
-  * to validate the C restatement in oracle/velocyto_oracle.c and to generate tests/golden/*.npz
-    (tests/golden/make_golden.py).
-bench.py's ``cpu_baseline`` times the pinned restatement (libvelocyto_oracle.so, kind "port"), not this module.
+is a build PRODUCT (oracle/_ref/ is listed in .gitignore: never in history; it is NOT gpurun-ignored, so it travels to the GPU box
+with the repository snapshot like the library's own .so) and is used, always in a subprocess (oracle.reference_coldeltacor), only
+  * to validate the C restatement in oracle/velocyto_oracle.c and to generate tests/golden/*.npz (tests/golden/make_golden.py);
+  * by tests/ where it is present: the restatement and the HIP kernels against the reference's own kernels on fresh random inputs;
+  * by bench.py's ``cpu_baseline`` leg: stage D - 98 % of the CPU time of the path - timed with the reference's own kernel on the
+    GPU box's host cores (cpu_baseline.kind = "reference"); where the module is absent the pinned restatement is timed (kind "port").
 
 Runs only where /root/reference exists (this container).  Needs Cython (3.2.9 here),
 gcc and numpy headers - all present in the image; nothing is stubbed.

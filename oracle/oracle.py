@@ -130,6 +130,67 @@ def coldeltacor_partial_compact(emat, dmat, ixs, transform="linear", psc=0.0, th
     return out
 
 
+# --------------------------------------------------------------------------- the REAL reference kernels (oracle/_ref)
+# oracle/build_ref.py compiles the reference's own Cython module (velocyto/speedboosted.pyx, its flags: -fopenmp -ffast-math) from where
+# it lies under /root/reference into oracle/_ref/ - a binary that is git-ignored but travels to the GPU box with the repository
+# snapshot.  Where it is present it validates the restatement above against the reference itself (tests) and is the CPU baseline of
+# stage D (bench.py, cpu_baseline.kind = "reference").  It runs in a SUBPROCESS: the module is linked with -ffast-math, whose start-up
+# code switches the loading process to flush-to-zero / denormals-are-zero, and its kernels take ~60 MB of scratch per thread.
+_REF_KERNELS = {("sqrt", True): "_colDeltaCorSqrtpartial", ("log10", True): "_colDeltaCorLog10partial", ("linear", True): "_colDeltaCorpartial",
+                ("sqrt", False): "_colDeltaCorSqrt", ("log10", False): "_colDeltaCorLog10", ("linear", False): "_colDeltaCor"}
+
+_REF_RUNNER = r"""
+import importlib.util, sys, time, numpy as np
+so, work, name, threads, psc, partial = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), float(sys.argv[5]), sys.argv[6] == "1"
+spec = importlib.util.spec_from_file_location("speedboosted", so)
+m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+e, d = np.load(work + "/e.npy"), np.load(work + "/d.npy")
+rm = np.zeros((e.shape[1], e.shape[1]))
+args = [e, d, rm]
+if partial:
+    ixs = np.load(work + "/ixs.npy")
+    args.append(ixs)
+args.append(threads)
+if name not in ("_colDeltaCor", "_colDeltaCorpartial"):
+    args.append(psc)
+t0 = time.perf_counter()
+getattr(m, name)(*args)
+dt = time.perf_counter() - t0
+np.save(work + "/out.npy", rm[np.arange(e.shape[1])[:, None], ixs] if partial else rm)
+np.save(work + "/seconds.npy", np.array([dt]))
+"""
+
+
+def reference_module_path() -> Optional[str]:
+    """Path of the compiled reference kernel module under oracle/_ref, or None where it was not built / did not travel."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(_HERE, "_ref", "speedboosted*.so")))
+    return hits[0] if hits else None
+
+
+def reference_coldeltacor(emat, dmat, ixs=None, transform="linear", psc=0.0, threads=8) -> Tuple[np.ndarray, float]:
+    """The reference's OWN kernel (speedboosted.pyx:13-610, as estimation.colDeltaCor* calls it: estimation.py:11-170) on
+    (genes, cells) fp64 inputs, in a subprocess.  ixs given: the *partial kernel, result gathered to the compact (C, nrndm) form;
+    ixs None: the full kernel, (C, C).  Returns (correlations, seconds inside the kernel call).  Raises FileNotFoundError where
+    oracle/_ref holds no module."""
+    import sys
+    import tempfile
+    so = reference_module_path()
+    if so is None:
+        raise FileNotFoundError("oracle/_ref holds no reference kernel module (oracle/build_ref.py builds it where /root/reference exists)")
+    name = _REF_KERNELS[({"log": "log10"}.get(transform, transform), ixs is not None)]
+    with tempfile.TemporaryDirectory() as work:
+        np.save(os.path.join(work, "e.npy"), np.ascontiguousarray(emat, dtype=np.float64))
+        np.save(os.path.join(work, "d.npy"), np.ascontiguousarray(dmat, dtype=np.float64))
+        if ixs is not None:
+            np.save(os.path.join(work, "ixs.npy"), np.ascontiguousarray(ixs, dtype=np.intp))
+        r = subprocess.run([sys.executable, "-c", _REF_RUNNER, so, work, name, str(int(threads)), repr(float(psc)), "1" if ixs is not None else "0"],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("reference kernel subprocess failed:\n" + r.stderr[-2000:])
+        return np.load(os.path.join(work, "out.npy")), float(np.load(os.path.join(work, "seconds.npy"))[0])
+
+
 # --------------------------------------------------------------------------- kNN + pooling
 def knn_search(space: np.ndarray, k: int, include_self: bool = False) -> Tuple[np.ndarray, np.ndarray]:
     """Exact Euclidean kNN (what sklearn NearestNeighbors computes for neighbors.py:363-376,

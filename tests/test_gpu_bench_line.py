@@ -67,5 +67,9 @@ def test_bench_line_structure():
         assert isinstance(cfg[k], float) and cfg[k] > 0, k
     # ---- CPU baseline: the oracle on the host cores, with the HIP path's distance from it on the same sub-problem
     cb = j["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
+    if cb["kind"] == "reference":          # oracle/_ref travelled with the snapshot: stage D by the reference's own Cython kernel
+        rk = cb["reference_kernel"]
+        assert rk["D_s"] > 0 and rk["nan_pattern_equal"] and rk["max_abs_dcorr_restatement_vs_reference"] < 1e-12
+        assert cb["restatement"]["value"] > 0 and abs(cb["stage_s"]["D"] - rk["D_s"]) < 1e-12
     assert cb["parity"]["f64"]["max_abs_dcorr"] < 1e-9 and cb["parity"]["f32_nopsc"]["max_abs_dcorr"] < 5e-5

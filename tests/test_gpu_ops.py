@@ -1160,3 +1160,29 @@ def test_embedding_scaling_against_the_two_step_route(ops, dtype, C, G, n):
     if n == 256:
         wide = np.concatenate([ixs, ixs[:, :1]], 1)
         assert ops.embedding_scaling(hi, dS, wide, torch.zeros((C, n + 1), dtype=tdt, device=dev)) is None
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_hip_kernels_against_the_reference_kernels_where_built(ops, oracle, dtype):
+    """The HIP stage-D kernels against the REFERENCE'S OWN Cython kernels (oracle/_ref: velocyto/speedboosted.pyx built with its own
+    flags in the build container, shipped to the GPU box as a binary and run in a subprocess) on fresh random inputs: all three
+    transforms, partial (compact lists) and full (all pairs).  Skipped where the module did not travel."""
+    if oracle.reference_module_path() is None:
+        pytest.skip("oracle/_ref did not travel to this box")
+    rng = np.random.default_rng(23)
+    G, C, nr = 1300, 96, 14
+    e = rng.gamma(1.0, 2.0, (G, C)) * (rng.random((G, C)) < 0.8)
+    d = rng.normal(size=(G, C))
+    ixs = np.stack([rng.choice(C, nr, replace=False) for _ in range(C)])
+    E, Dm = ops.CellMatrix.from_genes_major(e, dtype), ops.CellMatrix.from_genes_major(d, dtype)
+    es, ds = E.to_genes_major(), Dm.to_genes_major()           # the stored (possibly f32-rounded) values, as fp64
+    atol = CORR_ATOL[dtype]
+    for transform, kern, psc in (("sqrt", ops.SQRT, 1e-10), ("log10", ops.LOG10, 1.0), ("linear", ops.LINEAR, 0.0)):
+        ref, _ = oracle.reference_coldeltacor(es, ds, ixs, transform, psc, threads=4)
+        got = ops.coldeltacor_partial(E, Dm, ixs, kern, ops.RULES_PARTIAL, psc).cpu().numpy()
+        _nan_close(got, ref, atol)
+        full_ref, _ = oracle.reference_coldeltacor(es, ds, None, transform, psc, threads=4)
+        full = ops.coldeltacor_full(E, Dm, kern, psc).cpu().numpy()
+        off = ~np.eye(C, dtype=bool)
+        okf = np.isfinite(full_ref) & off
+        np.testing.assert_allclose(full[okf], full_ref[okf], atol=atol)

@@ -474,3 +474,33 @@ def test_cfg1_size_fit_gammas_plumbing(golden, oracle):
     assert np.all(ours <= ref * (1 + 1e-4) + 1e-7), float(np.max(ours - ref))
     same = rg <= 1e-4
     np.testing.assert_allclose(r2e[same], g["R2"][same], atol=2e-3)
+
+
+@pytest.mark.parametrize("transform,psc", [("linear", 0.0), ("sqrt", 1e-10), ("sqrt", 1.0), ("log10", 1.0), ("log10", 1e-10)])
+def test_restatement_against_the_reference_kernels_where_built(oracle, transform, psc):
+    """Where oracle/_ref holds the reference's own Cython module (built from /root/reference by oracle/build_ref.py; it travels to the
+    GPU box as a binary), the C restatement is checked against it directly on fresh random inputs - partial and full kernels, ties
+    and identical cells included - not only through the committed golden vectors."""
+    if oracle.reference_module_path() is None:
+        pytest.skip("oracle/_ref not built here")
+    rng = np.random.default_rng(17)
+    G, C, nr = 700, 60, 11
+    e = rng.gamma(1.0, 2.0, (G, C)) * (rng.random((G, C)) < 0.7)
+    e[:, 9] = e[:, 4]                                          # identical cells: zero differences on every gene
+    d = rng.normal(size=(G, C))
+    ixs = np.stack([rng.choice(C, nr, replace=False) for _ in range(C)])
+    ixs[4, 0] = 9
+    got, sec = oracle.reference_coldeltacor(e, d, ixs, transform, psc, threads=4)
+    ref = oracle.coldeltacor_partial_compact(e, d, ixs, transform, psc)
+    assert sec > 0 and got.shape == ref.shape
+    both = np.isfinite(got) & np.isfinite(ref)
+    assert both.mean() > 0.95
+    np.testing.assert_allclose(got[both], ref[both], atol=1e-12)
+    if transform == "sqrt":                                    # the partial sqrt rule zeroes exact ties: the identical pair is NaN in both
+        assert np.isnan(got[4, 0]) and np.isnan(ref[4, 0])
+    full, _ = oracle.reference_coldeltacor(e, d, None, transform, psc, threads=4)
+    reff = oracle.coldeltacor(e, d, transform, psc)
+    off = ~np.eye(C, dtype=bool)
+    off[4, 9] = off[9, 4] = False                              # (degenerate pairs: rounding noise over a zero variance under -ffast-math)
+    okf = np.isfinite(full) & np.isfinite(reff) & off
+    np.testing.assert_allclose(full[okf], reff[okf], atol=1e-12)
