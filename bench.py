@@ -63,10 +63,11 @@ VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
 #   2 pseudocount dropped (VCY_RULES_PARTIAL_NOPSC, f32): v_sub, v_rsq_f32, v_mul_legacy_f32, v_add, two v_fmac -
 #     "cdc no-psc element" 3.89 clocks x 6 instructions (the parts alone sum to 19.8: a transcendental between plain ops costs more)
 MIX_CLK_PER_ELEMENT = {1: 27.7, 2: 23.3}
-# f64 (the reference's arithmetic): literal element = v_add_f64 (sub), v_add_f64 (|t| + psc), v_cvt_f32_f64, v_rsq_f32, v_mul_f32 (the 24-bit seed), 2 x v_cvt_f64_f32,
-# v_add_u32 (h = y / 2), 4 x v_fma_f64 (two Newton corrections), v_cmp_lt_f64 + 2 x v_cndmask (zero rule), v_bfi (sign), v_add_f64 + 2 x v_fma_f64 (moments): measured as a
-# mix by tools/ubench/valu_issue_f64.hip (profiles/r04_valu_issue_f64.txt: "f64 element, f32 product seed + 2 Newton corrections (round 4)", wall-clock column)
-MIX_CLK_PER_ELEMENT_F64 = 83.2
+# f64 (the reference's arithmetic): literal element = v_add_f64 (sub), v_add_f64 (|t| + psc), v_cvt_f32_f64, v_cmp_f64 + v_cndmask (zero rule, on the argument of the
+# seed), v_rsq_f32, 2 x v_mul_f32 (the 24-bit seed s0 and h = y / 2), 2 x v_cvt_f64_f32, 4 x v_fma_f64 (two Newton corrections), v_bfi (sign), v_add_f64 + 2 x v_fma_f64
+# (moments) - 18 instructions: measured as a mix by tools/ubench/valu_issue_f64.hip (profiles/r04_valu_issue_f64.txt: "f64 element, zero rule on the seed's argument",
+# wall-clock column; the 19-instruction form it replaced: 83.2)
+MIX_CLK_PER_ELEMENT_F64 = 77.4
 F64_ISSUE_CLK = 4.1               # clocks per wave64 v_add_f64 / v_mul_f64 / v_fma_f64 per SIMD (same file): the f64 issue peak is 1 instruction / 4 clocks
 COUNTERS_FILE = os.path.join(ROOT, "profiles", "r04_cdc_counters.json")     # written by tools/summarize_profiles.py from the rocprofv3 passes
 COUNTERS_FALLBACK = os.path.join(ROOT, "profiles", "r03_cdc_counters.json")

@@ -96,8 +96,31 @@ __device__ __forceinline__ double sqrt_f32prod(double x)            // round 4 (
     d = fma(-s1, s1, x);
     return fma(d, h, s1);
 }
+__device__ __forceinline__ double sqrt_seedzero(double x, bool discard)   // round 4, second step (what the kernel runs now): the zero rule selects the ARGUMENT of
+{                                                                          // v_rsq_f32 (+inf -> y_f = 0 -> s0 = h = 0 -> the root is an exact 0: one v_cndmask, not two);
+    const float xf0 = (float)x;                                            // h = y_f / 2 halved in f32 (an exponent decrement would turn the zero into -inf)
+    const float xf = discard ? __builtin_inff() : xf0;
+    const float yf = __builtin_amdgcn_rsqf(xf);
+    const double s0 = (double)(xf0 * yf), h = (double)(0.5f * yf);
+    double d = fma(-s0, s0, x);
+    const double s1 = fma(d, h, s0);
+    d = fma(-s1, s1, x);
+    return fma(d, h, s1);
+}
+__device__ __forceinline__ double sqrt_seedzero_f64prod(double x, bool discard)   // measured and not kept: s0 = x y, h = y / 2 as f64 products of the one converted
+{                                                                                  // seed (17 instructions per element, two more on the f64 multiplier)
+    const float xf = discard ? __builtin_inff() : (float)x;
+    const double y = (double)__builtin_amdgcn_rsqf(xf);
+    const double s0 = x * y, h = 0.5 * y;
+    double d = fma(-s0, s0, x);
+    const double s1 = fma(d, h, s0);
+    d = fma(-s1, s1, x);
+    return fma(d, h, s1);
+}
 template <int MODE> __device__ __forceinline__ double elem(double t, double psc)
 {
+    if (MODE == 5) return copysign(sqrt_seedzero(fabs(t) + psc, fabs(t) < 1e-16), t);
+    if (MODE == 6) return copysign(sqrt_seedzero_f64prod(fabs(t) + psc, fabs(t) < 1e-16), t);
     const double a = fabs(t) + psc;
     const double s = MODE == 0 ? sqrt_lib_iter(a) : (MODE == 1 ? sqrt_f32seed(a) : (MODE == 2 ? sqrt_f32seed2(a) : (MODE == 4 ? sqrt_f32prod(a) : sqrt(a))));
     return (fabs(t) < 1e-16) ? 0.0 : copysign(s, t);
@@ -128,8 +151,8 @@ __global__ void __launch_bounds__(256) k_elem(double *out, unsigned long long *c
 // accuracy of the candidates against the library square root over a sweep of magnitudes
 __global__ void k_sqrt_err(double *maxrel, int n)
 {
-    double m1 = 0, m2 = 0, m3 = 0;
-    unsigned long long off = 0;
+    double m1 = 0, m2 = 0, m3 = 0, m4 = 0;
+    unsigned long long off = 0, off4 = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const double x = exp2(-60.0 + 120.0 * (double)i / n) * (1.0 + 1e-3 * (i % 997));
         const double s = sqrt(x);
@@ -138,7 +161,13 @@ __global__ void k_sqrt_err(double *maxrel, int n)
         const double p = sqrt_f32prod(x);
         m3 = fmax(m3, fabs(p - s) / s);
         off += p != s;
+        const double q = sqrt_seedzero(x, false);
+        m4 = fmax(m4, fabs(q - s) / s);
+        off4 += q != s;
+        if (sqrt_seedzero(x, true) != 0.0) off4 += 1ull << 40;          // a discarded element must be an exact zero
     }
+    atomicMax((unsigned long long *)&maxrel[4], (unsigned long long)__double_as_longlong(m4));
+    atomicAdd((unsigned long long *)&maxrel[5], off4);
     atomicMax((unsigned long long *)&maxrel[0], (unsigned long long)__double_as_longlong(m1));
     atomicMax((unsigned long long *)&maxrel[1], (unsigned long long)__double_as_longlong(m2));
     atomicMax((unsigned long long *)&maxrel[2], (unsigned long long)__double_as_longlong(m3));
@@ -174,12 +203,15 @@ int main()
     run("f64 element, f32 seed + 1 step + 1 correction", k_elem<1>, w, 4, "element");
     run("f64 element, f32 seed + 1 step + 2 corrections", k_elem<2>, w, 4, "element");
     run("f64 element, f32 product seed + 2 Newton corrections (round 4)", k_elem<4>, w, 4, "element");
+    run("f64 element, zero rule on the seed's argument (round 4, second step: the kernel's)", k_elem<5>, w, 4, "element");
+    run("f64 element, the same with s0 = x y and h = y / 2 as f64 products (not kept)", k_elem<6>, w, 4, "element");
     run("f64 element, library sqrt()", k_elem<3>, w, 4, "element");
-    double *mr; hipMalloc(&mr, 32); hipMemset(mr, 0, 32);
+    double *mr; hipMalloc(&mr, 48); hipMemset(mr, 0, 48);
     k_sqrt_err<<<1024, 256>>>(mr, 1 << 26);
-    double h[4]; hipMemcpy(h, mr, 32, hipMemcpyDeviceToHost);
-    unsigned long long noff; memcpy(&noff, &h[3], 8);
+    double h[6]; hipMemcpy(h, mr, 48, hipMemcpyDeviceToHost);
+    unsigned long long noff, noff4; memcpy(&noff, &h[3], 8); memcpy(&noff4, &h[5], 8);
     printf("max relative error against sqrt() over 2^26 arguments in [2^-60, 2^60]: f32 seed + 1 correction %.3g, + 2 corrections %.3g, f32 product seed + 2 Newton "
-           "corrections %.3g with %llu results not equal to sqrt() bit for bit (ulp = 1.1e-16)\n", h[0], h[1], h[2], noff);
+           "corrections %.3g with %llu results not equal to sqrt() bit for bit (ulp = 1.1e-16); the kernel's element (zero rule on the seed's argument) %.3g with %llu "
+           "(2^40 x the discarded elements that are not an exact 0 would show here)\n", h[0], h[1], h[2], noff, h[4], noff4);
     return 0;
 }

@@ -79,22 +79,32 @@ template <> __device__ __forceinline__ float xform<float, VCY_SQRT, VCY_RULES_PA
 // result that is the correctly rounded root in all but near-tie cases (round 3: up to 2 ulp; tools/ubench/valu_issue_f64.hip counts
 // both over 2^26 arguments in [2^-60, 2^60], profiles/r04_valu_issue_f64.txt).  Domain: |t| + psc in [1e-38, 3e38] - a count-derived
 // matrix never leaves it, ops.check_f64_sqrt_domain refuses one that does, below 1e-16 the zero rule discards the value.
-__device__ __forceinline__ double sqrt_normal_f64(double x)
+// The element of the hot loop: that seed and those two Newton corrections (tools/ubench/valu_issue_f64.hip: sqrt_f32prod), with the zero rule of speedboosted.pyx:372 applied to
+// the ARGUMENT of the seed: v_rsq_f32(+inf) = +0, a y_f of 0 makes s0 = x_f y_f = 0 and h = y_f / 2 = 0 (halved in f32 here: an exponent
+// decrement of the converted value would turn a zero into -inf), both corrections add (x - 0) 0 and the root comes out as an exact 0 -
+// one v_cndmask on a 32-bit value where zeroing the finished double took two.  (The select sits before the v_rsq because the compiler
+// moves one placed on y_f past the conversion to f64, where it is two again.)  18 instructions per element instead of 19: v_add_f64 (t),
+// v_add_f64 (|t| + psc), v_cvt_f32_f64, v_cmp_f64 + v_cndmask (zero rule), v_rsq_f32, 2 x v_mul_f32 (s0, h), 2 x v_cvt_f64_f32, 4 x
+// v_fma_f64, v_bfi (sign), v_add_f64 + 2 x v_fma_f64 (moments).  A discarded element is -0 where t < 0: it adds nothing to any moment.
+// Measured on one box, stage D at 50k x 30k (profiles/r04b_elem_variants*.txt; boxes differ by +-4 %, forms compared within a call):
+// 19-instruction form 245.2 / 241.2 ms, this one 232.6 / 232.4; s0 = x y and h = y / 2 as f64 products of the one converted seed (17
+// instructions, two more on the f64 multiplier) 237.9 - slower than this although shorter: the launch clocks lower (GRBM_GUI_ACTIVE / time
+// 2.27 -> 2.20 GHz), the f64 multiplier is what the power budget pays for; sum A^2 as sum |t| + psc x (kept elements, counted from the
+// compare's mask on the scalar unit: a v_add_f64 for a v_fma_f64) 235.4 against 232.6 - no gain, the literal a^2 stays; h = rsq / 2 and
+// s0 = 2 x_f h through output modifiers (17 instructions; needs the wave's IEEE bit and f32 denormals off, s_setreg at kernel start,
+// and the four f32 instructions of two elements in one asm block for the trans-use hazard: parity-green) 238.9 against 242.4 on its
+// box, 1.4 % - not kept.
+template <> __device__ __forceinline__ double xform<double, VCY_SQRT, VCY_RULES_PARTIAL>(double t, double psc)
 {
-    const float xf = (float)x;
+    const double x = fabs(t) + psc;
+    const float xf0 = (float)x;
+    const float xf = (fabs(t) < 1e-16) ? __builtin_inff() : xf0;
     const float yf = __builtin_amdgcn_rsqf(xf);
-    const double s0 = (double)(xf * yf);
-    const double y = (double)yf;
-    const double h = __hiloint2double(__double2hiint(y) - 0x00100000, __double2loint(y));
+    const double s0 = (double)(xf0 * yf), h = (double)(0.5f * yf);
     double d = fma(-s0, s0, x);
     const double s1 = fma(d, h, s0);
     d = fma(-s1, s1, x);
-    return fma(d, h, s1);
-}
-template <> __device__ __forceinline__ double xform<double, VCY_SQRT, VCY_RULES_PARTIAL>(double t, double psc)
-{
-    const double s = sqrt_normal_f64(fabs(t) + psc);
-    return (fabs(t) < 1e-16) ? 0.0 : copysign(s, t);
+    return copysign(fma(d, h, s1), t);
 }
 
 // VCY_RULES_PARTIAL_NOPSC (f32, sqrt): A = sign(t) sqrt|t| as t * rsq|t| with the legacy multiply (0 * anything = 0: the zero
