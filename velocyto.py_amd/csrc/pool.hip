@@ -208,7 +208,9 @@ __global__ __launch_bounds__(256) void k_knn_pool_counts(const CT *__restrict__ 
         // profiles/r04_pool_pmc.txt: 8.0 resident waves per SIMD, a wave issues 14 % of its time, waits to issue 43 % and is
         // parked at s_waitcnt 43 %; 1.5e9 VALU (2.1 per gathered element: v_cvt_f32_ubyte + half a v_pk_fma_f32) + 0.7e9 SALU
         // (the 64-bit row addresses, 15 per neighbour) + 4.7e7 gathers per layer = 3.8 clocks per issued instruction and SIMD.
-        // Nontemporal stores: 8.0 -> 10.7 ms (f64: 13.8 -> 28 ms).)
+        // Nontemporal stores: 8.0 -> 10.7 ms (f64: 13.8 -> 28 ms).  Two groups of four gathers in flight, the loads of group i + 1 issued
+        // before the arithmetic of group i: 110 / 158 VGPRs instead of 62 / 66 and slower, f32 7.85 -> 9.25 ms, f64 13.6 -> 15.6 ms,
+        // profiles/r04b_pool_dbuf.txt - the launch is not waiting for its gathers, resident waves cover them.)
         using OV = typename Vec<T>::type;
         constexpr int ON = Vec<T>::N;
         if (g0 + v * NE < ld_out) {
