@@ -549,12 +549,15 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
         static_assert(NV % 2 == 0, "operand buffers alternate");
 #define VCY_FENCE() __builtin_amdgcn_sched_barrier(0)
         constexpr int RQ = 4;
-        auto load_row = [&](V (&x)[NV], unsigned long long dsc) {
+        // (a full chunk - every chunk but the last - loads its rows without predicates: the guarded form costs a v_cmp + s_and_saveexec +
+        //  branch per vector, and in the f64 dual kernel the eight lane offsets it keeps for the compares were spilled and each reload
+        //  put an s_waitcnt vmcnt(0) in front of the next row load; the two forms are two instances of the row loop below)
+        auto load_row = [&](auto fullc, V (&x)[NV], unsigned long long dsc) {
             const T *row = e + (int64_t)(dsc >> 19) * ld + g0;
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 const int v = lane + 64 * u;
-                if (v < nvec) x[u] = reinterpret_cast<const V *>(row)[v];
+                if (decltype(fullc)::value || v < nvec) x[u] = reinterpret_cast<const V *>(row)[v];
                 else x[u] = V{};                                 // short last chunk: zeros against the zeros staged below
             }
         };
@@ -626,7 +629,7 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
                 m = mn;
             }
         };
-        {
+        auto rows = [&](auto fullc) {
             auto ticket = [&]() { int t = 0; if (lane == 0) t = atomicAdd(s_next, RQ); return t; };     // lane 0 holds the value
             auto uni = [&](unsigned long long v) {
                 const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
@@ -640,27 +643,28 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
             int q = __builtin_amdgcn_readfirstlane(tv);
             unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0;        // w0..w3: the descriptors of the quad in hand, n0..n3: of the next
             if (q < U) { w0 = uni(desc[q]); w1 = uni(desc[min(q + 1, U - 1)]); w2 = uni(desc[min(q + 2, U - 1)]); w3 = uni(desc[min(q + 3, U - 1)]); }
-            if (q < U) load_row(xa, w0);
+            if (q < U) load_row(fullc, xa, w0);
             while (q < U) {
                 tv = ticket();
-                if (q + 1 < U) load_row(xb, w1);
+                if (q + 1 < U) load_row(fullc, xb, w1);
                 eval_row(xa, w0);
                 if (q + 1 >= U) break;
-                if (q + 2 < U) load_row(xa, w2);
+                if (q + 2 < U) load_row(fullc, xa, w2);
                 eval_row(xb, w1);
                 const int qn = __builtin_amdgcn_readfirstlane(tv);
                 unsigned long long n0 = 0, n1 = 0, n2 = 0, n3 = 0;                     // requested here, read after the next row
                 if (qn < U) { n0 = desc[qn]; n1 = desc[min(qn + 1, U - 1)]; n2 = desc[min(qn + 2, U - 1)]; n3 = desc[min(qn + 3, U - 1)]; }
                 if (q + 2 >= U) break;
-                if (q + 3 < U) load_row(xb, w3);
+                if (q + 3 < U) load_row(fullc, xb, w3);
                 eval_row(xa, w2);
                 if (q + 3 >= U) break;
                 if (qn < U) { n0 = uni(n0); n1 = uni(n1); n2 = uni(n2); n3 = uni(n3); }
-                if (qn < U) load_row(xa, n0);
+                if (qn < U) load_row(fullc, xa, n0);
                 eval_row(xb, w3);
                 q = qn; w0 = n0; w1 = n1; w2 = n2; w3 = n3;
             }
-        }
+        };
+        if (nvec == 64 * NV) rows(std::true_type{}); else rows(std::false_type{});
     }
     psb = wave_sum(psb); psbb = wave_sum(psbb);
     if (DUAL) { psb2 = wave_sum(psb2); psbb2 = wave_sum(psbb2); }
