@@ -93,7 +93,8 @@ template <> __device__ __forceinline__ float xform<float, VCY_SQRT, VCY_RULES_PA
 // compare's mask on the scalar unit: a v_add_f64 for a v_fma_f64) 235.4 against 232.6 - no gain, the literal a^2 stays; h = rsq / 2 and
 // s0 = 2 x_f h through output modifiers (17 instructions; needs the wave's IEEE bit and f32 denormals off, s_setreg at kernel start,
 // and the four f32 instructions of two elements in one asm block for the trans-use hazard: parity-green) 238.9 against 242.4 on its
-// box, 1.4 % - not kept.
+// box, 1.4 % - not kept; v_rsq_f64 on x itself with the rule on the high word of its result and both products in f64 (15 instructions, no
+// conversions) 237.4 against 231.2 on its box.
 template <> __device__ __forceinline__ double xform<double, VCY_SQRT, VCY_RULES_PARTIAL>(double t, double psc)
 {
     const double x = fabs(t) + psc;
