@@ -210,7 +210,8 @@ __global__ __launch_bounds__(256) void k_knn_pool_counts(const CT *__restrict__ 
         // (the 64-bit row addresses, 15 per neighbour) + 4.7e7 gathers per layer = 3.8 clocks per issued instruction and SIMD.
         // Nontemporal stores: 8.0 -> 10.7 ms (f64: 13.8 -> 28 ms).  Two groups of four gathers in flight, the loads of group i + 1 issued
         // before the arithmetic of group i: 110 / 158 VGPRs instead of 62 / 66 and slower, f32 7.85 -> 9.25 ms, f64 13.6 -> 15.6 ms,
-        // profiles/r04b_pool_dbuf.txt - the launch is not waiting for its gathers, resident waves cover them.)
+        // profiles/r04b_pool_dbuf.txt - the launch is not waiting for its gathers, resident waves cover them.  Eight waves per SIMD for the
+        // f64 / uint8 instance (64 VGPRs instead of 66, 12 bytes of scratch): 13.85 -> 14.32 ms.)
         using OV = typename Vec<T>::type;
         constexpr int ON = Vec<T>::N;
         if (g0 + v * NE < ld_out) {
