@@ -618,13 +618,15 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
                     fold(x[u], eR[u % RD], bR[u % RD], b2R[u % RD], u == 0);
                     VCY_FENCE();
                 }
-                // the three (dual: four) wave totals in one transposing reduction: row r of `tot` holds moment r; lane 16 r
-                // adds it to acc[AS p + r] (the single-control kernel feeds a fourth value nobody reads, so that both
-                // variants sum in the same order)
-                const T tot = wave_sum_rows(sA[0] + sA[1], sAA[0] + sAA[1], sAb[0] + sAb[1], DUAL ? sAb2[0] + sAb2[1] : T(0));
-                // ds_add_f32 without return: the wave that owns the pair is the only writer of acc[p][.], so the order of the
-                // additions is its program order (deterministic) and nothing waits for the old value
-                if ((lane & 15) == 0 && (lane >> 4) < AS)
+                // the three (dual: four) wave totals in one transposing reduction: row r of `tot` holds moment r (the single-control
+                // kernel feeds a fourth value nobody reads, so that both variants sum in the same order);
+                // the last two steps of the row reduction are left to the LDS: the four quad totals of a row go into the pair's word as
+                // four lanes of ONE ds_add (same address: the LDS adds them one after the other, in lane order).  Without return: the
+                // wave that owns the pair is the only writer of acc[p][.], so the order of the additions is its program order
+                // (deterministic) and nothing waits for the old value.  (Same box, stage D at 50k x 30k: f64 235.6 -> 232.0 ms, f32 71.9 -> 71.2;
+                //  one step fewer still - pairs, eight lanes per row - f64 224.6 vs 225.2 but f32 75.8 vs 70.7; none at all f64 226.6, f32 109.9.)
+                const T tot = wave_sum_rows_quads(sA[0] + sA[1], sAA[0] + sAA[1], sAb[0] + sAb[1], DUAL ? sAb2[0] + sAb2[1] : T(0));
+                if ((lane & 3) == 0 && (lane >> 4) < AS)
                     __hip_atomic_fetch_add(&acc[AS * p + (lane >> 4)], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 ++p;
                 m = mn;

@@ -132,6 +132,20 @@ template <typename T> __device__ __forceinline__ T wave_sum_rows(T a, T b, T c, 
     return v;
 }
 
+// the same, stopped two steps early: every lane of a QUAD (4 lanes) of row r holds the sum of its quad's column partials of argument r;
+// the four quads of a row add up to the wave total (the caller lets lanes 0, 4, 8, 12 of the row add theirs to one LDS word each)
+template <typename T> __device__ __forceinline__ T wave_sum_rows_quads(T a, T b, T c, T d)
+{
+    lane_swap32(a, c);
+    lane_swap32(b, d);
+    T ac = a + c, bd = b + d;
+    lane_swap16(ac, bd);
+    T v = ac + bd;
+    v += dpp_val<0xB1, 0xF>(v);        // quad_perm [1,0,3,2]
+    v += dpp_val<0x4E, 0xF>(v);        // quad_perm [2,3,0,1]
+    return v;
+}
+
 template <typename T> __device__ __forceinline__ T wave_max(T v)
 {
 #pragma unroll
