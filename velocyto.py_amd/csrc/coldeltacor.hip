@@ -579,11 +579,12 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
             while (mask) {
                 mask &= mask - 1;
                 const int mn = mask ? __builtin_ctz(mask) : m;
-                T sA[2], sAA[2], sAb[2], sAb2[2];          // two partial sums per moment and lane: elements (0, 1) and (2, 3) of a vector fold into the SAME
-                                                            // accumulator pair (6 registers for three moments; four partials each cost 12)
-                // (no zeroing: the first two elements of a pair initialise the partial sums - six v_mov and four adds to zero less per
-                //  pair-chunk; sum A^2 of the no-pseudocount rule is sum |t| - A^2 = |t| exactly for A = sign(t) sqrt|t|, one v_add with
-                //  the |.| modifier that does not wait for the v_rsq_f32 - together 77.1 -> 74.6 ms at 50k x 30k)
+                T sA, sAA, sAb, sAb2;                       // ONE partial sum per moment and lane: an element is 18 instructions, so the next add to an
+                                                            // accumulator is issued long after the last one landed; two interleaved partials cost three adds
+                                                            // per pair-chunk and six (f64: twelve) registers - f64 227.5 -> 226.2 ms, f64 dual 247.2 -> 236.5
+                                                            // (fewer spills), f32 70.8 -> 70.4
+                // (no zeroing: the first element of a pair initialises the sums; sum A^2 of the no-pseudocount rule is sum |t| - A^2 = |t|
+                //  exactly for A = sign(t) sqrt|t|, one v_add with the |.| modifier that does not wait for the v_rsq_f32)
                 auto fold = [&](const V &xv, const V &ev, const V &bv, const V &b2v, bool first) {
                     const T *xp = reinterpret_cast<const T *>(&xv);
                     const T *ep = reinterpret_cast<const T *>(&ev);
@@ -594,18 +595,18 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
                     for (int k = 0; k < N; ++k) {
                         const T tt = xp[k] - ep[k];
                         const T a = xform_s<T, TR, RULES>(tt, psc, K);
-                        if (first && k < 2) {
-                            sA[k] = a;
-                            sAA[k] = ABS2 ? fabs(tt) : a * a;
-                            sAb[k] = a * bp[k];
-                            if (DUAL) sAb2[k] = a * bp2[k];
+                        if (first && k == 0) {
+                            sA = a;
+                            sAA = ABS2 ? fabs(tt) : a * a;
+                            sAb = a * bp[k];
+                            if (DUAL) sAb2 = a * bp2[k];
                             continue;
                         }
-                        sA[k & 1] += a;
-                        if (ABS2) sAA[k & 1] += fabs(tt);
-                        else sAA[k & 1] = fma(a, a, sAA[k & 1]);
-                        sAb[k & 1] = fma(a, bp[k], sAb[k & 1]);
-                        if (DUAL) sAb2[k & 1] = fma(a, bp2[k], sAb2[k & 1]);
+                        sA += a;
+                        if (ABS2) sAA += fabs(tt);
+                        else sAA = fma(a, a, sAA);
+                        sAb = fma(a, bp[k], sAb);
+                        if (DUAL) sAb2 = fma(a, bp2[k], sAb2);
                     }
                 };
 #pragma unroll
@@ -625,7 +626,7 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
                 // wave that owns the pair is the only writer of acc[p][.], so the order of the additions is its program order
                 // (deterministic) and nothing waits for the old value.  (Same box, stage D at 50k x 30k: f64 235.6 -> 232.0 ms, f32 71.9 -> 71.2;
                 //  one step fewer still - pairs, eight lanes per row - f64 224.6 vs 225.2 but f32 75.8 vs 70.7; none at all f64 226.6, f32 109.9.)
-                const T tot = wave_sum_rows_quads(sA[0] + sA[1], sAA[0] + sAA[1], sAb[0] + sAb[1], DUAL ? sAb2[0] + sAb2[1] : T(0));
+                const T tot = wave_sum_rows_quads(sA, sAA, sAb, DUAL ? sAb2 : T(0));
                 if ((lane & 3) == 0 && (lane >> 4) < AS)
                     __hip_atomic_fetch_add(&acc[AS * p + (lane >> 4)], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 ++p;
