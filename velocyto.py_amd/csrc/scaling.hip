@@ -53,11 +53,7 @@ __global__ __launch_bounds__(64 * SC_WAVES, 4) void k_embedding_scaling(const T 
 {
     using V = typename Vec<T>::type;
     constexpr int N = Vec<T>::N;
-#if defined(VCY_EXP) && VCY_EXP == 1
-    constexpr bool BCAST = false;
-#else
     constexpr bool BCAST = sizeof(T) == 8;                           // weights reach the f64 multiply-adds through DPP (fmac_bcast)
-#endif
     static_assert(SC_GC == 8, "fmac_bcast is instantiated for members 0..7");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int maxpairs = SC_GC * n;
@@ -145,12 +141,12 @@ __global__ __launch_bounds__(64 * SC_WAVES, 4) void k_embedding_scaling(const T 
         for (int m = 0; m < SC_GC; ++m)
 #pragma unroll
             for (int k = 0; k < N; ++k) { acc[m][k] = T(0); acc2[m][k] = T(0); }
-        // A row costs a wave ~100 clocks of multiply-adds and its gather one to two microseconds: SC_PF rows are kept in flight per
+        // A row costs a wave ~100 clocks of multiply-adds and its gather one to two microseconds: SC_PF (3 / 4) rows are kept in flight per
         // wave (gene chunk, weights, descriptor), and descriptors are requested another SC_PF rows ahead, so that neither a row's load
         // address nor its multiply-adds wait for an LDS or memory round trip issued in the same row.  A row's weights are contiguous
         // in sorted pair order: lanes 0..7 fetch its (at most GC) pairs with one LDS read, a member's weight is then broadcast out of
         // that register by v_readlane (wave-uniform lane number = how many members of the mask came before).
-        constexpr int SC_PF = 4;
+        constexpr int SC_PF = sizeof(T) == 8 ? 3 : 4;               // (f64: 2 / 3 / 4 / 5 rows in flight 105.4 / 84.9 / 88.4 / 95.6 ms; f32: 2 / 3 / 4 50.4 / 46.1 / 44.9)
         auto desc_at = [&](int r) { return desc[min(r, max(U - 1, 0))]; };
         // f32: lanes 0..7 hold the row's pairs in sorted order (the j-th member of the mask in lane j, handed out by v_readlane);
         // f64: lane m of every 16-lane row holds MEMBER m's pair (first pair + members of the mask below m), read through DPP
