@@ -402,3 +402,41 @@ def test_atlas_memory_plan_for_one_million_cells():
     assert one["block_Sx_Ux_GB"] < 20 and one["csr_layers_with_halo_GB"] < 40 and one["total_GB"] < 288
     dense = 1_000_000 * 30_016 * 4 * 2 / 1e9
     assert one["total_GB"] < 0.5 * dense                   # against Sx + Ux resident (240 GB)
+
+
+def test_dpp_operands_of_the_scaling_kernel_are_not_fresh_valu_results(tmp_path):
+    """k_embedding_scaling<double> reads a member's weights through `v_fmac_f64_dpp ... row_newbcast` written as inline asm
+    (csrc/scaling.hip: fmac_bcast).  gfx9 needs two wait states between a VALU write of a VGPR and a DPP read of it, and the
+    compiler's hazard recogniser does not look inside an asm statement: the listing must not hold a VALU instruction that writes
+    the DPP operand within the two instructions before it (the weights come straight from an LDS read)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "scaling.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-I" + os.path.join(root, "include"),
+                        os.path.join(root, "velocyto.py_amd", "csrc", "scaling.hip"), "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+    def regs(tok):
+        m = re.match(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"v(\d+)$", tok)
+        return {int(m.group(1))} if m else set()
+
+    instrs = [l.strip() for l in out.read_text().split("\n") if l.startswith("\t") and not l.strip().startswith((".", ";"))]
+    seen = 0
+    for i, l in enumerate(instrs):
+        if not l.startswith("v_fmac_f64_dpp"):
+            continue
+        seen += 1
+        src0 = regs([o.strip() for o in l.split(None, 1)[1].split(",")][1])
+        for back in (1, 2):
+            p = instrs[i - back]
+            if p.startswith("v_") and not p.startswith("v_cmp"):
+                dst = p.split(None, 1)[1].split(",")[0].strip()
+                assert not (regs(dst) & src0), f"{p}  ->  {l}"
+    assert seen >= 96                                      # 8 members x 2 elements x (1 + 2) weight sets x 3 rows in flight, at least

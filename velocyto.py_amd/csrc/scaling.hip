@@ -34,6 +34,8 @@ template <typename T> struct W2 { T a, b; };
 
 // acc += w(lane M of the own 16-lane row) * x: the f64 multiply-add reads its first operand through DPP row_newbcast (the one DPP
 // control the double-precision ALU has), so a member's weight needs no v_readlane and no SGPR - it only has to sit in lane M of every row
+// (A DPP read of a VGPR needs two wait states after a VALU write of it and the compiler does not see inside an asm statement: the weights
+// come straight from an LDS read; tests/test_host_and_abi.py checks the listing for a VALU write of the operand in the two slots before.)
 template <int M> __device__ __forceinline__ void fmac_bcast(double &acc, double w, double x)
 {
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(x), "n"(M));
