@@ -21,6 +21,7 @@ ARCH = "gfx950"
 _lib = None
 
 c_i64, c_int, c_dbl, c_vp, c_sz = ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t
+EXPECTED_ABI = 2                  # vcy_abi_version() of the header this table mirrors
 
 # name -> (restype, argtypes); mirrors include/velocyto_hip.h one to one
 SIGNATURES = {
@@ -157,6 +158,9 @@ def lib() -> ctypes.CDLL:
             fn = getattr(L, name)   # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
+        if L.vcy_abi_version() != EXPECTED_ABI:     # same symbols, other argument lists: never call into it
+            raise RuntimeError(f"{LIB_PATH} has ABI version {L.vcy_abi_version()}, this binding was written against {EXPECTED_ABI} "
+                               "(include/velocyto_hip.h): rebuild it with `python -c 'import __graft_entry__ as g; g.build()'`")
         _lib = L
     return _lib
 
