@@ -84,7 +84,8 @@ def parse():
     ap.add_argument("--pca-dims", type=int, default=30)
     ap.add_argument("--n-neighbors", type=int, default=500)
     ap.add_argument("--sampled-fraction", type=float, default=0.5)
-    ap.add_argument("--cpu-cells", type=int, default=512, help="cells of the closed CPU-baseline sub-problem")
+    ap.add_argument("--cpu-cells", type=int, default=256, help="cells of the closed CPU-baseline sub-problem (stages A-C, parity of the HIP path); "
+                                                                "stage D is timed at full width beside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass of THIS command; without it "
@@ -95,8 +96,9 @@ def parse():
     ap.add_argument("--density", type=float, default=0.08, help="cfg5: fraction of non-zero counts per cell")
     ap.add_argument("--block-cells", type=int, default=0, help="cfg5: cells per streamed block (0 = chosen from free HBM)")
     ap.add_argument("--knn", choices=["auto", "brute", "pruned"], default="auto", help="cfg5: exact kNN search by brute force or projection-pruned (auto: pruned from 100k cells)")
-    ap.add_argument("--counts", choices=["auto", "u16"], default="auto",
-                    help="storage of the resident count layers: auto = uint8 when no count exceeds 255, else uint16; u16 forces uint16")
+    ap.add_argument("--counts", choices=["auto", "u16"], default="u16",
+                    help="storage of the resident count layers: u16 = uint16, the loom's on-disk type (constants.py:11; the headline); auto = what "
+                         "ops.CountMatrix.narrowed() keeps for this dataset: uint8 when no count exceeds 255 (lossless), else uint16")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f64", help="arithmetic / storage type of the timed path (f64 = the reference's, the headline; "
                                                                          "f32 = the build's production mode)")
     ap.add_argument("--no-extra", action="store_true", help="skip precision_modes and the extra lines (E, F, default fit_gammas, nrndm = 3000, randomised control, cfg2)")
@@ -272,6 +274,10 @@ class Pipeline:
         self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(12)]
         self.stage_ms = np.zeros(7)
         self.d_ms = []
+        # shader clock WHILE stage D runs, measured in this run (ops.ClockProbe: one wave per XCD on a side stream reads the shader-clock
+        # counter against the 100 MHz counter every 2 ms; it starts when the main stream reaches stage D and ends before D does)
+        self.probe = ops.ClockProbe() if world == 1 else None
+        self.probe_samples = []
 
     def step(self, timed=False):
         ops, a = self.ops, self.a
@@ -305,6 +311,10 @@ class Pipeline:
         if not a.fuse:
             dmat = ops.velocity_chain(self.Sx_loc, self.Ux_loc, gamma, None, want=("dmat",), transform=ops.SQRT, psc=1e-10)["dmat"]
         ev[3].record()
+        if timed and self.probe is not None and self.d_ms:       # (the first timed step tells how long D takes; the later ones are probed)
+            self.probe.stream.wait_event(ev[3])
+            self.probe.start(0.9 * self.d_ms[-1])
+            self.probe_samples.append(self.probe.samples)
         # ---- D: colDeltaCorSqrtpartial; sharded: every rank needs the rows of e = Sx_sz its neighbour lists reference
         if self.rules is None:                   # decided once, on the first pooled matrix, from whole-matrix reductions all-reduced over the
             #                                      ranks (one host sync; every rank takes the same decision; see ops.partial_rules_for)
@@ -349,6 +359,19 @@ class Pipeline:
             self.d_ms.append(t_d)
         self.last_gamma = gamma
         return gamma
+
+    def stage_d_clock(self):
+        """(mean, min, max) GHz of the shader clock over the probed stage-D launches of this pipeline, or None."""
+        if not self.probe_samples:
+            return None
+        torch.cuda.synchronize()
+        f = []
+        for smp in self.probe_samples:
+            x = smp.cpu().numpy().astype(np.float64)
+            dc, dr = np.diff(x[:, :, 0], axis=1), np.diff(x[:, :, 1], axis=1)
+            f.append(dc / np.maximum(dr, 1.0) * 0.1)
+        f = np.concatenate([v.ravel() for v in f])
+        return {"mean": float(f.mean()), "min": float(f.min()), "max": float(f.max()), "launches": len(self.probe_samples), "readings": int(f.size)}
 
     def time_dual(self, reps=3):
         """Stage D with the randomised control of estimate_transition_prob (analysis.py:1539-1542): one dual-control launch
@@ -420,16 +443,99 @@ def hip_subproblem(pipe, args, Cs, ixs, dtype, rules):
     return Sx, gamma, corr
 
 
+def _host_genes_major(work, name, M, block=1500):
+    """The (genes, cells) fp64 form of a cells-major device matrix as <work>/<name>.npy, written gene block by gene block through a pinned
+    buffer (no second host copy).  Returns the memory map."""
+    C, G = M.C, M.G
+    mm = np.lib.format.open_memmap(os.path.join(work, name + ".npy"), mode="w+", dtype=np.float64, shape=(G, C))
+    pin = torch.empty((block, C), dtype=torch.float64, pin_memory=True)
+    for g0 in range(0, G, block):
+        g1 = min(G, g0 + block)
+        pin[:g1 - g0].copy_(M.t[:, g0:g1].t().to(torch.float64))
+        mm[g0:g1] = pin[:g1 - g0].numpy()
+    return mm
+
+
+def cpu_full_width(pipe, args):
+    """Stage D on the host cores AS THE REFERENCE READS IT (speedboosted.pyx:366-378): e and d are the FULL fp64
+    (genes, cells) matrices of the run (12 GB each at 50 000 x 30 000, built once from the device matrices into a RAM-backed directory), the
+    neighbour lists are the run's own, so every gather e[j * cols + i] has the stride of all 50 000 columns.
+      * the reference's OWN kernel (oracle/_ref): it has no cell range, so it is started over all columns and the rows it has finished are
+        counted at two instants before it is stopped (oracle.reference_coldeltacor_rate), at the reference's thread rule cpu_count() / 2
+        (estimation.py:27-28);
+      * the restatement (oracle/velocyto_oracle.c, the same loop order and scratch) on the first cells of the run, at cpu_count() / 2 and at
+        all cores."""
+    import shutil
+    import tempfile
+    import oracle
+    import psutil
+    ops = pipe.ops
+    C, G, nr = args.cells, args.genes, pipe.nrndm
+    cores = os.cpu_count() or 1
+    need = 2 * C * G * 8 + cores * G * nr * 8 * 2.2 + (8 << 30)          # e, d, the kernels' scratch (A and A - mean per thread), slack
+    avail = psutil.virtual_memory().available
+    if not os.path.isdir("/dev/shm") or avail < need or shutil.disk_usage("/dev/shm").free < 2 * C * G * 8 + (4 << 30):
+        return {"skipped": f"host memory: {avail / 2**30:.0f} GiB available, {need / 2**30:.0f} GiB needed for the full-width matrices and the kernels' scratch"}
+    t_all = time.perf_counter()
+    # the run's own pooled matrices, gammas and correlations (a fresh pipeline on the same resident inputs: the extra lines freed the first one's buffers)
+    pipe = Pipeline(args, pipe.dev, 0, 1, dtype=torch.float64, data=(pipe.cS, pipe.cU, pipe.fS, pipe.fU, pipe.pcs), counts=args.counts)
+    pipe.step()
+    gamma = pipe.last_gamma
+    dmat = ops.velocity_chain(pipe.Sx_loc, pipe.Ux_loc, gamma, None, want=("dmat",), transform=ops.SQRT, psc=1e-10)["dmat"]
+    work = tempfile.mkdtemp(prefix="vcy_cpu_", dir="/dev/shm")
+    try:
+        e = _host_genes_major(work, "e", pipe.Sx_loc)
+        d = _host_genes_major(work, "d", dmat)
+        del dmat
+        t_build = time.perf_counter() - t_all
+        ixs = pipe.neigh.cpu().numpy().astype(np.intp)
+        half = max(1, cores // 2)
+        out = {"e_stride_cells": C, "genes": G, "nrndm": nr, "host_matrices_GB": 2 * C * G * 8 / 1e9, "build_s": t_build}
+        # ---- the restatement on the first cells, both thread counts (two cells per thread: a second round shows the imbalance of the first)
+        rest = {}
+        hip = pipe.corr_loc.double().cpu().numpy()
+        for th in (half, cores):
+            n = min(C, 2 * th)
+            t0 = time.perf_counter()
+            cc = oracle.coldeltacor_partial_compact(e, d, ixs, "sqrt", 1e-10, threads=th, c0=0, c1=n)
+            dt = time.perf_counter() - t0
+            ok = np.isfinite(cc[:n])
+            rest[f"{th}_threads"] = {"cells": n, "seconds": dt, "cells_per_s": n / dt,
+                                     "max_abs_dcorr_hip_vs_restatement": float(np.abs(cc[:n][ok] - hip[:n][ok]).max()),
+                                     "nan_pattern_equal": bool(np.array_equal(np.isnan(cc[:n]), np.isnan(hip[:n])))}
+        out["restatement"] = rest
+        # ---- the reference's own kernel over all columns, stopped after its second reading
+        if oracle.reference_module_path() is not None:
+            try:
+                out["reference_kernel"] = {**oracle.reference_coldeltacor_rate(work, ixs, "sqrt", 1e-10, threads=half, t_first=5.0, t_second=13.0),
+                                           "kernel": "velocyto/speedboosted.pyx _colDeltaCorSqrtpartial (oracle/_ref), all columns started, rows finished between two readings",
+                                           "thread_rule": "cpu_count() / 2 (estimation.py:27-28)"}
+            except Exception as ex:                                          # noqa: BLE001
+                out["reference_kernel"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+        else:
+            out["reference_kernel"] = {"absent": oracle.reference_module_status()[1]}
+        out["wall_s"] = time.perf_counter() - t_all
+        return out
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def cpu_baseline(pipe, args):
-    """The oracle restatement (oracle/velocyto_oracle.c with OpenMP + oracle/oracle.py; pinned against the reference's own
-    outputs in tests/test_oracle_golden.py) for all four stages on a closed sub-problem of `cpu_cells` cells (all genes, same
-    k / nrndm).  Nothing built from the reference runs on the GPU box.  The oracle's numbers are not thrown away: the HIP path
-    runs the SAME sub-problem in its three arithmetic modes and `parity` reports how far each is from the fp64 restatement."""
+    """The CPU side of the path on the GPU box's host cores.
+
+    (1) Stage D - 98 % of the CPU time - at FULL WIDTH (cpu_full_width): the reference's own kernel and the restatement reading the run's
+        50 000-column matrices with the run's neighbour lists.  This is `value`.
+    (2) A closed sub-problem of `cpu_cells` cells (all genes, same k / nrndm) for everything else: stages A - C by the oracle restatement
+        (their per-cell cost enters `value`), stage D by both kernels once more (the e matrix fits the caches here: the figure the earlier
+        rounds quoted, kept for comparison), and the HIP path on the SAME sub-problem in its three arithmetic modes: `parity` reports how far
+        each is from the fp64 restatement.
+    The oracle is the checker and the baseline here, never the thing measured as the product."""
     import oracle
     ops = pipe.ops
     Cs = min(args.cpu_cells, args.cells)
     G = args.genes
     cores = os.cpu_count() or 1
+    half = max(1, cores // 2)
     cnt = lambda cm: cm.as_int32(0, Cs).double()
     S = (cnt(pipe.cS) * pipe.fS[:Cs, None]).cpu().numpy().T.copy()     # S_sz in the reference's (G, Cs) layout
     U = (cnt(pipe.cU) * pipe.fU[:Cs, None]).cpu().numpy().T.copy()
@@ -451,17 +557,15 @@ def cpu_baseline(pipe, args):
     t0 = time.perf_counter()
     corr = oracle.coldeltacor_partial_compact(Sx, dmat, ixs, "sqrt", 1e-10, threads=cores)
     tD = time.perf_counter() - t0
-    total = tA + tB + tC + tD
-    # ---- stage D by the REFERENCE'S OWN kernel where oracle/_ref travelled with the snapshot (speedboosted.pyx built with the
-    #      reference's flags by oracle/build_ref.py; run in a subprocess, see oracle.reference_coldeltacor).  Its threads hold 60 MB
-    #      of scratch each (G x nrndm fp64): at most 64 of them.
+    # ---- stage D of the closed sub-problem by the REFERENCE'S OWN kernel where oracle/_ref travelled with the snapshot (speedboosted.pyx
+    #      built with the reference's flags by oracle/build_ref.py; run in a subprocess), at the reference's thread rule
     ref = None
     if oracle.reference_module_path() is not None:
         try:
-            rthreads = min(cores, 64)
-            corr_ref, tD_ref = oracle.reference_coldeltacor(Sx, dmat, ixs, "sqrt", 1e-10, threads=rthreads)
+            corr_ref, tD_ref = oracle.reference_coldeltacor(Sx, dmat, ixs, "sqrt", 1e-10, threads=half)
             okr = np.isfinite(corr_ref) & np.isfinite(corr)
-            ref = {"D_s": tD_ref, "threads": rthreads, "kernel": "velocyto/speedboosted.pyx _colDeltaCorSqrtpartial, built with the reference's flags (oracle/build_ref.py)",
+            ref = {"D_s": tD_ref, "threads": half, "cells_per_s": Cs / tD_ref,
+                   "kernel": "velocyto/speedboosted.pyx _colDeltaCorSqrtpartial, built with the reference's flags (oracle/build_ref.py)",
                    "max_abs_dcorr_restatement_vs_reference": float(np.abs(corr_ref[okr] - corr[okr]).max()),
                    "nan_pattern_equal": bool(np.array_equal(np.isnan(corr_ref), np.isnan(corr)))}
         except Exception as e:                                                  # noqa: BLE001 - the baseline falls back to the restatement
@@ -485,20 +589,38 @@ def cpu_baseline(pipe, args):
                         "max_rel_dgamma": float((np.abs(hg[pos] - gam0[pos]) / gam0[pos]).max()),
                         "max_rel_dSx": float((np.abs(sx - Sx) / np.maximum(np.abs(Sx), 1e-30))[Sx != 0].max())}
         del hSx, hg, hc, sx
-    port = {"value": Cs / total, "cores": cores, "stage_s": {"A": tA, "B": tB, "C": tC, "D": tD}}
-    if ref is not None and "D_s" in ref:
-        total_ref = tA + tB + tC + ref["D_s"]
-        return {"value": Cs / total_ref, "unit": "cells/s", "cores": ref["threads"], "kind": "reference",
-                "sample": f"closed sub-problem of {Cs} cells x {G} genes, k={min(args.k, Cs - 1)}, nrndm={nr}: stage D ({100.0 * ref['D_s'] / total_ref:.0f} % of the "
-                          f"CPU time) by the reference's own Cython kernel on {ref['threads']} threads ({ref['D_s']:.2f} s), stages A-C by the oracle "
-                          f"restatement (A {tA:.2f} s, B {tB:.2f} s, C {tC:.2f} s); the restatement's stage D on {cores} threads: {tD:.2f} s",
-                "stage_s": {"A": tA, "B": tB, "C": tC, "D": ref["D_s"]}, "reference_kernel": ref, "restatement": port, "parity": parity}
-    return {"value": Cs / total, "unit": "cells/s", "cores": cores, "kind": "port",
-            "sample": f"closed sub-problem of {Cs} cells x {G} genes, k={min(args.k, Cs - 1)}, nrndm={nr}, all four stages by the oracle "
-                      f"restatement (C + OpenMP on {cores} threads for pooling and stage D, NumPy/SciPy for the rest): A {tA:.2f} s, B {tB:.2f} s, "
-                      f"C {tC:.2f} s, D {tD:.2f} s; the per-cell cost of D does not depend on the number of cells, the O(C^2) kNN is cheaper at this "
-                      "size (favours the CPU)",
-            "stage_s": {"A": tA, "B": tB, "C": tC, "D": tD}, "parity": parity, **({"reference_kernel": ref} if ref is not None else {})}
+    closed = {"cells": Cs, "stage_s": {"A": tA, "B": tB, "C": tC, "D_restatement": tD, **({"D_reference": ref["D_s"]} if ref and "D_s" in ref else {})},
+              "restatement_threads": cores, "reference_kernel": ref,
+              "note": f"closed sub-problem: {Cs} cells x {G} genes, k={min(args.k, Cs - 1)}, nrndm={nr}; its e matrix is {Cs * G * 8 / 1e6:.0f} MB and the lists index "
+                      f"{Cs} columns (row stride {Cs * 8} B): kinder to the CPU than the run's {args.cells} columns"}
+    abc_per_cell = (tA + tB + tC) / Cs
+    # ---- full width
+    try:
+        full = cpu_full_width(pipe, args) if (args.cells >= 4 * Cs and pipe.world == 1 and pipe.dtype == torch.float64) else {"skipped": "the run is not larger than the closed sub-problem, or not the f64 single-GPU pass"}
+    except Exception as e:                                                      # noqa: BLE001
+        torch.cuda.synchronize()
+        full = {"error": f"{type(e).__name__}: {e}"[:300]}
+    rk = full.get("reference_kernel") or {}
+    rs = full.get("restatement") or {}
+    if "cells_per_s" in rk:
+        dps, kind, th = rk["cells_per_s"], "reference", rk["threads"]
+        what = (f"stage D by the reference's own Cython kernel over the run's full {args.cells}-column fp64 matrices (stride {args.cells} cells = {args.cells * 8} B between "
+                f"the genes of a cell) with the run's neighbour lists, {th} threads = cpu_count() / 2 (estimation.py:27-28): {rk['rows_second'] - rk['rows_first']} cells finished "
+                f"between {rk['t_first']:.1f} s and {rk['t_second']:.1f} s of a run over all columns, then stopped")
+    elif rs:
+        best = max(rs.values(), key=lambda r: r["cells_per_s"])
+        dps, kind, th = best["cells_per_s"], "port", [int(k.split("_")[0]) for k, v in rs.items() if v is best][0]
+        what = (f"stage D by the oracle restatement (the reference's loop order and scratch) on the first {best['cells']} cells of the run over the full {args.cells}-column "
+                f"fp64 matrices, {th} threads")
+    else:
+        dps = Cs / (ref["D_s"] if ref and "D_s" in ref else tD)
+        kind, th = ("reference", ref["threads"]) if ref and "D_s" in ref else ("port", cores)
+        what = f"stage D on the CLOSED sub-problem only (full width not run: {full.get('skipped') or full.get('error')})"
+    value = 1.0 / (1.0 / dps + abc_per_cell)
+    return {"value": value, "unit": "cells/s", "cores": th, "host_cores": cores, "kind": kind,
+            "sample": what + f"; stages A-C by the oracle restatement on the closed sub-problem of {Cs} cells ({abc_per_cell * 1e3:.2f} ms per cell, "
+                             f"{100.0 * abc_per_cell * value:.1f} % of the CPU time per cell)",
+            "stage_D_cells_per_s": dps, "full_width": full, "closed_subproblem": closed, "parity": parity}
 
 
 def load_counters(dtype="f32"):
@@ -532,7 +654,7 @@ def dominant_roofline(a, pipe, d_ms, dtype):
     if cnt.get("rules") != pipe.rules:                               # the committed counters are of the other branch rule
         cnt = {}
     instr = cnt.get("valu_insts_per_pair_chunk", None)
-    default_wl = (C, G, nr, a.k, pipe.world, a.order, a.fuse, a.curve, a.counts) == (50000, 30000, 250, 30, 1, "embedding", True, "hilbert", "auto")
+    default_wl = (C, G, nr, a.k, pipe.world, a.order, a.fuse, a.curve) == (50000, 30000, 250, 30, 1, "embedding", True, "hilbert")
     traffic = a.traffic_bytes if (a.traffic_bytes is not None and dtype == a.dtype) else (cnt.get("hbm_bytes_per_launch") if default_wl else None)
     rule_name = pipe.ops.RULE_NAMES.get(pipe.rules, str(pipe.rules))
     shape = "8 cells, 6 vectors" if s == 4 else "6 cells, 8 vectors"
@@ -541,35 +663,47 @@ def dominant_roofline(a, pipe, d_ms, dtype):
             "unit": "Ginstr/s", "peak": VALU_ISSUE_PEAK / 1e9, "avg_launch_ms": d_ms,
             "peak_is": "VALU issue: 1024 SIMD-32 x 2.4 GHz / 2 clocks per wave64 instruction (MI355X_MICROARCH.md); f32 plain ops measure 2.25 clocks" +
                        (f", f64 add / mul / fma {F64_ISSUE_CLK} (profiles/r04_valu_issue_f64.txt) - see frac_of_f64_issue_peak" if s == 8 else "")}
+    # the shader clock of THIS run's stage-D launches (Pipeline.stage_d_clock: vcy_clock_probe on a side stream while D runs); everything
+    # that comes from the committed rocprofv3 passes of another run is named profile_*
+    clk = pipe.stage_d_clock()
+    ghz = clk["mean"] if clk else None
+    if clk:
+        roof.update({"effective_clock_ghz": ghz, "effective_clock": {**clk, "how": "vcy_clock_probe: one wave per XCD reads the shader-clock counter (s_memtime) against "
+                     "the 100 MHz counter (s_memrealtime) every 2 ms on a side stream while the stage-D launches of the timed steps run (all but the first)"}})
     if instr is not None:
         achieved = instr * pair_chunks / (d_ms * 1e-3)
         roof.update({"achieved": achieved / 1e9, "frac": achieved / VALU_ISSUE_PEAK,
-                     "valu_insts_per_launch": instr * pair_chunks, "counters_from": os.path.relpath(cnt_path, ROOT),
-                     "wave_time": cnt.get("wave_time")})
+                     "valu_insts_per_launch": instr * pair_chunks, "profile_valu_insts_per_pair_chunk": instr, "counters_from": os.path.relpath(cnt_path, ROOT),
+                     "profile_wave_time": cnt.get("wave_time"), "profile_effective_clock_ghz": cnt.get("effective_clock_ghz"),
+                     "profile_launch_ms": cnt.get("profiled_launch_ms")})
         if s == 8:
             roof["frac_of_f64_issue_peak"] = achieved / (VALU_ISSUE_PEAK * 2.0 / F64_ISSUE_CLK)
-        ghz = cnt.get("effective_clock_ghz")
         if ghz:
-            # the chip clocks to its power budget (MI355X_MICROARCH.md, DVFS): GRBM_GUI_ACTIVE / launch time of the profiled launch
-            roof.update({"effective_clock_ghz": ghz, "frac_at_effective_clock": achieved / (VALU_ISSUE_PEAK * ghz / 2.4)})
+            # the chip clocks to its power budget (MI355X_MICROARCH.md, DVFS)
+            roof["frac_at_effective_clock"] = achieved / (VALU_ISSUE_PEAK * ghz / 2.4)
+            if s == 8:
+                roof["frac_of_f64_issue_peak_at_effective_clock"] = achieved / (VALU_ISSUE_PEAK * 2.0 / F64_ISSUE_CLK * ghz / 2.4)
     else:
         roof.update({"achieved": None, "frac": None, "counters_from": None})
     mix = MIX_CLK_PER_ELEMENT.get(pipe.rules) if s == 4 else (MIX_CLK_PER_ELEMENT_F64 if pipe.rules == 1 else None)
     if mix:
         mix_floor_ms = pair_genes * mix / 64.0 / (1024 * 2.4e9) * 1e3
         roof.update({"mix_clk_per_element": mix, "mix_floor_ms": mix_floor_ms, "frac_of_mix_floor": mix_floor_ms / d_ms})
-        ghz = cnt.get("effective_clock_ghz")
         if ghz:
             roof["frac_of_mix_floor_at_effective_clock"] = mix_floor_ms * 2.4 / ghz / d_ms
-    roof.update({"traffic": traffic, "hbm_frac_measured": (traffic / (d_ms * 1e-3) / HBM_PEAK) if traffic else None,
+    roof.update({"traffic": traffic, "traffic_from": ("--traffic-bytes (a --pmc pass of this command)" if (a.traffic_bytes is not None and dtype == a.dtype) else
+                                                      (os.path.relpath(cnt_path, ROOT) + " (the profiled launch of the same kernel and workload)") if traffic else None),
+                 "hbm_frac_measured": (traffic / (d_ms * 1e-3) / HBM_PEAK) if traffic else None,
                  "algorithmic_bytes_per_launch": alg_bytes, "vs_noreuse_model": alg_bytes / (d_ms * 1e-3) / HBM_PEAK,
                  "note": "VALU-issue-bound: `achieved` = SQ_INSTS_VALU of this kernel (rocprofv3 pass in counters_from, per pair-chunk, scaled "
                          "by this run's exact pair-chunk count) / HIP-event launch time; `frac` is against the issue peak of one plain "
                          "instruction per 2 clocks per SIMD at 2.4 GHz.  Two things keep a correct kernel away from that peak and are reported beside it: "
                          "(1) the mix the arithmetic needs is slower than plain instructions (v_rsq_f32 8 clocks, f64 add / mul / fma 4, v_rsq_f64 12.5): "
                          "`mix_floor_ms` is the issue time of that mix alone at the measured rates (tools/ubench/valu_issue*.hip), `frac_of_mix_floor` = "
-                         "mix_floor_ms / launch time; (2) the chip does not hold 2.4 GHz under this load: `effective_clock_ghz` = GRBM_GUI_ACTIVE per XCD / "
-                         "duration of the profiled launch, `*_at_effective_clock` are the same fractions at that clock.  HBM is not the limit: "
+                         "mix_floor_ms / launch time; (2) the chip does not hold 2.4 GHz under this load: `effective_clock_ghz` is measured in THIS run while stage D "
+                         "executes (`effective_clock.how`), `*_at_effective_clock` are the same fractions at that clock; the instruction count per pair-chunk, "
+                         "`profile_wave_time`, `profile_effective_clock_ghz` (GRBM_GUI_ACTIVE per XCD / duration) and `traffic` are of the PROFILED launch "
+                         "named in `counters_from` / `traffic_from`, another run of the same binary.  HBM is not the limit: "
                          "`traffic` (2*FETCH_SIZE + WRITE_SIZE of the PMC passes) is `hbm_frac_measured` of 8 TB/s; `vs_noreuse_model` "
                          "is SURVEY 8(d)'s no-reuse byte model over launch time over 8 TB/s (above 1: neighbour rows are shared by the "
                          "cells of a group out of LDS and by adjacent groups out of L2)."})
@@ -689,8 +823,9 @@ def run(a, rank, local_rank, world):
                                    f"{a.pca_dims} PCs) -> fit_slope -> velocity chain -> colDeltaCorSqrtpartial(nrndm={nr}, "
                                    f"n_neighbors={a.n_neighbors}, sampled_fraction={a.sampled_fraction}, psc=1e-10)",
                        "cells": C, "genes": G, "k": a.k, "nrndm": nr,
-                       "inputs": f"spliced/unspliced count layers ({'uint8, no count above 255' if pipe.cS.t.dtype == torch.uint8 else 'uint16'}) + per-cell size factors "
-                                 "(S_sz = factor*counts), pcs, sampled neighbours",
+                       "inputs": f"spliced/unspliced count layers ({'uint8: narrowed, no count of this dataset exceeds 255' if pipe.cS.t.dtype == torch.uint8 else 'uint16, the loom type of constants.py:11'}) "
+                                 "+ per-cell size factors (S_sz = factor*counts), pcs, sampled neighbours",
+                       "count_layer_dtype": "uint8" if pipe.cS.t.dtype == torch.uint8 else "uint16",
                        "parallelism": "single GPU" if world == 1 else f"cells sharded over {world} GPUs in embedding ({a.curve} curve) order; RCCL "
                                       "all-reduce of fit moments, " + (f"halo exchange of Sx rows into a compact own+halo buffer (all_to_all, {pipe.plan.n_recv} "
                                       f"of {C} rows received by rank 0" + (f"; overlapped with stage D of {int(pipe.sched[0].numel())} of the {pipe.n_interior} interior cells of {nloc}: whole device rounds)"
@@ -707,7 +842,7 @@ def run(a, rank, local_rank, world):
                        "cell_order_D": a.order + (f" ({a.curve} curve)" if a.order == "embedding" else "")},
             "roofline": roof, "stages": stages,
         }
-        if world == 1 and not a.no_extra and a.counts == "auto":
+        if world == 1 and not a.no_extra:
             res["precision_modes"], res["extra"] = extra_lines(a, dev, pipe, res)
             # the key numbers of the extra lines as scalars of `config` (the driver's record keeps scalars)
             res["config"].update(extra_scalars(res["extra"], res["precision_modes"]))
@@ -894,7 +1029,7 @@ def extra_lines(a, dev, pipe, res):
     def other_modes():
         other = torch.float32 if main_f64 else torch.float64
         oname = "f32" if main_f64 else "f64"
-        po = Pipeline(a, dev, 0, 1, dtype=other, data=data)
+        po = Pipeline(a, dev, 0, 1, dtype=other, data=data, counts=a.counts)
         n = 3 if main_f64 else 2
         ms = _short(po, n)
         st = po.stage_ms / n
@@ -926,14 +1061,15 @@ def extra_lines(a, dev, pipe, res):
                                              "is": "the f32 run's stages A-C + one stage-D launch with VCY_RULES_PARTIAL (pseudocount kept)"}
             po.step()
             torch.cuda.synchronize()
-            if po.cS.t.dtype == torch.uint8:
+            if a.counts == "u16" and data[0].t.dtype == torch.uint8:
                 c32 = po.corr_loc.clone()
-                p16 = Pipeline(a, dev, 0, 1, dtype=torch.float32, data=data, counts="u16")
-                ms16 = _short(p16, 2)
-                modes["f32_uint16_layers"] = {"dtype": "f32", "ms_per_step": ms16, "cells_per_s": C / (ms16 * 1e-3), "A_pooling_ms": (p16.stage_ms / 2)[6],
-                                              "same_results_as_uint8": bool(torch.equal(p16.corr_loc, c32)),
-                                              "is": "the loom's on-disk count type (constants.py:11); taken when any count of a layer exceeds 255"}
-                del p16, c32
+                p8 = Pipeline(a, dev, 0, 1, dtype=torch.float32, data=data, counts="auto")
+                ms8 = _short(p8, 2)
+                modes["f32_uint8_layers"] = {"dtype": "f32", "ms_per_step": ms8, "cells_per_s": C / (ms8 * 1e-3), "A_pooling_ms": (p8.stage_ms / 2)[6],
+                                             "same_results_as_uint16": bool(torch.equal(p8.corr_loc, c32)),
+                                             "is": "f32_production with the count layers narrowed to uint8 (ops.CountMatrix.narrowed: lossless, no count of this "
+                                                   "dataset exceeds 255)"}
+                del p8, c32
         del po
         torch.cuda.empty_cache()
         return None
@@ -941,6 +1077,25 @@ def extra_lines(a, dev, pipe, res):
     failed = modes.pop("_modes", None)
     if failed:
         modes["not_measured"] = failed
+
+    def narrowed_layers():
+        """The headline pass with the count layers narrowed to uint8 where that is lossless (what the product's upload keeps for this dataset,
+        ops.CountMatrix.narrowed), timed with the headline's --steps: `value` is on uint16 layers, the loom's own type (constants.py:11)."""
+        if not (a.counts == "u16" and data[0].t.dtype == torch.uint8):
+            return {"skipped": "the dataset's layers do not narrow (a count above 255) or the headline already runs on the narrowed layers"}
+        p8 = Pipeline(a, dev, 0, 1, dtype=torch.float64 if main_f64 else torch.float32, data=data, counts="auto")
+        ms8 = _short(p8, a.steps)
+        st = p8.stage_ms / a.steps
+        ok = torch.isfinite(p8.corr_loc)
+        r = {"dtype": a.dtype, "steps": a.steps, "warmup": 1, "ms_per_step": ms8, "cells_per_s": C / (ms8 * 1e-3), "A_pooling_ms": st[6], "D_ms": float(np.mean(p8.d_ms)),
+             "same_results_as_uint16": bool(torch.equal(p8.corr_loc[ok], corr_main[ok]) and torch.equal(torch.isnan(p8.corr_loc), torch.isnan(corr_main))),
+             "vs_headline": C / (ms8 * 1e-3) / res["value"],
+             "is": "the headline pass with uint8 count layers (1 byte per count gathered by the pooling instead of 2): lossless for this dataset, "
+                   "not what a loom delivers"}
+        del p8
+        torch.cuda.empty_cache()
+        return r
+    guarded(f"{a.dtype}_uint8_layers", narrowed_layers, store=modes)
     modes["headline"] = {"dtype": a.dtype, "cells_per_s": res["value"], "ms_per_step": res["ms_per_step"], "D_ms": d_main,
                          "stage_D_rule": ops.RULE_NAMES.get(pipe.rules, str(pipe.rules)), "is": "`value`: the K timed steps of this run"}
     del corr_main
@@ -972,7 +1127,8 @@ def extra_scalars(extra, modes):
         if name in c2:
             out[f"cfg2_{name}_A_ms"] = c2[name]["A_knn_imputation_ms"]
             out[f"cfg2_{name}_B_ms"] = c2[name]["B_fit_slope_ms"]
-    for key, short in (("f32_production", "f32_production"), ("f32_literal_rule", "f32_literal"), ("f64_reference_arithmetic", "f64")):
+    for key, short in (("f32_production", "f32_production"), ("f32_literal_rule", "f32_literal"), ("f64_reference_arithmetic", "f64"),
+                       ("f64_uint8_layers", "f64_uint8_layers"), ("f32_uint8_layers", "f32_uint8_layers")):
         if key in modes and "cells_per_s" in modes[key]:
             out[f"{short}_cells_per_s"] = modes[key]["cells_per_s"]
     return out

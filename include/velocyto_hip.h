@@ -58,11 +58,18 @@ typedef enum {
 typedef void *vcy_stream;  /* hipStream_t */
 
 const char *vcy_last_error(void);
-/* 2 (round 4).  History: 1 -> 2: vcy_diffuse_step_factored gained `int prepared` before compute_dtype; vcy_gram and vcy_embedding_scaling added;
- * vcy_knn_pool_csr requires >= 4 stored elements.  A binder refuses a library whose version it was not built against. */
+/* 3 (round 5).  History: 1 -> 2: vcy_diffuse_step_factored gained `int prepared` before compute_dtype; vcy_gram and vcy_embedding_scaling added;
+ * vcy_knn_pool_csr requires >= 4 stored elements.  2 -> 3: vcy_clock_probe added.  A binder refuses a library whose version it was not built
+ * against (velocyto_amd/_lib.py: EXPECTED_ABI). */
 int vcy_abi_version(void);
 /* Number of CUs / LDS bytes per workgroup of the current device (host query). */
 int vcy_device_info(int *cu_count, int *lds_bytes_per_block, int64_t *hbm_bytes);
+/* Measurement aid (no reference counterpart): the shader clock while other kernels run.  `nblocks` one-wave workgroups (workgroup b runs on
+ * XCD b % 8) each take `nsamples` readings, `interval_ticks` ticks of the constant 100 MHz counter apart, of (shader-clock counter,
+ * 100 MHz counter) into samples[b][i][2] (device int64).  The CUs run at the clock the power budget allows: between two readings
+ * d(shader) / d(100 MHz) x 0.1 is the clock in GHz.  Launch it on a side stream before the kernel of interest; it ends by itself after
+ * nsamples x interval_ticks (at most 3 s).                                                                                          */
+int vcy_clock_probe(int64_t *samples, int64_t nblocks, int64_t nsamples, int64_t interval_ticks, vcy_stream stream);
 
 /* ---------------------------------------------------------------- layout plumbing
  * (G,C) genes-major  <->  (C,ld) cells-major tiled transpose with optional dtype change.

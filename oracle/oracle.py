@@ -161,11 +161,29 @@ np.save(work + "/seconds.npy", np.array([dt]))
 """
 
 
-def reference_module_path() -> Optional[str]:
-    """Path of the compiled reference kernel module under oracle/_ref, or None where it was not built / did not travel."""
+def reference_module_status() -> Tuple[str, str]:
+    """("present", path) - a module this interpreter can load; ("unloadable", why) - oracle/_ref holds a module built for another
+    interpreter; ("absent", why) - nothing was built (no /root/reference where oracle/build_ref.py ran) or it did not travel."""
     import glob
+    import importlib.machinery
     hits = sorted(glob.glob(os.path.join(_HERE, "_ref", "speedboosted*.so")))
-    return hits[0] if hits else None
+    if not hits:
+        return "absent", "oracle/_ref holds no speedboosted*.so (oracle/build_ref.py builds it where /root/reference exists)"
+    for h in hits:
+        if any(os.path.basename(h) == "speedboosted" + suf for suf in importlib.machinery.EXTENSION_SUFFIXES):
+            return "present", h
+    return "unloadable", f"{', '.join(os.path.basename(h) for h in hits)}: built for another interpreter than this one ({importlib.machinery.EXTENSION_SUFFIXES[0]})"
+
+
+def reference_module_path() -> Optional[str]:
+    """Path of the compiled reference kernel module under oracle/_ref, or None where it was not built / did not travel / cannot be loaded."""
+    st, what = reference_module_status()
+    return what if st == "present" else None
+
+
+def reference_module_expected() -> bool:
+    """Whether this tree SHOULD have the reference kernels: a build happened (oracle/_ref exists) or could happen here (/root/reference)."""
+    return os.path.isdir(os.path.join(_HERE, "_ref")) or os.path.exists("/root/reference/velocyto/speedboosted.pyx")
 
 
 def reference_coldeltacor(emat, dmat, ixs=None, transform="linear", psc=0.0, threads=8) -> Tuple[np.ndarray, float]:
@@ -189,6 +207,87 @@ def reference_coldeltacor(emat, dmat, ixs=None, transform="linear", psc=0.0, thr
         if r.returncode != 0:
             raise RuntimeError("reference kernel subprocess failed:\n" + r.stderr[-2000:])
         return np.load(os.path.join(work, "out.npy")), float(np.load(os.path.join(work, "seconds.npy"))[0])
+
+
+_REF_RATE_RUNNER = r"""
+import importlib.util, sys, time, numpy as np
+so, work, name, threads, psc = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), float(sys.argv[5])
+spec = importlib.util.spec_from_file_location("speedboosted", so)
+m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+e, d = np.load(work + "/e.npy", mmap_mode="c"), np.load(work + "/d.npy", mmap_mode="c")      # copy-on-write maps: writable buffers, nothing copied
+ixs = np.load(work + "/ixs.npy")
+rm = np.load(work + "/rm.npy", mmap_mode="r+")
+args = [e, d, rm, ixs, threads] + ([] if name == "_colDeltaCorpartial" else [psc])
+np.save(work + "/started.npy", np.array([time.time()]))
+t0 = time.perf_counter()
+getattr(m, name)(*args)
+np.save(work + "/seconds.npy", np.array([time.perf_counter() - t0]))
+"""
+
+
+def reference_coldeltacor_rate(work: str, ixs, transform="sqrt", psc=1e-10, threads=8, t_first=6.0, t_second=16.0) -> dict:
+    """Cells per second of the reference's OWN partial kernel on a problem too large to run to the end: `work` holds e.npy and d.npy, the
+    full (genes, cells) fp64 matrices (put them on a RAM-backed file system; the kernel maps them copy-on-write), `ixs` the (cells, nrndm)
+    neighbour lists.  The kernel (speedboosted.pyx:352-443) has no cell range - it walks all columns under `schedule='guided'` - so it runs
+    in a subprocess over ALL of them with its (cells, cells) output as a sparse file in `work`, and the rows it has finished are counted from
+    outside at two instants: rate = (rows(t_second) - rows(t_first)) / (t_second - t_first) - rows in progress cancel, start-up is left out -
+    and the subprocess is killed.  A problem it finishes earlier gives cells / seconds.  Returns {"cells_per_s", "rows_first", "rows_second",
+    "t_first", "t_second", "threads", "finished"}."""
+    import signal
+    import sys
+    import time
+    so = reference_module_path()
+    if so is None:
+        raise FileNotFoundError("oracle/_ref holds no reference kernel module (oracle/build_ref.py builds it where /root/reference exists)")
+    name = _REF_KERNELS[({"log": "log10"}.get(transform, transform), True)]
+    ix = np.ascontiguousarray(ixs, dtype=np.intp)
+    C = ix.shape[0]
+    np.save(os.path.join(work, "ixs.npy"), ix)
+    rm = np.lib.format.open_memmap(os.path.join(work, "rm.npy"), mode="w+", dtype=np.float64, shape=(C, C))     # sparse: pages appear as rows are written
+    for f in ("started.npy", "seconds.npy"):
+        if os.path.exists(os.path.join(work, f)):
+            os.remove(os.path.join(work, f))
+    proc = subprocess.Popen([sys.executable, "-c", _REF_RATE_RUNNER, so, work, name, str(int(threads)), repr(float(psc))], stderr=subprocess.PIPE, text=True)
+    rows = np.arange(C)
+    probe = ix[:, 0]
+    done = lambda: int(np.count_nonzero(rm[rows, probe] != 0.0))           # (NaN != 0 too: a finished zero-variance pair counts)
+    try:
+        t_wait = time.time()
+        while not os.path.exists(os.path.join(work, "started.npy")):
+            if proc.poll() is not None:
+                raise RuntimeError("reference kernel subprocess failed:\n" + proc.stderr.read()[-2000:])
+            if time.time() - t_wait > 300:
+                raise RuntimeError("reference kernel subprocess did not start within 300 s")
+            time.sleep(0.05)
+        time.sleep(0.1)
+        t0 = float(np.load(os.path.join(work, "started.npy"))[0])
+        out = {"threads": int(threads), "finished": False}
+        marks = []
+        for t in (t_first, t_second):
+            while time.time() - t0 < t and proc.poll() is None:
+                time.sleep(0.02)
+            marks.append((time.time() - t0, done()))
+            if proc.poll() is not None:
+                break
+        if proc.poll() is not None and os.path.exists(os.path.join(work, "seconds.npy")):
+            sec = float(np.load(os.path.join(work, "seconds.npy"))[0])
+            out.update({"finished": True, "seconds": sec, "cells_per_s": C / sec, "rows_first": marks[0][1], "rows_second": C, "t_first": marks[0][0], "t_second": sec})
+        elif proc.poll() is not None:
+            raise RuntimeError("reference kernel subprocess failed:\n" + proc.stderr.read()[-2000:])
+        else:
+            (ta, na), (tb, nb) = marks
+            out.update({"cells_per_s": (nb - na) / (tb - ta), "rows_first": na, "rows_second": nb, "t_first": ta, "t_second": tb})
+        return out
+    finally:
+        if proc.poll() is None:
+            os.kill(proc.pid, signal.SIGKILL)           # this exact process, nothing else
+        proc.wait()
+        del rm
+        for f in ("rm.npy", "ixs.npy", "started.npy", "seconds.npy"):
+            try:
+                os.remove(os.path.join(work, f))
+            except OSError:
+                pass
 
 
 # --------------------------------------------------------------------------- kNN + pooling

@@ -121,6 +121,43 @@ void vo_coldeltacor(const double *e, const double *d, double *rm, int rows, int 
     }
 }
 
+/* One cell of a partial variant, in the reference's own loop order (speedboosted.pyx:366-440): genes outer, neighbours inner - each gene
+ * row of e is visited once and the nrndm neighbour values are gathered from inside that one row - over a per-thread scratch A of
+ * rows x nrndm doubles: fill A, column means, centre, column sums of squares, centred b, then the scaled products accumulated gene by
+ * gene.  (The reference keeps A and A - mean as two arrays; one array centred in place holds the same numbers.)  Per pair the sums run
+ * over the genes in ascending order, exactly as in vo_pair_corr.  acc: nrndm doubles, zeroed here; b: rows doubles of scratch.          */
+static void vo_partial_cell(const double *e, const double *d, int rows, int cols, int c, const int64_t *ix, int nrndm,
+                            int transform, double psc, double *A, double *mu, double *b, double *acc)
+{
+    for (int n = 0; n < nrndm; ++n) { mu[n] = 0.0; acc[n] = 0.0; }
+    for (int g = 0; g < rows; ++g) {
+        const double *row = e + (size_t)g * cols;
+        const double ec = row[c];
+        double *Ag = A + (size_t)g * nrndm;
+        for (int n = 0; n < nrndm; ++n) {
+            Ag[n] = vo_transform(row[ix[n]] - ec, transform, 1, psc);
+            mu[n] += Ag[n];
+        }
+    }
+    for (int n = 0; n < nrndm; ++n) mu[n] /= rows;
+    double inv_ssb;
+    vo_centre_b(d, rows, cols, c, b, &inv_ssb);
+    /* ss in acc for a moment */
+    for (int g = 0; g < rows; ++g) {
+        double *Ag = A + (size_t)g * nrndm;
+        for (int n = 0; n < nrndm; ++n) {
+            Ag[n] -= mu[n];
+            acc[n] += Ag[n] * Ag[n];
+        }
+    }
+    for (int n = 0; n < nrndm; ++n) { mu[n] = 1.0 / sqrt(acc[n]); acc[n] = 0.0; }   /* 1/sqrt(0) = inf -> 0 * inf = NaN, as in the reference */
+    for (int g = 0; g < rows; ++g) {
+        const double *Ag = A + (size_t)g * nrndm;
+        const double bg = b[g] * inv_ssb;
+        for (int n = 0; n < nrndm; ++n) acc[n] += (Ag[n] * mu[n]) * bg;
+    }
+}
+
 /* Partial variants: only i = ixs[c,n]; scatter-add into the dense (cols,cols) matrix.
  * speedboosted.pyx:263-346, 352-443, 449-538.                                          */
 void vo_coldeltacor_partial(const double *e, const double *d, double *rm, const int64_t *ixs,
@@ -131,26 +168,26 @@ void vo_coldeltacor_partial(const double *e, const double *d, double *rm, const 
 #endif
 #pragma omp parallel
     {
-        double *a = (double *)malloc(sizeof(double) * rows);
+        double *A = (double *)malloc(sizeof(double) * (size_t)rows * nrndm);
         double *b = (double *)malloc(sizeof(double) * rows);
+        double *mu = (double *)malloc(sizeof(double) * 2 * nrndm), *acc = mu + nrndm;
 #pragma omp for schedule(dynamic, 1)
         for (int c = 0; c < cols; ++c) {
-            double inv_ssb;
-            vo_centre_b(d, rows, cols, c, b, &inv_ssb);
-            for (int n = 0; n < nrndm; ++n) {
-                int i = (int)ixs[(size_t)c * nrndm + n];
-                rm[(size_t)c * cols + i] += vo_pair_corr(e, d, rows, cols, c, i, transform, 1, psc, a, b, inv_ssb);
-            }
+            const int64_t *ix = ixs + (size_t)c * nrndm;
+            vo_partial_cell(e, d, rows, cols, c, ix, nrndm, transform, psc, A, mu, b, acc);
+            for (int n = 0; n < nrndm; ++n) rm[(size_t)c * cols + ix[n]] += acc[n];
         }
-        free(a);
+        free(A);
         free(b);
+        free(mu);
     }
 }
 
 /* Same as vo_coldeltacor_partial but with the compact (cols, nrndm) result the GPU path
  * produces natively (out[c,n] = corr with neighbour ixs[c,n]); used for at-scale checks
  * where a dense (cols,cols) fp64 matrix is not affordable, and by the CPU baseline.
- * Cells c in [c0, c1) only.                                                                */
+ * Cells c in [c0, c1) only: e and d keep their full width, so a cell range of a large problem
+ * is read with the large problem's strides.                                                */
 void vo_coldeltacor_partial_compact(const double *e, const double *d, double *out, const int64_t *ixs,
                                     int rows, int cols, int nrndm, int transform, double psc,
                                     int c0, int c1, int num_threads)
@@ -160,19 +197,17 @@ void vo_coldeltacor_partial_compact(const double *e, const double *d, double *ou
 #endif
 #pragma omp parallel
     {
-        double *a = (double *)malloc(sizeof(double) * rows);
+        double *A = (double *)malloc(sizeof(double) * (size_t)rows * nrndm);
         double *b = (double *)malloc(sizeof(double) * rows);
+        double *mu = (double *)malloc(sizeof(double) * 2 * nrndm), *acc = mu + nrndm;
 #pragma omp for schedule(dynamic, 1)
         for (int c = c0; c < c1; ++c) {
-            double inv_ssb;
-            vo_centre_b(d, rows, cols, c, b, &inv_ssb);
-            for (int n = 0; n < nrndm; ++n) {
-                int i = (int)ixs[(size_t)c * nrndm + n];
-                out[(size_t)c * nrndm + n] = vo_pair_corr(e, d, rows, cols, c, i, transform, 1, psc, a, b, inv_ssb);
-            }
+            vo_partial_cell(e, d, rows, cols, c, ixs + (size_t)c * nrndm, nrndm, transform, psc, A, mu, b, acc);
+            for (int n = 0; n < nrndm; ++n) out[(size_t)c * nrndm + n] = acc[n];
         }
-        free(a);
+        free(A);
         free(b);
+        free(mu);
     }
 }
 

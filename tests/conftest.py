@@ -35,6 +35,18 @@ def oracle():
     return _oracle
 
 
+@pytest.fixture(scope="session")
+def reference_kernels(oracle):
+    """The reference's own compiled kernels (oracle/_ref).  Where this tree should have them (a build happened, or /root/reference is
+    here to build from) their absence FAILS the test that asks for them; a tree that never had them skips, and says why."""
+    st, what = oracle.reference_module_status()
+    if st == "present":
+        return what
+    if oracle.reference_module_expected():
+        pytest.fail(f"the reference kernels are expected here but {st}: {what}")
+    pytest.skip(f"reference kernels {st}: {what}")
+
+
 @pytest.fixture(autouse=True)
 def _release_device_memory():
     """After every test: drop what the caching allocator still holds.  The suite runs in ONE process and some tests need most of the

@@ -34,6 +34,9 @@ def test_bench_line_structure():
     assert "literal" in j["config"]["stage_D_rule"] and j["config"]["arithmetic"].startswith("f64")
     roof = j["roofline"]
     assert roof["dtype"] == "f64" and "double" in roof["kernel"] and roof["bound"] == "valu" and roof["avg_launch_ms"] > 0
+    assert 0.3 < roof["effective_clock_ghz"] < 3.0 and roof["effective_clock"]["launches"] == 1          # measured in this run (the second timed step)
+    assert not any(k in roof for k in ("wave_time",))                               # what comes from a committed profile is named profile_*
+    assert j["config"]["count_layer_dtype"] == "uint16"                             # the loom's type is what `value` ran on
     for k in ("A_knn_search_ms", "A_pooling_ms", "B_fit_slope_ms", "D_coldeltacor_ms"):
         assert j["config"][k] > 0
     # ---- the production modes beside it, each with its own roofline block and its distance from the headline
@@ -44,6 +47,8 @@ def test_bench_line_structure():
     assert f32["vs_headline"]["max_abs_dcorr_all_pairs"] < 5e-5 and f32["vs_headline"]["nan_pattern_equal"]
     assert f32["cells_per_s"] > j["value"]                                  # narrower arithmetic is faster - and is not the headline
     assert pm["headline"]["dtype"] == "f64"
+    u8 = pm["f64_uint8_layers"]
+    assert u8["steps"] == 2 and u8["same_results_as_uint16"] and u8["cells_per_s"] > 0
     # ---- SURVEY 8(d)'s other lines, all present and none of them failed or skipped
     ex = j["extra"]
     for name in ("randomised_control", "D_reference_defaults_nrndm3000", "facade", "cfg2"):
@@ -63,13 +68,20 @@ def test_bench_line_structure():
     # ---- the same numbers as scalars of `config` (what the driver's record keeps)
     cfg = j["config"]
     for k in ("E_calculate_embedding_shift_ms", "F_run_markov_ms_per_step", "B_fit_gammas_default_ms", "D_reference_defaults_nrndm3000_ms",
-              "cfg2_unbalanced_A_ms", "cfg2_unbalanced_B_ms", "cfg2_balanced_A_ms", "cfg2_balanced_B_ms", "f32_production_cells_per_s", "D_dual_control_over_single"):
+              "cfg2_unbalanced_A_ms", "cfg2_unbalanced_B_ms", "cfg2_balanced_A_ms", "cfg2_balanced_B_ms", "f32_production_cells_per_s", "D_dual_control_over_single",
+              "f64_uint8_layers_cells_per_s"):
         assert isinstance(cfg[k], float) and cfg[k] > 0, k
-    # ---- CPU baseline: the oracle on the host cores, with the HIP path's distance from it on the same sub-problem
+    # ---- CPU baseline: stage D at full width (the run's own matrices and lists) by the reference's kernel and the restatement, the closed
+    #      sub-problem for stages A - C and the HIP path's distance from the oracle on the same inputs
     cb = j["cpu_baseline"]
-    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["stage_D_cells_per_s"] >= cb["value"]
+    full, closed = cb["full_width"], cb["closed_subproblem"]
+    assert "error" not in full and "skipped" not in full, full
+    assert full["e_stride_cells"] == 6000 and "stride 6000 cells" in cb["sample"]
+    for r in full["restatement"].values():
+        assert r["cells_per_s"] > 0 and r["nan_pattern_equal"] and r["max_abs_dcorr_hip_vs_restatement"] < 1e-9
     if cb["kind"] == "reference":          # oracle/_ref travelled with the snapshot: stage D by the reference's own Cython kernel
-        rk = cb["reference_kernel"]
+        assert full["reference_kernel"]["cells_per_s"] > 0 and full["reference_kernel"]["threads"] == cb["cores"]
+        rk = closed["reference_kernel"]
         assert rk["D_s"] > 0 and rk["nan_pattern_equal"] and rk["max_abs_dcorr_restatement_vs_reference"] < 1e-12
-        assert cb["restatement"]["value"] > 0 and abs(cb["stage_s"]["D"] - rk["D_s"]) < 1e-12
     assert cb["parity"]["f64"]["max_abs_dcorr"] < 1e-9 and cb["parity"]["f32_nopsc"]["max_abs_dcorr"] < 5e-5

@@ -1163,12 +1163,11 @@ def test_embedding_scaling_against_the_two_step_route(ops, dtype, C, G, n):
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
-def test_hip_kernels_against_the_reference_kernels_where_built(ops, oracle, dtype):
+def test_hip_kernels_against_the_reference_kernels_where_built(ops, oracle, reference_kernels, dtype):
     """The HIP stage-D kernels against the REFERENCE'S OWN Cython kernels (oracle/_ref: velocyto/speedboosted.pyx built with its own
     flags in the build container, shipped to the GPU box as a binary and run in a subprocess) on fresh random inputs: all three
-    transforms, partial (compact lists) and full (all pairs).  Skipped where the module did not travel."""
-    if oracle.reference_module_path() is None:
-        pytest.skip("oracle/_ref did not travel to this box")
+    transforms, partial (compact lists) and full (all pairs).  A tree that should hold the module and does not FAILS here
+    (conftest.reference_kernels); only a tree that never had it skips."""
     rng = np.random.default_rng(23)
     G, C, nr = 1300, 96, 14
     e = rng.gamma(1.0, 2.0, (G, C)) * (rng.random((G, C)) < 0.8)

@@ -7,6 +7,8 @@ own code (Cython kernels built with its flags + its Python modules imported from
 Tolerances: the reference kernels are compiled with -ffast-math (reassociation), the oracle
 with strict IEEE -> correlations agree to ~1e-13 absolute; integer outputs are bit-exact.
 """
+import os
+
 import numpy as np
 import pytest
 from scipy import sparse
@@ -477,12 +479,10 @@ def test_cfg1_size_fit_gammas_plumbing(golden, oracle):
 
 
 @pytest.mark.parametrize("transform,psc", [("linear", 0.0), ("sqrt", 1e-10), ("sqrt", 1.0), ("log10", 1.0), ("log10", 1e-10)])
-def test_restatement_against_the_reference_kernels_where_built(oracle, transform, psc):
+def test_restatement_against_the_reference_kernels_where_built(oracle, reference_kernels, transform, psc):
     """Where oracle/_ref holds the reference's own Cython module (built from /root/reference by oracle/build_ref.py; it travels to the
     GPU box as a binary), the C restatement is checked against it directly on fresh random inputs - partial and full kernels, ties
     and identical cells included - not only through the committed golden vectors."""
-    if oracle.reference_module_path() is None:
-        pytest.skip("oracle/_ref not built here")
     rng = np.random.default_rng(17)
     G, C, nr = 700, 60, 11
     e = rng.gamma(1.0, 2.0, (G, C)) * (rng.random((G, C)) < 0.7)
@@ -504,3 +504,22 @@ def test_restatement_against_the_reference_kernels_where_built(oracle, transform
     off[4, 9] = off[9, 4] = False                              # (degenerate pairs: rounding noise over a zero variance under -ffast-math)
     okf = np.isfinite(full) & np.isfinite(reff) & off
     np.testing.assert_allclose(full[okf], reff[okf], atol=1e-12)
+
+
+def test_reference_kernel_rate_on_a_run_cut_short(oracle, reference_kernels, tmp_path):
+    """oracle.reference_coldeltacor_rate (the CPU baseline's full-width leg in bench.py): the reference's partial kernel started on a
+    problem, its finished rows counted from outside at two instants, the subprocess killed; a problem it finishes earlier reports
+    cells / seconds.  The rate of the cut run agrees with that of the same problem run to the end."""
+    rng = np.random.default_rng(3)
+    G, C, nr = 6000, 400, 120
+    e = rng.gamma(1.0, 2.0, (G, C))
+    d = rng.normal(size=(G, C))
+    ixs = np.stack([rng.choice(C, nr, replace=False) for _ in range(C)])
+    np.save(tmp_path / "e.npy", e)
+    np.save(tmp_path / "d.npy", d)
+    whole = oracle.reference_coldeltacor_rate(str(tmp_path), ixs, "sqrt", 1e-10, threads=2, t_first=60.0, t_second=120.0)
+    assert whole["finished"] and whole["cells_per_s"] > 0
+    cut = oracle.reference_coldeltacor_rate(str(tmp_path), ixs, "sqrt", 1e-10, threads=2, t_first=0.25 * whole["seconds"], t_second=0.7 * whole["seconds"])
+    assert not cut["finished"] and 0 < cut["rows_first"] < cut["rows_second"] < C
+    assert 0.6 < cut["cells_per_s"] / whole["cells_per_s"] < 1.6
+    assert sorted(os.listdir(tmp_path)) == ["d.npy", "e.npy"]                 # the sparse output file and the markers are gone

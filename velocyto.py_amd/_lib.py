@@ -21,13 +21,14 @@ ARCH = "gfx950"
 _lib = None
 
 c_i64, c_int, c_dbl, c_vp, c_sz = ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t
-EXPECTED_ABI = 2                  # vcy_abi_version() of the header this table mirrors
+EXPECTED_ABI = 3                  # vcy_abi_version() of the header this table mirrors
 
 # name -> (restype, argtypes); mirrors include/velocyto_hip.h one to one
 SIGNATURES = {
     "vcy_last_error": (ctypes.c_char_p, []),
     "vcy_abi_version": (c_int, []),
     "vcy_device_info": (c_int, [ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_i64)]),
+    "vcy_clock_probe": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp]),
     "vcy_transpose": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp]),
     "vcy_coldeltacor_partial": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                                         c_int, c_int, c_dbl, c_int, c_vp]),

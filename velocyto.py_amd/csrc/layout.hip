@@ -91,13 +91,39 @@ static int launch_transpose(const void *src, void *dst, int64_t rows, int64_t co
     VCY_LAUNCH_CHECK();
     return VCY_OK;
 }
+
+// Shader-clock probe: one wave per workgroup (workgroup b lands on XCD b % 8) takes `nsamples` readings of the shader-clock counter
+// (s_memtime: counts at the clock the CUs run at, which the chip sets to its power budget) against the constant 100 MHz counter
+// (s_memrealtime), `interval` real-time ticks apart, sleeping in between.  Launched on a side stream it measures the clock WHILE another
+// kernel runs: the wave takes one slot of one SIMD per XCD and issues a handful of scalar instructions per microsecond.
+__global__ __launch_bounds__(64) void k_clock_probe(long long *__restrict__ samples, int nsamples, long long interval)
+{
+    long long *mine = samples + (long long)blockIdx.x * 2 * nsamples;
+    const long long r0 = wall_clock64();
+    for (int i = 0; i < nsamples; ++i) {
+        const long long until = r0 + (long long)i * interval;
+        while (wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
+        const long long c = clock64(), r = wall_clock64();
+        if (threadIdx.x == 0) { mine[2 * i] = c; mine[2 * i + 1] = r; }
+    }
+}
 }  // namespace vcy
 
 using namespace vcy;
 
 extern "C" const char *vcy_last_error(void) { return g_err; }
 // 2: vcy_diffuse_step_factored gained `prepared` (round 3); vcy_gram added and vcy_knn_pool_csr's 4-element minimum stated (round 4)
-extern "C" int vcy_abi_version(void) { return 2; }
+// 3: vcy_clock_probe added (round 5)
+extern "C" int vcy_abi_version(void) { return 3; }
+
+extern "C" int vcy_clock_probe(int64_t *samples, int64_t nblocks, int64_t nsamples, int64_t interval_ticks, vcy_stream stream)
+{
+    VCY_REQUIRE(samples && nblocks > 0 && nblocks <= 64 && nsamples >= 2 && nsamples <= 4096 && interval_ticks > 0 &&
+                nsamples * interval_ticks <= 300000000, "clock_probe: bad arguments (at most 3 s of 100 MHz ticks in all)");
+    hipLaunchKernelGGL(k_clock_probe, dim3((unsigned)nblocks), dim3(64), 0, as_stream(stream), (long long *)samples, (int)nsamples, (long long)interval_ticks);
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
+}
 
 extern "C" int vcy_device_info(int *cu_count, int *lds_bytes_per_block, int64_t *hbm_bytes)
 {

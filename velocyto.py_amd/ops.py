@@ -1732,3 +1732,27 @@ def hilbert_order(points, bits: int = 16) -> torch.Tensor:
         x, y = torch.where(swap, y, x), torch.where(swap, x, y)
         s >>= 1
     return torch.argsort(d).to(torch.int32)
+
+
+class ClockProbe:
+    """Shader clock while other kernels run (vcy_clock_probe; measurement only).  `start(duration_ms)` launches the one-wave-per-XCD
+    probe on a side stream; after the kernels of interest have been enqueued and the device synchronised, `ghz()` returns
+    (mean, min, max) of the clock over the sampling intervals, in GHz."""
+
+    def __init__(self, nblocks: int = 8, interval_ms: float = 2.0):
+        self.dev = require_gpu()
+        self.nblocks, self.interval = nblocks, int(interval_ms * 1e5)       # ticks of the 100 MHz counter
+        self.stream = torch.cuda.Stream(device=self.dev)
+        self.samples = None
+
+    def start(self, duration_ms: float) -> None:
+        n = int(min(4096, max(2, duration_ms * 1e5 / self.interval + 1)))
+        self.samples = torch.zeros((self.nblocks, n, 2), dtype=torch.int64, device=self.dev)
+        _lib.check(_lib.lib().vcy_clock_probe(self.samples.data_ptr(), self.nblocks, n, self.interval, self.stream.cuda_stream), "clock_probe")
+
+    def ghz(self) -> Tuple[float, float, float]:
+        self.stream.synchronize()
+        s = self.samples.cpu().numpy().astype(np.float64)
+        dc, dr = np.diff(s[:, :, 0], axis=1), np.diff(s[:, :, 1], axis=1)
+        f = dc / np.maximum(dr, 1.0) * 0.1
+        return float(f.mean()), float(f.min()), float(f.max())
