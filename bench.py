@@ -507,7 +507,7 @@ def cpu_full_width(pipe, args):
         # ---- the reference's own kernel over all columns, stopped after its second reading
         if oracle.reference_module_path() is not None:
             try:
-                out["reference_kernel"] = {**oracle.reference_coldeltacor_rate(work, ixs, "sqrt", 1e-10, threads=half, t_first=5.0, t_second=13.0),
+                out["reference_kernel"] = {**oracle.reference_coldeltacor_rate(work, ixs, "sqrt", 1e-10, threads=half, t_first=5.0, t_second=17.0),
                                            "kernel": "velocyto/speedboosted.pyx _colDeltaCorSqrtpartial (oracle/_ref), all columns started, rows finished between two readings",
                                            "thread_rule": "cpu_count() / 2 (estimation.py:27-28)"}
             except Exception as ex:                                          # noqa: BLE001
@@ -995,7 +995,10 @@ def extra_lines(a, dev, pipe, res):
     t_start = time.perf_counter()
     C = a.cells
     main_f64 = a.dtype == "f64"
-    data = (pipe.cS, pipe.cU, pipe.fS, pipe.fU, pipe.pcs)
+    nS, nU = pipe.cS.narrowed(), pipe.cU.narrowed()      # the layers as ops.CountMatrix keeps them at upload: uint8 where no count exceeds 255
+    if nS.t.dtype != nU.t.dtype:
+        nS, nU = pipe.cS, pipe.cU
+    data = (nS, nU, pipe.fS, pipe.fU, pipe.pcs)
     extra, modes = {}, {}
 
     def guarded(name, fn, store=extra):

@@ -262,21 +262,24 @@ def reference_coldeltacor_rate(work: str, ixs, transform="sqrt", psc=1e-10, thre
         time.sleep(0.1)
         t0 = float(np.load(os.path.join(work, "started.npy"))[0])
         out = {"threads": int(threads), "finished": False}
-        marks = []
-        for t in (t_first, t_second):
-            while time.time() - t0 < t and proc.poll() is None:
-                time.sleep(0.02)
-            marks.append((time.time() - t0, done()))
-            if proc.poll() is not None:
-                break
+        # the count of finished rows, read every 0.2 s: all threads start together, so rows finish in waves - the rate is taken between the
+        # FIRST and the LAST instant at which the count moved inside [t_first, t_second], not between the two ends of the window
+        series = []
+        while time.time() - t0 < t_second and proc.poll() is None:
+            time.sleep(0.2)
+            series.append((time.time() - t0, done()))
         if proc.poll() is not None and os.path.exists(os.path.join(work, "seconds.npy")):
             sec = float(np.load(os.path.join(work, "seconds.npy"))[0])
-            out.update({"finished": True, "seconds": sec, "cells_per_s": C / sec, "rows_first": marks[0][1], "rows_second": C, "t_first": marks[0][0], "t_second": sec})
+            out.update({"finished": True, "seconds": sec, "cells_per_s": C / sec, "rows_first": series[0][1] if series else C, "rows_second": C,
+                        "t_first": series[0][0] if series else sec, "t_second": sec})
         elif proc.poll() is not None:
             raise RuntimeError("reference kernel subprocess failed:\n" + proc.stderr.read()[-2000:])
         else:
-            (ta, na), (tb, nb) = marks
-            out.update({"cells_per_s": (nb - na) / (tb - ta), "rows_first": na, "rows_second": nb, "t_first": ta, "t_second": tb})
+            moves = [(t, n) for (t, n), (_, n_prev) in zip(series[1:], series[:-1]) if n != n_prev and t >= t_first]
+            if len(moves) < 2:
+                raise RuntimeError(f"the reference kernel finished too few rows in {t_second:.0f} s to give a rate: {series[-1][1] if series else 0}")
+            (ta, na), (tb, nb) = moves[0], moves[-1]
+            out.update({"cells_per_s": (nb - na) / (tb - ta), "rows_first": na, "rows_second": nb, "t_first": ta, "t_second": tb, "readings": len(series)})
         return out
     finally:
         if proc.poll() is None:

@@ -757,6 +757,14 @@ def test_checkpoint_restores_masks_and_device_state(vcy, golden, tmp_path):
     serialization.dump_hdf5(vlm, path, data_compression=4, chunks=(64, 64), pickle_protocol=4)
     v2 = serialization.load_hdf5(path, obj_class=vcy.analysis.VelocytoLoom, dtype="float64")
     assert v2.cv_mean_selected.dtype == np.bool_ and np.array_equal(v2.cv_mean_selected, vlm.cv_mean_selected)
+
+    class Mine(vcy.analysis.VelocytoLoom):               # a subclass with its own constructor: made by __new__, like the reference's loader does
+        def __init__(self, project, loom):
+            raise AssertionError("load_hdf5 must not call __init__")
+    v3 = serialization.load_hdf5(path, obj_class=Mine, dtype="float64")
+    assert isinstance(v3, Mine)
+    np.testing.assert_array_equal(v3.corrcoef, vlm.corrcoef)
+    np.testing.assert_array_equal(v3.Sx_sz, vlm.Sx_sz)
     np.testing.assert_array_equal(v2.corrcoef, vlm.corrcoef)
     np.testing.assert_array_equal(v2.corrcoef_random, vlm.corrcoef_random)
     np.testing.assert_array_equal(v2.transition_prob, vlm.transition_prob)

@@ -213,7 +213,8 @@ def test_array_valued_root_attributes(loom_io, tmp_path):
 def test_serialization_container_of_any_object(loom_io, tmp_path):
     """serialization.dump_hdf5 (serialization.py:44-97) walks the attributes of ANY object: numeric arrays become datasets of their
     own name, everything else a pickled + zlib-compressed uint8 dataset "&name" (the reference's container format); exclusion,
-    compression and pickle protocol are honoured.  (load_hdf5 instantiates a VelocytoLoom and needs the device: GPU suite.)"""
+    compression and pickle protocol are honoured; load_hdf5 (serialization.py:100-115) reads it back into ANY class, made with
+    obj_class.__new__ as the reference does.  (A VelocytoLoom rebuilds device state on load: GPU suite.)"""
     import types
     from scipy import sparse
     from velocyto_amd import serialization
@@ -233,3 +234,13 @@ def test_serialization_container_of_any_object(loom_io, tmp_path):
     assert (serialization._uint2obj(raw["&knn"]) != obj.knn).nnz == 0
     assert np.array_equal(serialization._uint2obj(raw["&ca"])["CellID"], np.arange(3))
     assert serialization._uint2obj(serialization._obj2uint({"x": 1}, compression=1, protocol=2)) == {"x": 1}
+
+    class Plain:                                         # no usable __init__: the reference never calls it either
+        def __init__(self, required):
+            raise AssertionError("load_hdf5 must not call __init__")
+    back = serialization.load_hdf5(path, Plain)
+    assert isinstance(back, Plain) and back.note == "hello" and not hasattr(back, "skipped")
+    np.testing.assert_array_equal(back.mat, obj.mat)
+    assert (back.knn != obj.knn).nnz == 0 and list(back.names) == ["a", "bc", "def"]
+    with pytest.raises(TypeError):
+        serialization.load_hdf5(path, "VelocytoLoom")

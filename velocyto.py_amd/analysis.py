@@ -52,9 +52,16 @@ class VelocytoLoom(PreprocessMixin):
     ``VelocytoLoom(loom_filepath)`` reads a .loom file (HDF5 via loom_io: h5py if present, else ctypes-bound libhdf5);
     ``VelocytoLoom.from_arrays(S, U, A=None, ca=None, ra=None)`` starts from in-memory layers."""
 
-    def __init__(self, loom_filepath: str = None, dtype=None) -> None:
+    def __new__(cls, *args, **kwargs):
+        # the device-side containers exist from creation, not from __init__: serialization.load_hdf5 makes its object with
+        # obj_class.__new__(obj_class) like the reference (serialization.py:107), whatever __init__ a subclass defines
+        self = super().__new__(cls)
         object.__setattr__(self, "_dev", {})
         object.__setattr__(self, "_host", {})
+        object.__setattr__(self, "_dtype", ops.resolve_dtype(None))
+        return self
+
+    def __init__(self, loom_filepath: str = None, dtype=None) -> None:
         object.__setattr__(self, "_dtype", ops.resolve_dtype(dtype))
         if loom_filepath is not None:
             from .loom_io import read_loom

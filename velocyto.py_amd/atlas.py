@@ -227,6 +227,8 @@ class AtlasPath:
             mom += ops.fit_slope_moments(Ux_b, Sx_b)
             ev[2].record()
             if self.rules is None:                    # first pass only: the scale facts of e = Sx_sz over ALL cells of ALL ranks
+                if self.dtype == torch.float64:       # the f64 sqrt element's domain, checked on every pooled block - the matrix itself, never
+                    ops.check_f64_sqrt_domain(Sx_b)   # the staging buffer (its halo rows are not written yet on the first pass)
                 st = ops.abs_stats(Sx_b)
                 abs_st = st if abs_st is None else torch.stack([abs_st[0] + st[0], torch.minimum(abs_st[1], st[1]), abs_st[2] + st[2]])
             if timed:
@@ -237,7 +239,7 @@ class AtlasPath:
             # every block size (a per-block or per-rank decision could differ on borderline data)
             if abs_st is None:                      # a rank without a block still takes part in the all-reduce: the neutral element
                 abs_st = torch.tensor([0.0, float("inf"), 0.0], dtype=torch.float64, device=self._ebuf.t.device)
-            self.rules = ops.partial_rules_for(self._ebuf, ops.SQRT, self.psc, stats=D.all_reduce_abs_stats(abs_st), cells=self.C)
+            self.rules = ops.partial_rules_for(self._ebuf, ops.SQRT, self.psc, stats=D.all_reduce_abs_stats(abs_st), cells=self.C, domain_checked=True)
         ev[0].record()
         D.all_reduce_sum(mom)
         gamma = ops.fit_slope_from_moments(mom)

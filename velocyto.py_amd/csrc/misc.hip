@@ -483,7 +483,7 @@ __device__ __forceinline__ float exp2_neg(float d2) { return __builtin_amdgcn_ex
 // time here: 0.76 -> 0.5 ms per step at 50 000 cells.
 __device__ __forceinline__ double exp2_neg(double d2)
 {
-    const double x = fmax(-d2, -1100.0);
+    const double x = (d2 != d2) ? d2 : fmax(-d2, -1100.0);         // (fmax drops a NaN: a NaN distance stays NaN, as in the f32 form and in exp2())
     const double kf = rint(x);
     const double r = x - kf;
     double p = 1.3691488853904124e-12;                              // ln2^13 / 13!

@@ -426,10 +426,11 @@ F64_SQRT_MAX = 1e38
 
 
 def check_f64_sqrt_domain(e: CellMatrix) -> None:
-    """The f64 partial-sqrt element (csrc/coldeltacor.hip, sqrt_normal_f64) seeds its square root from the f32 unit: faithfully
-    rounded (<= 2 ulp against a correctly rounded sqrt) for arguments inside the f32 exponent range, silently 0 above 3.4e38.  A
-    count-derived matrix never comes near it; a matrix that does is refused here (one reduction, one device->host sync - the
-    callers that decide the branch rule once per matrix come through here, ops.partial_rules_for)."""
+    """The f64 partial-sqrt element (csrc/coldeltacor.hip, xform<double, SQRT, PARTIAL>) seeds its square root from the f32 unit: the
+    correctly rounded root in all but near-tie cases for arguments inside the f32 exponent range, NaN above 3.4e38 (the converted
+    argument is +inf, v_rsq_f32 of it is 0, and inf * 0 is NaN).  A count-derived matrix never comes near it; a matrix that does is
+    refused here (one reduction, one device->host sync - the callers that decide the branch rule once per matrix come through here,
+    ops.partial_rules_for; every `validate=True` call of the partial entry points, fused ones included, does too)."""
     lo, hi = e.t.aminmax()
     m = max(abs(float(lo)), abs(float(hi)))
     if m >= F64_SQRT_MAX:
@@ -443,7 +444,7 @@ def literal_rule_forced() -> bool:
 
 
 def partial_rules_for(e: CellMatrix, transform: int, psc: float, stats: Optional[torch.Tensor] = None, cells: Optional[int] = None,
-                      literal: bool = False) -> int:
+                      literal: bool = False, domain_checked: bool = False) -> int:
     """The rules value the callers of the *partial kernels pass for the reference's partial rule on this matrix:
     RULES_PARTIAL_NOPSC (A = sign(t) sqrt|t|, three instructions per gene instead of five) for the sqrt transform on an f32
     matrix when the pseudocount cannot be told from zero at the matrix's scale, else RULES_PARTIAL, the literal rule.
@@ -464,8 +465,8 @@ def partial_rules_for(e: CellMatrix, transform: int, psc: float, stats: Optional
     i.e. <= psc * sqrt(mean_g 1/|t_g|) / sd(A) over the genes with 0 < |t_g| < 2^24 psc: a few 1e-7 on count-scale data
     (measured 1.5e-7 over all 12.5 M pairs of the bench workload), and below the f32 tolerance of 1e-5 down to matrix scales of
     1e-4 (tests/test_gpu_ops.py::test_partial_nopsc_rule_bound_on_scaled_matrices)."""
-    if transform == SQRT and e.dtype == torch.float64 and e.C:
-        check_f64_sqrt_domain(e)
+    if transform == SQRT and e.dtype == torch.float64 and e.C and not domain_checked:     # (domain_checked: the caller ran check_f64_sqrt_domain on
+        check_f64_sqrt_domain(e)                                                            #  the matrix itself - `e` may be a staging buffer, atlas.py)
     if transform != SQRT or e.dtype != torch.float32 or not (0.0 <= float(psc) <= PSC_NEGLIGIBLE) or e.C == 0 or literal or literal_rule_forced():
         return RULES_PARTIAL
     st = abs_stats(e) if stats is None else stats
@@ -516,6 +517,8 @@ def coldeltacor_partial_fused(Sx: CellMatrix, Ux: CellMatrix, gamma: torch.Tenso
     assert u_row0 <= cell0 and cell0 + C_out <= u_row0 + Ux.C
     if validate and ix.numel() and (int(ix.min()) < 0 or int(ix.max()) >= Sx.C):
         raise ValueError("neighbour index out of range")
+    if validate and transform == SQRT and Sx.dtype == torch.float64 and Sx.C:
+        check_f64_sqrt_domain(Sx)
     if out is None:
         out = torch.empty((C_out, nrndm), dtype=Sx.dtype, device=dev)
     gamma = gamma.to(device=dev, dtype=torch.float32).contiguous()
@@ -589,6 +592,8 @@ def coldeltacor_partial_fused_dual(Sx: CellMatrix, Ux: CellMatrix, gamma: torch.
     assert u_row0 <= cell0 and cell0 + C_out <= u_row0 + Ux.C
     if validate and ix.numel() and (int(ix.min()) < 0 or int(ix.max()) >= Sx.C):
         raise ValueError("neighbour index out of range")
+    if validate and transform == SQRT and Sx.dtype == torch.float64 and Sx.C:
+        check_f64_sqrt_domain(Sx)
     out = torch.empty((C_out, nrndm), dtype=Sx.dtype, device=dev) if out is None else out
     out_rndm = torch.empty((C_out, nrndm), dtype=Sx.dtype, device=dev) if out_rndm is None else out_rndm
     gamma = gamma.to(device=dev, dtype=torch.float32).contiguous()

@@ -54,14 +54,20 @@ def dump_hdf5(obj: Any, filename: str, data_compression: int = 7, chunks=(2048, 
 
 
 def load_hdf5(filename: str, obj_class: type = None, dtype=None):
-    """serialization.py:100-115: an instance of `obj_class` (default: this package's VelocytoLoom; it must be that class or a
-    subclass of it, as the reference asks for `vcy.VelocytoLoom`) with every dataset of the file set as an attribute - "&name"
-    datasets decoded back into the objects they held.  `dtype` (an extension) is the device storage type of the new object."""
-    from .analysis import VelocytoLoom
+    """serialization.py:100-115: an instance of `obj_class` - ANY class, made with `obj_class.__new__(obj_class)` as the reference does
+    (no `__init__` runs, so a subclass with another signature loads too); default: this package's VelocytoLoom - with every dataset of
+    the file set as an attribute, "&name" datasets decoded back into the objects they held.  An object that knows how to rebuild
+    device-side state (`_import_state`, VelocytoLoom) is asked to.  `dtype` (an extension) is the device storage type of a VelocytoLoom."""
     from .loom_io import hdf5_load
-    if obj_class is not None and not (isinstance(obj_class, type) and issubclass(obj_class, VelocytoLoom)):
-        raise TypeError("obj_class must be VelocytoLoom or a subclass of it")
-    obj = (obj_class or VelocytoLoom)(None, dtype=dtype)
+    if obj_class is None:
+        from .analysis import VelocytoLoom
+        obj_class = VelocytoLoom
+    if not isinstance(obj_class, type):
+        raise TypeError("obj_class must be a class")
+    obj = obj_class.__new__(obj_class)
+    if dtype is not None and hasattr(obj, "_dtype"):
+        from . import ops
+        object.__setattr__(obj, "_dtype", ops.resolve_dtype(dtype))
     for name, arr in hdf5_load(filename).items():
         if name.startswith("&"):
             setattr(obj, name[1:], _uint2obj(arr))
