@@ -160,8 +160,9 @@ def test_coldeltacor_partial_fused_equals_two_kernels(ops, dtype, transform):
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_coldeltacor_full_linear_gemm_route(ops, oracle, dtype):
-    """The all-pairs linear variant as two fp64 GEMMs == the VALU kernel == the oracle, including nearly identical cells
-    (where the expanded sum of squares cancels) and exact duplicates (zero variance -> NaN)."""
+    """The all-pairs linear variant as two contractions over the genes on the f64 matrix cores (vcy_coldeltacor_full_linear: Pearson
+    epilogue fused, no library GEMM) == the element-wise kernel == the oracle, including nearly identical cells (where the expanded sum
+    of squares cancels) and exact duplicates (zero variance -> NaN); row blocks (cell0 / C_out), ragged tiles and `rm +=` as well."""
     rng = np.random.default_rng(31)
     G, C = 700, 130
     e, d = rng.gamma(2.0, 1.0, (G, C)), rng.normal(size=(G, C))
@@ -170,11 +171,11 @@ def test_coldeltacor_full_linear_gemm_route(ops, oracle, dtype):
     want = oracle.coldeltacor(e, d, "linear", 0.0)
     E, D = ops.CellMatrix.from_genes_major(e, dtype), ops.CellMatrix.from_genes_major(d, dtype)
     got = ops.coldeltacor_full(E, D, ops.LINEAR).cpu().numpy()
-    ops.FULL_LINEAR_GEMM = False
+    ops.FULL_LINEAR_MFMA = False
     try:
         kern = ops.coldeltacor_full(E, D, ops.LINEAR).cpu().numpy()
     finally:
-        ops.FULL_LINEAR_GEMM = True
+        ops.FULL_LINEAR_MFMA = True
     skip = np.eye(C, dtype=bool)
     skip[8, 9] = skip[9, 8] = True
     skip[4, 5] = skip[5, 4] = True                           # checked separately below (cancellation in the expanded sum of squares)
@@ -182,8 +183,17 @@ def test_coldeltacor_full_linear_gemm_route(ops, oracle, dtype):
     tol = 1e-9 if dtype == "float64" else 5e-5
     np.testing.assert_allclose(got[~skip], want[~skip], atol=tol)
     np.testing.assert_allclose(kern[~skip], want[~skip], atol=tol * (1 if dtype == "float64" else 4))
-    # the near-duplicate pair is where an f32 expansion would fail: fp64 GEMM keeps it
+    # the near-duplicate pair is where an f32 expansion would fail: the f64 contraction keeps it
     assert abs(got[4, 5] - want[4, 5]) < (1e-6 if dtype == "float64" else 5e-3) and abs(got[5, 4] - want[5, 4]) < (1e-6 if dtype == "float64" else 5e-3)
+    assert np.isnan(got[8, 9]) and np.isnan(got[9, 8])
+    # a row block in the middle (tile edges inside the matrix) and the reference's accumulate-into semantics
+    blk = ops.coldeltacor_full(E, D, ops.LINEAR, cell0=37, C_out=70).cpu().numpy()
+    ok = ~np.isnan(got[37:107])
+    assert np.array_equal(np.isnan(blk), ~ok) and np.array_equal(blk[ok], got[37:107][ok])
+    rm = torch.full((C, C), 2.0, dtype=E.dtype, device=E.t.device)
+    acc = ops.coldeltacor_full(E, D, ops.LINEAR, rm=rm, accumulate=True).cpu().numpy()
+    okf = ~np.isnan(got)
+    np.testing.assert_allclose(acc[okf], got[okf] + 2.0, atol=1e-6 if dtype == "float32" else 1e-14)
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])

@@ -40,6 +40,8 @@ SIGNATURES = {
                                                    c_i64, c_i64, c_int, c_int, c_dbl, c_dbl, c_dbl, c_int, c_vp]),
     "vcy_coldeltacor_full": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_dbl,
                                      c_int, c_int, c_vp]),
+    "vcy_coldeltacor_full_linear_workspace_bytes": (c_sz, [c_i64]),
+    "vcy_coldeltacor_full_linear": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp]),
     "vcy_scatter_rows": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]),
     "vcy_knn_pool": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_vp]),
     "vcy_knn_pool2": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_vp]),

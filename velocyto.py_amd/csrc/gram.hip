@@ -283,6 +283,181 @@ static int launch_gram(const void *A, const void *B, const double *ma, const dou
     return launch_gram_t<TA, TB, SYM, 128>(A, B, ma, mb, out, ws, C, Ga, Gb, lda, ldb, ldo, st);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The linear all-pairs variant, speedboosted._colDeltaCor (speedboosted.pyx:13-87; wrapper estimation.py:11-33): without a transform the
+// correlation of A = e_i - e_c with b = d_c over the genes is separable,
+//     sum A = Se_i - Se_c,    sum A^2 = See_i + See_c - 2 (E E^T)[c][i],    sum A b = (D E^T)[c][i] - sum_g e_c[g] d_c[g],
+// i.e. two products that contract over the GENES, the contiguous dimension of both operands ("NT"): the one place on the path that is a
+// genuine dense block contraction, done here on the f64 matrix cores with the moment algebra, the noise-floor NaN rule and the
+// `rm[c][i] (+)= r` store fused into the epilogue - no (rows x C) temporaries, no library GEMM.
+// A workgroup of 4 waves owns a 128 (cells c) x 64 (cells i) tile of rm and both products of it: wave (wm, wn) owns 64 x 32 = 4 x 2
+// MFMA tiles of each product = 64 f64 accumulators per lane.  Slabs of 16 genes of the 128 + 128 + 64 rows are staged into LDS
+// [row][gene] with an odd row pitch (17 doubles): an A- or B-fragment of v_mfma_f64_16x16x4_f64 is row (lane & 15), gene (lane >> 4) of a
+// 16 x 4 block, and the 16 rows of a quarter-wave start in 16 different bank pairs.  The expansion of sum A^2 cancels where e_i is
+// close to e_c - which is why everything is f64 whatever the storage type.
+// Measured at 10 000 cells x 20 000 genes, f64 (tools/bench_full.py, profiles/r05_full_linear.txt): 155 ms = 51.6 Tflop/s = 0.66 of the f64
+// matrix peak at a shader clock of 2.37 GHz (vcy_clock_probe: not power-limited), 2.8 x the element-wise kernel (430 ms); the same algebra as
+// two library GEMMs + eager elementwise passes (round 4's route) takes 122 ms.  Tile width (64 / 128 cells i, the latter with 256
+// accumulators in AGPRs at one workgroup per CU), slab depth (16 / 32 genes) and the LDS pitch (17 / 18 doubles) all measure 155-159 ms: the
+// kernel waits on its one-slab-ahead prefetch, not on LDS or the matrix cores.  VCY_NT_N / VCY_NT_KS / VCY_NT_PAD rebuild the variants.
+#ifndef VCY_NT_N
+#define VCY_NT_N 64
+#endif
+#ifndef VCY_NT_KS
+#define VCY_NT_KS 16
+#endif
+#ifndef VCY_NT_PAD
+#define VCY_NT_PAD 1
+#endif
+static_assert(2 * (2 * 128 + VCY_NT_N) * (VCY_NT_KS + VCY_NT_PAD) * 8 <= 160 * 1024, "the double-buffered slabs must fit the LDS of a CU");
+constexpr int NT_M = 128, NT_N = VCY_NT_N, NT_KS = VCY_NT_KS, NT_LD = NT_KS + VCY_NT_PAD;
+constexpr int NT_YT = NT_N / 32;       // 16 x 16 tiles per wave along i (waves 2 x 2)
+
+// per cell: Se = sum e, See = sum e^2, sb = sum d, sbb = sum d^2, sed = sum e d   (f64, one workgroup per cell, fixed order)
+template <typename T> __global__ __launch_bounds__(256) void k_cell_linear_sums(const T *__restrict__ e, const T *__restrict__ d, double *__restrict__ sums,
+                                                                                  int G, int64_t ld, int64_t cell0, int C_out)
+{
+    __shared__ double red[8];
+    const int64_t c = blockIdx.x;
+    const T *er = e + c * ld;
+    const bool own = c >= cell0 && c < cell0 + C_out;                 // d holds the same rows as e; only the launch's own cells need its sums
+    const T *dr = d + c * ld;
+    double se = 0.0, see = 0.0, sb = 0.0, sbb = 0.0, sed = 0.0;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        const double x = (double)er[g];
+        se += x; see = fma(x, x, see);
+        if (own) { const double y = (double)dr[g]; sb += y; sbb = fma(y, y, sbb); sed = fma(x, y, sed); }
+    }
+    se = block_sum(se, red); see = block_sum(see, red);
+    sb = block_sum(sb, red); sbb = block_sum(sbb, red); sed = block_sum(sed, red);
+    if (threadIdx.x == 0) { double *o = sums + 5 * c; o[0] = se; o[1] = see; o[2] = sb; o[3] = sbb; o[4] = sed; }
+}
+
+template <typename T, typename OT>
+__global__ __launch_bounds__(GM_THREADS, NT_N == 128 ? 1 : 2) void k_cdc_full_linear(const T *__restrict__ e, const T *__restrict__ d, const double *__restrict__ sums,
+                                                                    OT *__restrict__ rm, int C, int G, int64_t ld, int64_t cell0, int C_out, int64_t ld_rm,
+                                                                    int accumulate, int ntn)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *Es = reinterpret_cast<double *>(smem);                    // [2][NT_M][NT_LD]   e of the tile's cells c
+    double *Ds = Es + 2 * NT_M * NT_LD;                               // [2][NT_M][NT_LD]   d of the tile's cells c
+    double *Bs = Ds + 2 * NT_M * NT_LD;                               // [2][NT_N][NT_LD]   e of the tile's cells i
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // workgroup b runs on XCD b % 8 (observed; speed only): an XCD owns a contiguous range of tiles, walked along i inside a row panel
+    const int total = (int)gridDim.x, per = (total + 7) / 8;
+    const int q = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    const int mt = q / ntn, nt = q - mt * ntn;
+    if (mt * NT_M >= C_out) return;
+    const int c0 = mt * NT_M, i0 = nt * NT_N;
+    // staging: 8 gene pairs per row (16 genes: one 128-byte line of an f64 row), 32 rows per pass
+    constexpr int PR = NT_KS / 2, RP = GM_THREADS / PR, UA = NT_M / RP, UB = NT_N / RP;
+    const int cp = tid % PR, r0 = tid / PR;
+    double ra[UA][2], rd[UA][2], rb[UB][2];
+    auto fetch = [&](int g0) {
+        const int g = g0 + 2 * cp;
+        const int gc = g < ld ? g : 0;                                // rows are padded to an even pitch: a pair below the pitch lies inside its row
+#pragma unroll
+        for (int u = 0; u < UA; ++u) {
+            const int64_t row = cell0 + min(c0 + r0 + RP * u, C_out - 1);
+            load2<T>(e + row * ld + gc, ra[u][0], ra[u][1]);
+            load2<T>(d + row * ld + gc, rd[u][0], rd[u][1]);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int64_t row = min(i0 + r0 + RP * u, C - 1);
+            load2<T>(e + row * ld + gc, rb[u][0], rb[u][1]);
+        }
+    };
+    auto stash = [&](int buf, int g0) {
+        const int g = g0 + 2 * cp;
+        const bool k0 = g < G, k1 = g + 1 < G;
+#pragma unroll
+        for (int u = 0; u < UA; ++u) {
+            const int r = r0 + RP * u;
+            const bool in = c0 + r < C_out;
+            double *pe = Es + (buf * NT_M + r) * NT_LD + 2 * cp, *pd = Ds + (buf * NT_M + r) * NT_LD + 2 * cp;
+            pe[0] = (in && k0) ? ra[u][0] : 0.0; pe[1] = (in && k1) ? ra[u][1] : 0.0;
+            pd[0] = (in && k0) ? rd[u][0] : 0.0; pd[1] = (in && k1) ? rd[u][1] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int r = r0 + RP * u;
+            const bool in = i0 + r < C;
+            double *pb = Bs + (buf * NT_N + r) * NT_LD + 2 * cp;
+            pb[0] = (in && k0) ? rb[u][0] : 0.0; pb[1] = (in && k1) ? rb[u][1] : 0.0;
+        }
+    };
+    const int wm = wave >> 1, wn = wave & 1;
+    const int wi = wm * 64, wj = wn * (NT_N / 2);                     // the wave's corner inside the tile
+    v4d_t accE[4][NT_YT], accD[4][NT_YT];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < NT_YT; ++y) { accE[x][y] = v4d_t{0.0, 0.0, 0.0, 0.0}; accD[x][y] = v4d_t{0.0, 0.0, 0.0, 0.0}; }
+    const int lrow = lane >> 4, lcol = lane & 15;
+    int buf = 0;
+    fetch(0);
+    stash(0, 0);
+    __syncthreads();
+    for (int g0 = 0; g0 < G; g0 += NT_KS) {
+        const bool more = g0 + NT_KS < G;
+        if (more) fetch(g0 + NT_KS);                                  // next slab in flight while this one is multiplied
+        __builtin_amdgcn_sched_barrier(0);
+        const double *es = Es + buf * NT_M * NT_LD, *ds = Ds + buf * NT_M * NT_LD, *bs = Bs + buf * NT_N * NT_LD;
+#pragma unroll
+        for (int kk = 0; kk < NT_KS / 4; ++kk) {
+            double a[4], b2[4], b[NT_YT];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                a[x] = es[(wi + x * 16 + lcol) * NT_LD + kk * 4 + lrow];
+                b2[x] = ds[(wi + x * 16 + lcol) * NT_LD + kk * 4 + lrow];
+            }
+#pragma unroll
+            for (int y = 0; y < NT_YT; ++y) b[y] = bs[(wj + y * 16 + lcol) * NT_LD + kk * 4 + lrow];
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < NT_YT; ++y) {
+                    accE[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], accE[x][y], 0, 0, 0);
+                    accD[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(b2[x], b[y], accD[x][y], 0, 0, 0);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) stash(buf ^ 1, g0 + NT_KS);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // ---- epilogue: D[row = (lane >> 4) + 4 reg][col = lane & 15] of every 16 x 16 tile -> Pearson's r of the pair (c, i)
+    const double n = (double)G, eps64 = 64.0 * 2.220446049250313e-16;
+#pragma unroll
+    for (int y = 0; y < NT_YT; ++y) {
+        const int i = i0 + wj + y * 16 + lcol;
+        const bool iok = i < C;
+        const double Se_i = iok ? sums[5 * (int64_t)i] : 0.0, See_i = iok ? sums[5 * (int64_t)i + 1] : 0.0;
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cl = c0 + wi + x * 16 + lrow + 4 * r;
+                if (!(iok && cl < C_out)) continue;
+                const double *sc = sums + 5 * (cell0 + cl);
+                const double Se_c = sc[0], See_c = sc[1], sb = sc[2], sbb = sc[3], sed = sc[4];
+                const double sA = Se_i - Se_c;
+                const double sAA = See_i + See_c - 2.0 * accE[x][y][r];
+                const double sAb = accD[x][y][r] - sed;
+                const double cov = sAb - sA * sb / n, va = sAA - sA * sA / n, vb = sbb - sb * sb / n;
+                double v = cov / sqrt(va * vb);
+                // i == c, duplicate cells (e_i == e_c) and a constant d_c: the reference's centred sums are exactly zero there (0 * inf = NaN);
+                // the expanded moments leave rounding noise of either sign - variances below the noise floor of the expansion (a few ulps
+                // of the terms that cancel) are zero
+                if ((int64_t)i == cell0 + cl || va <= eps64 * (See_i + See_c) || vb <= eps64 * sbb) v = __builtin_nan("");
+                OT *o = rm + (int64_t)cl * ld_rm + i;
+                *o = accumulate ? (OT)((double)*o + v) : (OT)v;
+            }
+    }
+}
+
 }  // namespace vcy
 
 using namespace vcy;
@@ -345,4 +520,37 @@ extern "C" int vcy_gram_tn(const void *X, const double *mean, const double *Y, d
     hipStream_t st = as_stream(stream);
     if (dtype == VCY_F32) return launch_gram<float, double, false>(X, Y, mean, nullptr, out, workspace, C, G, L, ld, ldy, ldo, st);
     return launch_gram<double, double, false>(X, Y, mean, nullptr, out, workspace, C, G, L, ld, ldy, ldo, st);
+}
+
+extern "C" size_t vcy_coldeltacor_full_linear_workspace_bytes(int64_t C) { return C > 0 ? (size_t)C * 5 * sizeof(double) : 0; }
+
+extern "C" int vcy_coldeltacor_full_linear(const void *e, const void *d, void *rm, void *workspace, int64_t C, int64_t G, int64_t ld, int64_t cell0,
+                                           int64_t C_out, int64_t ld_rm, int accumulate, int dtype, vcy_stream stream)
+{
+    VCY_REQUIRE(e && d && rm && workspace, "coldeltacor_full_linear: null pointer");
+    VCY_REQUIRE(C > 0 && G > 0 && C_out > 0 && cell0 >= 0 && cell0 + C_out <= C && ld >= G && ld_rm >= C, "coldeltacor_full_linear: bad shape");
+    VCY_REQUIRE(C < (1LL << 31) && G < (1LL << 31), "coldeltacor_full_linear: dimension too large");
+    VCY_REQUIRE(dtype == VCY_F32 || dtype == VCY_F64, "coldeltacor_full_linear: bad dtype");
+    VCY_REQUIRE(ld % (dtype == VCY_F32 ? 4 : 2) == 0 && ((uintptr_t)e % 16) == 0 && ((uintptr_t)d % 16) == 0, "coldeltacor_full_linear: rows must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    double *sums = (double *)workspace;
+    const int64_t ntm = (C_out + NT_M - 1) / NT_M, ntn = (C + NT_N - 1) / NT_N;
+    const int64_t blocks = (ntm * ntn + 7) / 8 * 8;
+    VCY_REQUIRE(blocks < (1LL << 31), "coldeltacor_full_linear: grid too large");
+    const size_t lds = (size_t)2 * (2 * NT_M + NT_N) * NT_LD * sizeof(double);
+    int rc;
+#define VCY_NT(T)                                                                                                                          \
+    do {                                                                                                                                   \
+        hipLaunchKernelGGL(k_cell_linear_sums<T>, dim3((unsigned)C), dim3(256), 0, st, (const T *)e, (const T *)d, sums, (int)G, ld, cell0, (int)C_out); \
+        VCY_LAUNCH_CHECK();                                                                                                                \
+        auto kern = k_cdc_full_linear<T, T>;                                                                                               \
+        rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);                                                                \
+        if (rc) return rc;                                                                                                                 \
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(GM_THREADS), lds, st, (const T *)e, (const T *)d, (const double *)sums, (T *)rm, (int)C, (int)G, \
+                           ld, cell0, (int)C_out, ld_rm, accumulate, (int)ntn);                                                            \
+    } while (0)
+    if (dtype == VCY_F32) VCY_NT(float); else VCY_NT(double);
+#undef VCY_NT
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
 }

@@ -622,55 +622,20 @@ def coldeltacor_full(e: CellMatrix, d: CellMatrix, transform: int, psc: float = 
         rm = torch.zeros((C_out, e.C), dtype=e.dtype, device=e.t.device)
         accumulate = False
     assert rm.is_contiguous() and rm.shape == (C_out, e.C) and rm.dtype == e.dtype
-    if transform == LINEAR and FULL_LINEAR_GEMM:
-        return _coldeltacor_full_linear_gemm(e, d, cell0, C_out, rm, accumulate)
-    _lib.check(_lib.lib().vcy_coldeltacor_full(e.t.data_ptr(), d.t.data_ptr(), rm.data_ptr(), e.C, e.G, e.ld, cell0, C_out,
-                                               rm.shape[1], transform, float(psc), int(accumulate), e.code, _stream()),
+    L = _lib.lib()
+    if transform == LINEAR and FULL_LINEAR_MFMA:
+        # the one dense block contraction of the path (E E^T and D E^T over the genes): f64 matrix cores, Pearson epilogue fused
+        ws = torch.empty(int(L.vcy_coldeltacor_full_linear_workspace_bytes(e.C)), dtype=torch.uint8, device=e.t.device)
+        _lib.check(L.vcy_coldeltacor_full_linear(e.t.data_ptr(), d.t.data_ptr(), rm.data_ptr(), ws.data_ptr(), e.C, e.G, e.ld, cell0, C_out,
+                                                 rm.shape[1], int(accumulate), e.code, _stream()), "coldeltacor_full_linear")
+        return rm
+    _lib.check(L.vcy_coldeltacor_full(e.t.data_ptr(), d.t.data_ptr(), rm.data_ptr(), e.C, e.G, e.ld, cell0, C_out,
+                                      rm.shape[1], transform, float(psc), int(accumulate), e.code, _stream()),
                "coldeltacor_full")
     return rm
 
 
-FULL_LINEAR_GEMM = True    # the all-pairs LINEAR variant as two plain GEMMs (rocBLAS, fp64 MFMA); False = the VALU kernel
-
-
-def _coldeltacor_full_linear_gemm(e: CellMatrix, d: CellMatrix, cell0: int, C_out: int, rm: torch.Tensor, accumulate: bool,
-                                  block: int = 4096) -> torch.Tensor:
-    """speedboosted._colDeltaCor (speedboosted.pyx:13-87) without a transform is separable: with A = e_i - e_c, b = d_c
-        sum A  = Se_i - Se_c,   sum A^2 = See_i + See_c - 2 (E E^T)[c,i],   sum A b = (D E^T)[c,i] - sum_g e_cg d_cg,
-    i.e. two (rows x G) x (G x C) matrix products - the one place on the path that IS a dense contraction, so it goes to
-    the library GEMM in fp64 (the expansion of sum A^2 cancels catastrophically in f32 when e_i is close to e_c).
-    Measured 10k x 20k: 346 ms on the VALU kernel."""
-    G, n = e.G, float(e.G)
-    E = e.t[:, :G].double()
-    Se, See = E.sum(1), (E * E).sum(1)
-    for r0 in range(0, C_out, block):
-        r1 = min(C_out, r0 + block)
-        Eb = E[cell0 + r0:cell0 + r1]
-        Db = d.t[cell0 + r0:cell0 + r1, :G].double()
-        sb, sbb, sed = Db.sum(1), (Db * Db).sum(1), (Eb * Db).sum(1)
-        sA = Se[None, :] - Se[cell0 + r0:cell0 + r1, None]
-        sAA = See[None, :] + See[cell0 + r0:cell0 + r1, None] - 2.0 * (Eb @ E.T)
-        sAb = Db @ E.T - sed[:, None]
-        cov = sAb - sA * sb[:, None] / n
-        va = sAA - sA * sA / n
-        vb = (sbb - sb * sb / n)[:, None]
-        # rounding of the expanded moments can leave a tiny negative variance where it is exactly zero (i == c, duplicate
-        # cells): those entries are NaN in the reference (0 * inf) and stay NaN here
-        r = cov / torch.sqrt(va * vb)
-        idx = torch.arange(r0, r1, device=r.device)
-        r[idx - r0, cell0 + idx] = float("nan")
-        # duplicate cells (e_i == e_c) and constant d_c: the reference's centred sums are exactly zero there (0 * inf = NaN);
-        # the expanded moments leave rounding noise of either sign - treat variances below the noise floor of the
-        # expansion (a few ulps of the terms that cancel) as zero
-        noise_a = 64 * torch.finfo(torch.float64).eps * (See[None, :] + See[cell0 + r0:cell0 + r1, None])
-        noise_b = (64 * torch.finfo(torch.float64).eps * sbb)[:, None]
-        r[(va <= noise_a) | (vb <= noise_b)] = float("nan")
-        r = r.to(rm.dtype)
-        if accumulate:
-            rm[r0:r1] += r
-        else:
-            rm[r0:r1] = r
-    return rm
+FULL_LINEAR_MFMA = True    # the all-pairs LINEAR variant on the f64 matrix cores (vcy_coldeltacor_full_linear); False = the element-wise kernel
 
 
 def scatter_rows(vals: torch.Tensor, ixs, ncols: int, rm: Optional[torch.Tensor] = None) -> torch.Tensor:
