@@ -633,39 +633,54 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
                 m = mn;
             }
         };
+        // tickets: quads of rows first, then - for the last TAIL rows of the chunk - pairs: the waves reach the chunk barrier within one
+        // ticket of each other, and a pair is half the wait of a quad (round 5, one box, stage D at 50k x 30k: f64 234.7 -> 233.8 ms,
+        // f32 72.7 -> 71.7; profiles/r05_tail_tickets.txt)
         auto rows = [&](auto fullc) {
-            auto ticket = [&]() { int t = 0; if (lane == 0) t = atomicAdd(s_next, RQ); return t; };     // lane 0 holds the value
+            auto ticket = [&]() { int t = 0; if (lane == 0) t = atomicAdd(s_next, 1); return t; };     // lane 0 holds the value
             auto uni = [&](unsigned long long v) {
                 const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
                 const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
                 return ((unsigned long long)hi << 32) | lo;
             };
-            // (rows stay in ascending neighbour order: a longest-first queue measured 4 % slower - it trades the
-            //  last few % of balance for scattered HBM pages)
+            constexpr int TAIL = 64;
+            const int U4 = U > TAIL ? ((U - TAIL) & ~3) : 0, T4 = U4 >> 2;
+            auto first_row = [&](int v) { return v < T4 ? 4 * v : U4 + 2 * (v - T4); };
             V xa[NV], xb[NV];
-            int tv = ticket();
-            int q = __builtin_amdgcn_readfirstlane(tv);
-            unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0;        // w0..w3: the descriptors of the quad in hand, n0..n3: of the next
+            int v = __builtin_amdgcn_readfirstlane(ticket());
+            int q = min(first_row(v), U);
+            unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0;
             if (q < U) { w0 = uni(desc[q]); w1 = uni(desc[min(q + 1, U - 1)]); w2 = uni(desc[min(q + 2, U - 1)]); w3 = uni(desc[min(q + 3, U - 1)]); }
             if (q < U) load_row(fullc, xa, w0);
-            while (q < U) {
-                tv = ticket();
-                if (q + 1 < U) load_row(fullc, xb, w1);
+            while (v < T4) {                                     // a quad: rows q .. q + 3, all below U4
+                const int tv = ticket();
+                load_row(fullc, xb, w1);
                 eval_row(xa, w0);
-                if (q + 1 >= U) break;
-                if (q + 2 < U) load_row(fullc, xa, w2);
+                load_row(fullc, xa, w2);
                 eval_row(xb, w1);
-                const int qn = __builtin_amdgcn_readfirstlane(tv);
-                unsigned long long n0 = 0, n1 = 0, n2 = 0, n3 = 0;                     // requested here, read after the next row
+                const int vn = __builtin_amdgcn_readfirstlane(tv);
+                const int qn = min(first_row(vn), U);
+                unsigned long long n0 = 0, n1 = 0, n2 = 0, n3 = 0;
                 if (qn < U) { n0 = desc[qn]; n1 = desc[min(qn + 1, U - 1)]; n2 = desc[min(qn + 2, U - 1)]; n3 = desc[min(qn + 3, U - 1)]; }
-                if (q + 2 >= U) break;
-                if (q + 3 < U) load_row(fullc, xb, w3);
+                load_row(fullc, xb, w3);
                 eval_row(xa, w2);
-                if (q + 3 >= U) break;
                 if (qn < U) { n0 = uni(n0); n1 = uni(n1); n2 = uni(n2); n3 = uni(n3); }
                 if (qn < U) load_row(fullc, xa, n0);
                 eval_row(xb, w3);
-                q = qn; w0 = n0; w1 = n1; w2 = n2; w3 = n3;
+                v = vn; q = qn; w0 = n0; w1 = n1; w2 = n2; w3 = n3;
+            }
+            while (q < U) {                                      // a pair: rows q, q + 1
+                const int tv = ticket();
+                const bool two = q + 1 < U;
+                if (two) load_row(fullc, xb, w1);
+                eval_row(xa, w0);
+                const int vn = __builtin_amdgcn_readfirstlane(tv);
+                const int qn = min(first_row(vn), U);
+                unsigned long long n0 = 0, n1 = 0;
+                if (qn < U) { n0 = uni(desc[qn]); n1 = uni(desc[min(qn + 1, U - 1)]); }
+                if (qn < U) load_row(fullc, xa, n0);
+                if (two) eval_row(xb, w1);
+                v = vn; q = qn; w0 = n0; w1 = n1;
             }
         };
         if (nvec == 64 * NV) rows(std::true_type{}); else rows(std::false_type{});
