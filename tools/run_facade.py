@@ -64,5 +64,5 @@ for _pass in range(int(os.environ.get("PASSES", 1))):          # PASSES=2: the s
     timed("estimate_transition_prob", vlm.estimate_transition_prob, hidim="Sx_sz", embed="ts", n_neighbors=500, sampled_fraction=0.5)
     timed("calculate_embedding_shift", vlm.calculate_embedding_shift)
     timed("prepare_markov", vlm.prepare_markov, 2.0, 4.0)
-    timed("run_markov(2500)", vlm.run_markov)
+    timed(f"run_markov({int(os.environ.get('MARKOV_STEPS', 2500))})", vlm.run_markov, n_steps=int(os.environ.get("MARKOV_STEPS", 2500)))
     print("total", time.perf_counter() - t_all, "s;  delta_embedding[:2] =", vlm.delta_embedding[:2])
