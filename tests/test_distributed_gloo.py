@@ -220,7 +220,7 @@ def _self_check_worker(rank, world, port, inject, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,inject", [(2, ""), (4, ""), (3, "all_to_all_uneven@1")])      # 4 ranks: empty segments between different ranks
+@pytest.mark.parametrize("world,inject", [(2, ""), (4, ""), (3, "all_to_all_uneven@1"), (8, ""), (3, "all_to_all_halo_sizes@2")])      # 4 ranks: empty segments between different ranks; 8: the split table of cfg3
 def test_collective_self_check(world, inject):
     """distributed.self_check: every collective shape of the sharded path on tiny tensors (uneven all-to-all with empty
     segments, ragged and equal all-gathers, SUM / MIN all-reduces, the halo masks).  A failure on ONE rank becomes the same

@@ -330,7 +330,14 @@ def overlap_schedules(base: torch.Tensor, interior: torch.Tensor, cells_per_roun
     return first.to(torch.int32).contiguous(), base[~taken[base]].to(torch.int32).contiguous()
 
 
-SELF_CHECKS = ("all_reduce_sum", "all_reduce_min", "all_to_all_uneven", "all_gather_rows_equal", "all_gather_rows_ragged", "all_gather_masks")
+SELF_CHECKS = ("all_reduce_sum", "all_reduce_min", "all_to_all_uneven", "all_to_all_halo_sizes", "all_gather_rows_equal", "all_gather_rows_ragged", "all_gather_masks")
+
+# Halo rows rank r RECEIVES from peer p in the 8-rank run of cfg3 (50 000 cells x 30 000 genes, Hilbert-ordered shards, nrndm 250):
+# profiles/r04_shard_model.json, worlds["8"].ranks[r].halo_bytes_per_peer / (30 016 x 8 B).  The start-up check replays exactly these
+# split vectors - empty segments, 7-row and 3 000-row segments side by side - at the real row width where the device has the memory
+# (up to 723 MB to one peer: the size-dependent paths of the transport are built and used once before real data moves).
+CFG3_HALO_ROWS_8 = ((0, 2119, 0, 0, 0, 0, 0, 0), (3013, 0, 1389, 7, 0, 0, 0, 0), (0, 202, 0, 375, 228, 0, 0, 0), (0, 108, 1413, 0, 1568, 0, 106, 0),
+                    (0, 0, 329, 1446, 0, 956, 1373, 38), (0, 0, 0, 0, 580, 0, 1833, 0), (0, 0, 0, 302, 947, 1732, 0, 1524), (0, 0, 0, 0, 57, 0, 1435, 0))
 
 
 def self_check(device: torch.device, group=None) -> dict:
@@ -383,6 +390,35 @@ def self_check(device: torch.device, group=None) -> dict:
                          [torch.empty((0, 4), dtype=torch.float32, device=device)])
         assert recv.shape == want.shape and torch.equal(recv, want), "rows arrived in the wrong place"
 
+    def a2a_sizes():
+        # the halo exchange at the SIZES of a real run: at 8 ranks cfg3's own table and row width (f64, 30 016 columns: 240 KB per row) when the
+        # device has room for it; any other world size (and CPU tensors): the same kind of table - empty, short and long segments - on narrow rows
+        if ws == 8:
+            table = CFG3_HALO_ROWS_8
+        else:
+            table = tuple(tuple(0 if (src == dst or (7 * src + 3 * dst) % 4 == 0) else 5 + 997 * ((src + 2 * dst) % 5) for src in range(ws)) for dst in range(ws))
+        recv_splits = list(table[rank])
+        send_splits = [table[p][rank] for p in range(ws)]
+        width = 4
+        if ws == 8 and device.type == "cuda":
+            free, _ = torch.cuda.mem_get_info(device)
+            if free > 3 * (sum(recv_splits) + sum(send_splits)) * 30016 * 8:
+                width = 30016
+        dt = torch.float64 if width > 4 else torch.float32
+        send = torch.empty((sum(send_splits), width), dtype=dt, device=device)
+        o = 0
+        for p, n in enumerate(send_splits):
+            send[o:o + n] = 1000.0 * rank + p
+            o += n
+        recv = all_to_all_uneven(send, send_splits, recv_splits, group)
+        assert recv.shape == (sum(recv_splits), width), f"received {tuple(recv.shape)}"
+        o = 0
+        for p, n in enumerate(recv_splits):
+            if n:
+                seg = recv[o:o + n]
+                assert float(seg.min()) == float(seg.max()) == 1000.0 * p + rank, f"segment of peer {p} holds {float(seg.min())} .. {float(seg.max())}"
+            o += n
+
     def gather(n_total):
         def run():
             a, b = shard_bounds(n_total, ws, rank)
@@ -401,6 +437,7 @@ def self_check(device: torch.device, group=None) -> dict:
         raise RuntimeError(f"rank {rank}: the basic all-reduce of the '{dist.get_backend(group)}' backend failed, no sharded run is possible: {res['all_reduce_sum']}")
     attempt("all_reduce_min", ar_min)
     attempt("all_to_all_uneven", a2a)
+    attempt("all_to_all_halo_sizes", a2a_sizes)
     attempt("all_gather_rows_equal", gather(2 * ws))
     attempt("all_gather_rows_ragged", gather(2 * ws + 1) if ws > 1 else gather(2))
     attempt("all_gather_masks", masks)
