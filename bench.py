@@ -69,8 +69,8 @@ MIX_CLK_PER_ELEMENT = {1: 27.7, 2: 23.3}
 # wall-clock column; the 19-instruction form it replaced: 83.2)
 MIX_CLK_PER_ELEMENT_F64 = 77.4
 F64_ISSUE_CLK = 4.1               # clocks per wave64 v_add_f64 / v_mul_f64 / v_fma_f64 per SIMD (same file): the f64 issue peak is 1 instruction / 4 clocks
-COUNTERS_FILE = os.path.join(ROOT, "profiles", "r04_cdc_counters.json")     # written by tools/summarize_profiles.py from the rocprofv3 passes
-COUNTERS_FALLBACK = os.path.join(ROOT, "profiles", "r03_cdc_counters.json")
+COUNTERS_FILE = os.path.join(ROOT, "profiles", "r05_cdc_counters.json")     # written by tools/summarize_profiles.py from the rocprofv3 passes
+COUNTERS_FALLBACK = os.path.join(ROOT, "profiles", "r04_cdc_counters.json")
 
 
 def parse():

@@ -170,6 +170,34 @@ def test_atlas_path_equals_resident_dense_path(ops):
     assert many.peak_block_bytes < one.peak_block_bytes / 2        # the point of streaming: O(block) dense memory
 
 
+def test_atlas_path_in_f64_with_garbage_in_the_staging_buffers(ops):
+    """The f64 atlas pass (the bench's default arithmetic) over several blocks, with the staging buffers holding what a caching allocator
+    may hand out - bit patterns that read as 1e300 / inf / NaN in f64 - before the first block is pooled: the square-root domain check looks
+    at the pooled blocks (the matrix itself), never at rows of the staging buffer that are not written yet, and the blocked run equals
+    the one-block run."""
+    from velocyto_amd import atlas
+    dev = ops.require_gpu()
+    C, G, k = 4000, 2100, 10
+    cS, cU, totS, totU, pcs, emb = atlas.synth_atlas(C, G, 10, dev, density=0.08)
+    fS, fU = atlas.size_factors(totS, totU, C)
+    one = atlas.AtlasPath(cS, cU, fS, fU, pcs, emb, k=k, n_neighbors=80, sampled_fraction=0.5, block_cells=0, dtype=torch.float64)
+    c1 = one.run().clone()
+    many = atlas.AtlasPath(cS, cU, fS, fU, pcs, emb, k=k, n_neighbors=80, sampled_fraction=0.5, block_cells=900, dtype=torch.float64)
+    assert len(many.blocks()) >= 4
+    many._ebuf.t[:, :G] = 1e308                                          # (the zero padding beyond G is the buffers' invariant: left alone)
+    many._ebuf.t[::7, :G] = float("nan")
+    many._ubuf.t[:, :G] = float("inf")
+    c5 = many.run()
+    fin = torch.isfinite(c1)
+    assert torch.equal(torch.isfinite(c5), fin)
+    assert float((c5[fin] - c1[fin]).abs().max()) <= 1e-12
+    torch.testing.assert_close(many.gamma, one.gamma, rtol=1e-6, atol=1e-12)
+    # a matrix that really leaves the domain is refused, by name
+    big = atlas.AtlasPath(cS, cU, fS * 1e40, fU, pcs, emb, k=k, n_neighbors=80, sampled_fraction=0.5, block_cells=900, dtype=torch.float64)
+    with pytest.raises(ValueError, match="outside the supported range"):
+        big.run()
+
+
 ARGS = ["--workload", "cfg5", "--no-cpu-baseline", "--cells", "9000", "--genes", "2100", "--n-neighbors", "100", "--k", "12", "--pca-dims", "10",
         "--steps", "1", "--warmup", "0"]
 
