@@ -440,6 +440,7 @@ def hip_subproblem(pipe, args, Cs, ixs, dtype, rules):
     gamma = ops.fit_slope_from_moments(ops.fit_slope_moments(Ux, Sx))
     gamma[~torch.isfinite(gamma)] = 0.0
     corr = ops.coldeltacor_partial_fused(Sx, Ux, gamma, None, torch.from_numpy(ixs.astype(np.int32)).to(dev), ops.SQRT, rules, 1e-10, validate=False)
+    pipe._last_sub_Ux = Ux
     return Sx, gamma, corr
 
 
@@ -588,6 +589,19 @@ def cpu_baseline(pipe, args):
                         "nan_pattern_equal": bool(np.array_equal(np.isnan(hc), ~ok)),
                         "max_rel_dgamma": float((np.abs(hg[pos] - gam0[pos]) / gam0[pos]).max()),
                         "max_rel_dSx": float((np.abs(sx - Sx) / np.maximum(np.abs(Sx), 1e-30))[Sx != 0].max())}
+        if name == "f64":
+            # stage D alone on IDENTICAL inputs (the HIP path's own pooled matrices and gammas handed to the oracle).  The figure above runs
+            # all four stages on both sides: the two poolings sum in different orders, their results differ in the last bit (max_rel_dSx), and
+            # the reference's rule is discontinuous at |t| = 1e-16 (speedboosted.pyx:372: A jumps from 0 to +-sqrt(psc) = 1e-5) - on a small
+            # closed sub-problem, where pooled neighbourhoods overlap heavily, many genes of a pair sit exactly there
+            ux = pipe._last_sub_Ux.t[:, :G].double().cpu().numpy().T
+            _, _, dS_h, _ = oracle.velocity_chain(sx, ux, hg, None)
+            d_h = oracle.delta_transform(sx, sx + dS_h, "sqrt", 1e-10)
+            c_h = oracle.coldeltacor_partial_compact(sx, d_h, ixs, "sqrt", 1e-10, threads=cores)
+            ok_h = np.isfinite(c_h)
+            parity[name]["stage_D_on_identical_inputs"] = {"max_abs_dcorr": float(np.abs(hc[ok_h] - c_h[ok_h]).max()),
+                                                             "nan_pattern_equal": bool(np.array_equal(np.isnan(hc), ~ok_h))}
+            del ux, dS_h, d_h, c_h
         del hSx, hg, hc, sx
     closed = {"cells": Cs, "stage_s": {"A": tA, "B": tB, "C": tC, "D_restatement": tD, **({"D_reference": ref["D_s"]} if ref and "D_s" in ref else {})},
               "restatement_threads": cores, "reference_kernel": ref,

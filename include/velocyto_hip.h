@@ -143,7 +143,8 @@ int vcy_coldeltacor_full(const void *e, const void *d, void *rm, int64_t C, int6
  * genes on the f64 matrix cores (v_mfma_f64_16x16x4_f64, 128 x 64 tiles) with Pearson's r, the NaN rule of zero variances (i == c,
  * duplicate cells, a constant d_c: variances below 64 ulp of the terms that cancel) and the `rm[c][i] (+)= r` store fused into the
  * epilogue.  Same arguments as vcy_coldeltacor_full; workspace: vcy_coldeltacor_full_linear_workspace_bytes(C) bytes (five f64 sums per
- * cell).  f64 arithmetic whatever `dtype` the matrices are stored in.                                                                    */
+ * cell).  f64 arithmetic whatever `dtype` the matrices are stored in.  ld must be a multiple of 16 and the columns G .. ld - 1 of e and d
+ * zero (the cells-major layout's padding, as vcy_transpose writes it).                                                                  */
 size_t vcy_coldeltacor_full_linear_workspace_bytes(int64_t C);
 int vcy_coldeltacor_full_linear(const void *e, const void *d, void *rm, void *workspace, int64_t C, int64_t G, int64_t ld, int64_t cell0,
                                 int64_t C_out, int64_t ld_rm, int accumulate, int dtype, vcy_stream stream);

@@ -184,6 +184,7 @@ def test_atlas_path_in_f64_with_garbage_in_the_staging_buffers(ops):
     c1 = one.run().clone()
     many = atlas.AtlasPath(cS, cU, fS, fU, pcs, emb, k=k, n_neighbors=80, sampled_fraction=0.5, block_cells=900, dtype=torch.float64)
     assert len(many.blocks()) >= 4
+    many._plan_blocks()                                                  # (the staging buffers are allocated with the block plan)
     many._ebuf.t[:, :G] = 1e308                                          # (the zero padding beyond G is the buffers' invariant: left alone)
     many._ebuf.t[::7, :G] = float("nan")
     many._ubuf.t[:, :G] = float("inf")
@@ -196,6 +197,7 @@ def test_atlas_path_in_f64_with_garbage_in_the_staging_buffers(ops):
     big = atlas.AtlasPath(cS, cU, fS * 1e40, fU, pcs, emb, k=k, n_neighbors=80, sampled_fraction=0.5, block_cells=900, dtype=torch.float64)
     with pytest.raises(ValueError, match="outside the supported range"):
         big.run()
+    torch.cuda.synchronize()
 
 
 ARGS = ["--workload", "cfg5", "--no-cpu-baseline", "--cells", "9000", "--genes", "2100", "--n-neighbors", "100", "--k", "12", "--pca-dims", "10",

@@ -296,11 +296,14 @@ static int launch_gram(const void *A, const void *B, const double *ma, const dou
 // [row][gene] with an odd row pitch (17 doubles): an A- or B-fragment of v_mfma_f64_16x16x4_f64 is row (lane & 15), gene (lane >> 4) of a
 // 16 x 4 block, and the 16 rows of a quarter-wave start in 16 different bank pairs.  The expansion of sum A^2 cancels where e_i is
 // close to e_c - which is why everything is f64 whatever the storage type.
-// Measured at 10 000 cells x 20 000 genes, f64 (tools/bench_full.py, profiles/r05_full_linear.txt): 155 ms = 51.6 Tflop/s = 0.66 of the f64
-// matrix peak at a shader clock of 2.37 GHz (vcy_clock_probe: not power-limited), 2.8 x the element-wise kernel (430 ms); the same algebra as
-// two library GEMMs + eager elementwise passes (round 4's route) takes 122 ms.  Tile width (64 / 128 cells i, the latter with 256
-// accumulators in AGPRs at one workgroup per CU), slab depth (16 / 32 genes) and the LDS pitch (17 / 18 doubles) all measure 155-159 ms: the
-// kernel waits on its one-slab-ahead prefetch, not on LDS or the matrix cores.  VCY_NT_N / VCY_NT_KS / VCY_NT_PAD rebuild the variants.
+// Measured at 10 000 cells x 20 000 genes, f64 (tools/bench_full.py, profiles/r05_full_linear.txt): 146 ms = 54.8 Tflop/s = 0.70 of the f64
+// matrix peak at a shader clock of 2.36 GHz (vcy_clock_probe: not power-limited; SQ_VALU_MFMA_BUSY_CYCLES: the matrix pipes busy 0.70 of the
+// launch), 3.0 x the element-wise kernel (432 ms); the same algebra as two library GEMMs + eager elementwise passes (round 4's route) takes
+// 123 ms.  Steps of the round: 155 ms with masked LDS writes after the slab's matrix instructions; 149.7 without the masks (nothing to
+// mask: the contraction runs over zero-padded genes); 146 with the LDS writes issued between the third and the fourth quarter of the
+// slab.  What does NOT move it: the tile width (64 / 128 cells i), the slab depth (16 / 32 genes where LDS allows), the LDS pitch (17 / 18
+// doubles), issuing the loads a whole slab earlier.  Two workgroups per CU (two waves per SIMD) run the same code in step: both reach
+// their barriers and their fragment reads together.  VCY_NT_N / VCY_NT_KS / VCY_NT_PAD rebuild the variants.
 #ifndef VCY_NT_N
 #define VCY_NT_N 64
 #endif
@@ -369,23 +372,23 @@ __global__ __launch_bounds__(GM_THREADS, NT_N == 128 ? 1 : 2) void k_cdc_full_li
             load2<T>(e + row * ld + gc, rb[u][0], rb[u][1]);
         }
     };
+    // no masks on the way into LDS: the contraction runs over the genes, and the rows of e and d are zero beyond G up to their pitch (the
+    // layout's invariant, velocyto_hip.h) - a slab that ends past G adds zeros; rows past the last cell are clamped copies whose outputs
+    // the epilogue never writes
     auto stash = [&](int buf, int g0) {
-        const int g = g0 + 2 * cp;
-        const bool k0 = g < G, k1 = g + 1 < G;
+        (void)g0;
 #pragma unroll
         for (int u = 0; u < UA; ++u) {
             const int r = r0 + RP * u;
-            const bool in = c0 + r < C_out;
             double *pe = Es + (buf * NT_M + r) * NT_LD + 2 * cp, *pd = Ds + (buf * NT_M + r) * NT_LD + 2 * cp;
-            pe[0] = (in && k0) ? ra[u][0] : 0.0; pe[1] = (in && k1) ? ra[u][1] : 0.0;
-            pd[0] = (in && k0) ? rd[u][0] : 0.0; pd[1] = (in && k1) ? rd[u][1] : 0.0;
+            pe[0] = ra[u][0]; pe[1] = ra[u][1];
+            pd[0] = rd[u][0]; pd[1] = rd[u][1];
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int r = r0 + RP * u;
-            const bool in = i0 + r < C;
             double *pb = Bs + (buf * NT_N + r) * NT_LD + 2 * cp;
-            pb[0] = (in && k0) ? rb[u][0] : 0.0; pb[1] = (in && k1) ? rb[u][1] : 0.0;
+            pb[0] = rb[u][0]; pb[1] = rb[u][1];
         }
     };
     const int wm = wave >> 1, wn = wave & 1;
@@ -399,11 +402,10 @@ __global__ __launch_bounds__(GM_THREADS, NT_N == 128 ? 1 : 2) void k_cdc_full_li
     int buf = 0;
     fetch(0);
     stash(0, 0);
-    __syncthreads();
+    if (NT_KS < G) fetch(NT_KS);                                      // the loads of a slab are issued as soon as the staging registers are free:
+    __syncthreads();                                                  // a whole slab of matrix instructions ahead of the LDS writes that wait for them
     for (int g0 = 0; g0 < G; g0 += NT_KS) {
         const bool more = g0 + NT_KS < G;
-        if (more) fetch(g0 + NT_KS);                                  // next slab in flight while this one is multiplied
-        __builtin_amdgcn_sched_barrier(0);
         const double *es = Es + buf * NT_M * NT_LD, *ds = Ds + buf * NT_M * NT_LD, *bs = Bs + buf * NT_N * NT_LD;
 #pragma unroll
         for (int kk = 0; kk < NT_KS / 4; ++kk) {
@@ -422,9 +424,15 @@ __global__ __launch_bounds__(GM_THREADS, NT_N == 128 ? 1 : 2) void k_cdc_full_li
                     accE[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], accE[x][y], 0, 0, 0);
                     accD[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(b2[x], b[y], accD[x][y], 0, 0, 0);
                 }
+            // the next slab goes into the OTHER buffer while the last matrix instructions of this one are still queued: its loads have had
+            // three quarters of the slab to arrive, and the LDS writes run beside the matrix pipe instead of after it
+            if (kk == NT_KS / 4 - 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) stash(buf ^ 1, g0 + NT_KS);
+                if (g0 + 2 * NT_KS < G) fetch(g0 + 2 * NT_KS);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) stash(buf ^ 1, g0 + NT_KS);
         __syncthreads();
         buf ^= 1;
     }
@@ -531,7 +539,8 @@ extern "C" int vcy_coldeltacor_full_linear(const void *e, const void *d, void *r
     VCY_REQUIRE(C > 0 && G > 0 && C_out > 0 && cell0 >= 0 && cell0 + C_out <= C && ld >= G && ld_rm >= C, "coldeltacor_full_linear: bad shape");
     VCY_REQUIRE(C < (1LL << 31) && G < (1LL << 31), "coldeltacor_full_linear: dimension too large");
     VCY_REQUIRE(dtype == VCY_F32 || dtype == VCY_F64, "coldeltacor_full_linear: bad dtype");
-    VCY_REQUIRE(ld % (dtype == VCY_F32 ? 4 : 2) == 0 && ((uintptr_t)e % 16) == 0 && ((uintptr_t)d % 16) == 0, "coldeltacor_full_linear: rows must be 16-byte aligned");
+    VCY_REQUIRE(ld % NT_KS == 0 && ((uintptr_t)e % 16) == 0 && ((uintptr_t)d % 16) == 0,
+                "coldeltacor_full_linear: the row pitch must be a multiple of 16 elements (zero beyond G) and the matrices 16-byte aligned");
     hipStream_t st = as_stream(stream);
     double *sums = (double *)workspace;
     const int64_t ntm = (C_out + NT_M - 1) / NT_M, ntn = (C + NT_N - 1) / NT_N;
