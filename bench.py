@@ -275,11 +275,13 @@ class Pipeline:
         self.stage_ms = np.zeros(7)
         self.d_ms = []
         # shader clock WHILE stage D runs, measured in this run (ops.ClockProbe: one wave per XCD on a side stream reads the shader-clock
-        # counter against the 100 MHz counter every 2 ms; it starts when the main stream reaches stage D and ends before D does)
-        self.probe = ops.ClockProbe() if world == 1 else None
+        # counter against the 100 MHz counter every 2 ms; it starts when the main stream reaches stage D and ends before D does).  The
+        # probe's eight workgroups take eight CUs away from the 160 KB-LDS workgroups of stage D (236 against 226 ms with it): it runs in
+        # EXTRA, untimed steps right after the timed ones (step(probe=True)), never inside the timed region
+        self.probe = ops.ClockProbe() if (world == 1 and os.environ.get("VCY_NO_PROBE") != "1") else None
         self.probe_samples = []
 
-    def step(self, timed=False):
+    def step(self, timed=False, probe=False):
         ops, a = self.ops, self.a
         C, G, k = a.cells, a.genes, a.k
         c0, c1 = self.c0, self.c1
@@ -311,7 +313,7 @@ class Pipeline:
         if not a.fuse:
             dmat = ops.velocity_chain(self.Sx_loc, self.Ux_loc, gamma, None, want=("dmat",), transform=ops.SQRT, psc=1e-10)["dmat"]
         ev[3].record()
-        if timed and self.probe is not None and self.d_ms:       # (the first timed step tells how long D takes; the later ones are probed)
+        if probe and self.probe is not None and self.d_ms:        # (the timed steps have told how long D takes)
             self.probe.stream.wait_event(ev[3])
             self.probe.start(0.9 * self.d_ms[-1])
             self.probe_samples.append(self.probe.samples)
@@ -372,6 +374,15 @@ class Pipeline:
             f.append(dc / np.maximum(dr, 1.0) * 0.1)
         f = np.concatenate([v.ravel() for v in f])
         return {"mean": float(f.mean()), "min": float(f.min()), "max": float(f.max()), "launches": len(self.probe_samples), "readings": int(f.size)}
+
+    def probe_clock(self, steps=3):
+        """`steps` extra, untimed steps with the clock probe running beside their stage-D launches (after the timed steps: same data, same
+        launches, the caches and the power state they left)."""
+        if self.probe is None or not self.d_ms:
+            return
+        for _ in range(steps):
+            self.step(probe=True)
+        torch.cuda.synchronize()
 
     def time_dual(self, reps=3):
         """Stage D with the randomised control of estimate_transition_prob (analysis.py:1539-1542): one dual-control launch
@@ -683,7 +694,8 @@ def dominant_roofline(a, pipe, d_ms, dtype):
     ghz = clk["mean"] if clk else None
     if clk:
         roof.update({"effective_clock_ghz": ghz, "effective_clock": {**clk, "how": "vcy_clock_probe: one wave per XCD reads the shader-clock counter (s_memtime) against "
-                     "the 100 MHz counter (s_memrealtime) every 2 ms on a side stream while the stage-D launches of the timed steps run (all but the first)"}})
+                     "the 100 MHz counter (s_memrealtime) every 2 ms on a side stream while the stage-D launches of EXTRA, untimed steps run, right after the "
+                     "timed ones in the same process (inside the timed steps the probe's workgroups would take CUs from stage D: 236 against 226 ms)"}})
     if instr is not None:
         achieved = instr * pair_chunks / (d_ms * 1e-3)
         roof.update({"achieved": achieved / 1e9, "frac": achieved / VALU_ISSUE_PEAK,
@@ -783,6 +795,7 @@ def run(a, rank, local_rank, world):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / a.steps * 1e3
+    pipe.probe_clock()                                      # untimed: the shader clock under stage D, for roofline.effective_clock_ghz
     # every rank's own view of the pass (stage times, shard and halo sizes) -> rank 0, for config.parallelism_detail
     per_rank = None
     if dist.is_initialized() and pipe.collect:
@@ -902,7 +915,9 @@ def _short(p, steps):
     for _ in range(steps):
         p.step(timed=True)
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps * 1e3
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    p.probe_clock(2)
+    return ms
 
 
 def wide_list_line(a, dev, pipe):

@@ -23,6 +23,9 @@
 // over `ksplit` workgroups per tile, each writing its partial tile to a workspace; k_gram_reduce adds the partials in a fixed
 // order (deterministic - no atomics) and mirrors.
 #include "common.h"
+#ifndef VCY_EXP
+#define VCY_EXP 0
+#endif
 
 namespace vcy {
 
@@ -296,14 +299,18 @@ static int launch_gram(const void *A, const void *B, const double *ma, const dou
 // [row][gene] with an odd row pitch (17 doubles): an A- or B-fragment of v_mfma_f64_16x16x4_f64 is row (lane & 15), gene (lane >> 4) of a
 // 16 x 4 block, and the 16 rows of a quarter-wave start in 16 different bank pairs.  The expansion of sum A^2 cancels where e_i is
 // close to e_c - which is why everything is f64 whatever the storage type.
-// Measured at 10 000 cells x 20 000 genes, f64 (tools/bench_full.py, profiles/r05_full_linear.txt): 146 ms = 54.8 Tflop/s = 0.70 of the f64
-// matrix peak at a shader clock of 2.36 GHz (vcy_clock_probe: not power-limited; SQ_VALU_MFMA_BUSY_CYCLES: the matrix pipes busy 0.70 of the
-// launch), 3.0 x the element-wise kernel (432 ms); the same algebra as two library GEMMs + eager elementwise passes (round 4's route) takes
-// 123 ms.  Steps of the round: 155 ms with masked LDS writes after the slab's matrix instructions; 149.7 without the masks (nothing to
-// mask: the contraction runs over zero-padded genes); 146 with the LDS writes issued between the third and the fourth quarter of the
-// slab.  What does NOT move it: the tile width (64 / 128 cells i), the slab depth (16 / 32 genes where LDS allows), the LDS pitch (17 / 18
-// doubles), issuing the loads a whole slab earlier.  Two workgroups per CU (two waves per SIMD) run the same code in step: both reach
-// their barriers and their fragment reads together.  VCY_NT_N / VCY_NT_KS / VCY_NT_PAD rebuild the variants.
+// Two forms.  k_cdc_full_linear_dma (below; the one that runs whenever the row pitch holds whole 128-byte slab rows, i.e. always with the
+// layout's 64-element padding): slabs DMA'd from global memory straight into LDS.  Measured at 10 000 cells x 20 000 genes
+// (tools/bench_full.py, profiles/r05_full_linear.txt): f64 storage 120.4 ms = 66.4 Tflop/s = 0.85 of the f64 matrix peak (0.87 at the 2.33 GHz
+// of the launch), f32 storage 118.0 ms; the same algebra as two library GEMMs + eager elementwise passes (round 4's route) 122.2 ms; the
+// element-wise kernel 427 ms.  k_cdc_full_linear (this one; the fallback for other pitches, VCY_NT_DMA=0 for A/B): slabs staged through
+// registers, 146-150 ms.  How the first became the second: 155 ms with masked LDS writes after the slab's matrix instructions; 149.7 without
+// the masks (nothing to mask: the contraction runs over zero-padded genes); 146 with the LDS writes issued inside the slab's matrix
+// instructions.  Cost probes on that form (results wrong, cost right): no loads and no LDS writes after the first slab 115.7 ms - the
+// matrix / fragment-read / barrier skeleton is worth 0.88 of the peak -, LDS writes of stale registers 133.9, i.e. the ds_write instructions
+// cost 16 % of the launch and the wait for their loads 10 %; tile width (64 / 128 cells i), LDS pitch (17 / 18 doubles), 8- or 16-byte LDS
+// accesses, issuing the loads a slab earlier: no change.  So the staged slab had to reach LDS without passing through the wave:
+// global_load_lds_dwordx4.  VCY_NT_N / VCY_NT_KS / VCY_NT_PAD rebuild variants of the register-staged form.
 #ifndef VCY_NT_N
 #define VCY_NT_N 64
 #endif
@@ -311,8 +318,9 @@ static int launch_gram(const void *A, const void *B, const double *ma, const dou
 #define VCY_NT_KS 16
 #endif
 #ifndef VCY_NT_PAD
-#define VCY_NT_PAD 1
+#define VCY_NT_PAD 2
 #endif
+static_assert(VCY_NT_PAD % 2 == 0 && VCY_NT_KS % 8 == 0, "16-byte LDS accesses");
 static_assert(2 * (2 * 128 + VCY_NT_N) * (VCY_NT_KS + VCY_NT_PAD) * 8 <= 160 * 1024, "the double-buffered slabs must fit the LDS of a CU");
 constexpr int NT_M = 128, NT_N = VCY_NT_N, NT_KS = VCY_NT_KS, NT_LD = NT_KS + VCY_NT_PAD;
 constexpr int NT_YT = NT_N / 32;       // 16 x 16 tiles per wave along i (waves 2 x 2)
@@ -335,6 +343,40 @@ template <typename T> __global__ __launch_bounds__(256) void k_cell_linear_sums(
     se = block_sum(se, red); see = block_sum(see, red);
     sb = block_sum(sb, red); sbb = block_sum(sbb, red); sed = block_sum(sed, red);
     if (threadIdx.x == 0) { double *o = sums + 5 * c; o[0] = se; o[1] = see; o[2] = sb; o[3] = sbb; o[4] = sed; }
+}
+
+// the epilogue of both forms of the kernel: D[row = (lane >> 4) + 4 reg][col = lane & 15] of every 16 x 16 tile -> Pearson's r of the pair (c, i)
+template <typename OT>
+__device__ __forceinline__ void nt_epilogue(const v4d_t (&accE)[4][NT_YT], const v4d_t (&accD)[4][NT_YT], const double *__restrict__ sums, OT *__restrict__ rm,
+                                            int C, int G, int64_t cell0, int C_out, int64_t ld_rm, int accumulate, int c0, int i0, int wi, int wj, int lrow, int lcol)
+{
+    const double n = (double)G, eps64 = 64.0 * 2.220446049250313e-16;
+#pragma unroll
+    for (int y = 0; y < NT_YT; ++y) {
+        const int i = i0 + wj + y * 16 + lcol;
+        const bool iok = i < C;
+        const double Se_i = iok ? sums[5 * (int64_t)i] : 0.0, See_i = iok ? sums[5 * (int64_t)i + 1] : 0.0;
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cl = c0 + wi + x * 16 + lrow + 4 * r;
+                if (!(iok && cl < C_out)) continue;
+                const double *sc = sums + 5 * (cell0 + cl);
+                const double Se_c = sc[0], See_c = sc[1], sb = sc[2], sbb = sc[3], sed = sc[4];
+                const double sA = Se_i - Se_c;
+                const double sAA = See_i + See_c - 2.0 * accE[x][y][r];
+                const double sAb = accD[x][y][r] - sed;
+                const double cov = sAb - sA * sb / n, va = sAA - sA * sA / n, vb = sbb - sb * sb / n;
+                double v = cov / sqrt(va * vb);
+                // i == c, duplicate cells (e_i == e_c) and a constant d_c: the reference's centred sums are exactly zero there (0 * inf = NaN);
+                // the expanded moments leave rounding noise of either sign - variances below the noise floor of the expansion (a few ulps
+                // of the terms that cancel) are zero
+                if ((int64_t)i == cell0 + cl || va <= eps64 * (See_i + See_c) || vb <= eps64 * sbb) v = __builtin_nan("");
+                OT *o = rm + (int64_t)cl * ld_rm + i;
+                *o = accumulate ? (OT)((double)*o + v) : (OT)v;
+            }
+    }
 }
 
 template <typename T, typename OT>
@@ -380,15 +422,13 @@ __global__ __launch_bounds__(GM_THREADS, NT_N == 128 ? 1 : 2) void k_cdc_full_li
 #pragma unroll
         for (int u = 0; u < UA; ++u) {
             const int r = r0 + RP * u;
-            double *pe = Es + (buf * NT_M + r) * NT_LD + 2 * cp, *pd = Ds + (buf * NT_M + r) * NT_LD + 2 * cp;
-            pe[0] = ra[u][0]; pe[1] = ra[u][1];
-            pd[0] = rd[u][0]; pd[1] = rd[u][1];
+            *reinterpret_cast<double2 *>(Es + (buf * NT_M + r) * NT_LD + 2 * cp) = double2{ra[u][0], ra[u][1]};
+            *reinterpret_cast<double2 *>(Ds + (buf * NT_M + r) * NT_LD + 2 * cp) = double2{rd[u][0], rd[u][1]};
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int r = r0 + RP * u;
-            double *pb = Bs + (buf * NT_N + r) * NT_LD + 2 * cp;
-            pb[0] = rb[u][0]; pb[1] = rb[u][1];
+            *reinterpret_cast<double2 *>(Bs + (buf * NT_N + r) * NT_LD + 2 * cp) = double2{rb[u][0], rb[u][1]};
         }
     };
     const int wm = wave >> 1, wn = wave & 1;
@@ -407,63 +447,166 @@ __global__ __launch_bounds__(GM_THREADS, NT_N == 128 ? 1 : 2) void k_cdc_full_li
     for (int g0 = 0; g0 < G; g0 += NT_KS) {
         const bool more = g0 + NT_KS < G;
         const double *es = Es + buf * NT_M * NT_LD, *ds = Ds + buf * NT_M * NT_LD, *bs = Bs + buf * NT_N * NT_LD;
+        // one 16-byte LDS read feeds TWO matrix instructions: the contraction index may be visited in any order as long as both operands agree, so
+        // lane group q = lane >> 4 takes genes 8 kk2 + 2 q and 8 kk2 + 2 q + 1 of the slab - adjacent doubles - for the steps 2 kk2 and 2 kk2 + 1
 #pragma unroll
-        for (int kk = 0; kk < NT_KS / 4; ++kk) {
-            double a[4], b2[4], b[NT_YT];
+        for (int kk2 = 0; kk2 < NT_KS / 8; ++kk2) {
+            double2 a[4], b2[4], b[NT_YT];
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-                a[x] = es[(wi + x * 16 + lcol) * NT_LD + kk * 4 + lrow];
-                b2[x] = ds[(wi + x * 16 + lcol) * NT_LD + kk * 4 + lrow];
+                a[x] = *reinterpret_cast<const double2 *>(es + (wi + x * 16 + lcol) * NT_LD + kk2 * 8 + 2 * lrow);
+                b2[x] = *reinterpret_cast<const double2 *>(ds + (wi + x * 16 + lcol) * NT_LD + kk2 * 8 + 2 * lrow);
             }
 #pragma unroll
-            for (int y = 0; y < NT_YT; ++y) b[y] = bs[(wj + y * 16 + lcol) * NT_LD + kk * 4 + lrow];
+            for (int y = 0; y < NT_YT; ++y) b[y] = *reinterpret_cast<const double2 *>(bs + (wj + y * 16 + lcol) * NT_LD + kk2 * 8 + 2 * lrow);
 #pragma unroll
             for (int x = 0; x < 4; ++x)
 #pragma unroll
                 for (int y = 0; y < NT_YT; ++y) {
-                    accE[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], accE[x][y], 0, 0, 0);
-                    accD[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(b2[x], b[y], accD[x][y], 0, 0, 0);
+                    accE[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x].x, b[y].x, accE[x][y], 0, 0, 0);
+                    accD[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(b2[x].x, b[y].x, accD[x][y], 0, 0, 0);
+                }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < NT_YT; ++y) {
+                    accE[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x].y, b[y].y, accE[x][y], 0, 0, 0);
+                    accD[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(b2[x].y, b[y].y, accD[x][y], 0, 0, 0);
                 }
             // the next slab goes into the OTHER buffer while the last matrix instructions of this one are still queued: its loads have had
-            // three quarters of the slab to arrive, and the LDS writes run beside the matrix pipe instead of after it
-            if (kk == NT_KS / 4 - 2) {
+            // a slab to arrive, and the LDS writes run beside the matrix pipe instead of after it
+            if (kk2 == 0) {
                 __builtin_amdgcn_sched_barrier(0);
+#if VCY_EXP == 1       /* probe: no global loads, no LDS writes after the first slab (results wrong): what the MFMA / LDS-read / barrier skeleton costs */
+#elif VCY_EXP == 2     /* probe: LDS writes of stale registers, no loads */
+                if (more) stash(buf ^ 1, g0 + NT_KS);
+#else
                 if (more) stash(buf ^ 1, g0 + NT_KS);
                 if (g0 + 2 * NT_KS < G) fetch(g0 + 2 * NT_KS);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#if VCY_EXP != 3
         __syncthreads();
+#endif
         buf ^= 1;
     }
-    // ---- epilogue: D[row = (lane >> 4) + 4 reg][col = lane & 15] of every 16 x 16 tile -> Pearson's r of the pair (c, i)
-    const double n = (double)G, eps64 = 64.0 * 2.220446049250313e-16;
+    nt_epilogue<OT>(accE, accD, sums, rm, C, G, cell0, C_out, ld_rm, accumulate, c0, i0, wi, wj, lrow, lcol);
+}
+
+
+// The same kernel with the slabs DMA'd straight from global memory into LDS (global_load_lds_dwordx4: 16 bytes per lane, no
+// staging registers, no ds_write instruction, nothing in the wave's instruction stream between two slabs' matrix instructions but the
+// wait).  Measured on the register-staged form: the matrix skeleton alone runs at 0.86-0.88 of the f64 matrix peak, the LDS writes of the
+// staged slab cost 16 % of the launch and the wait for their loads 10 % (profiles/r05_full_linear.txt).  An LDS-DMA instruction lays the 64
+// lanes' 16-byte pieces down back to back, so a slab row is 8 pieces of 2 genes with NO padding, and the bank spread comes from a swizzle
+// instead: piece p of row r holds genes 2 (p ^ (r & 7)), +1.  A fragment read (row = lane & 15 of a 16-row tile, piece 4 kk2 + (lane >> 4))
+// then takes eight different pieces per eight rows.  f32 storage: the same 128-byte rows hold 32 genes, a piece is four floats converted
+// after the LDS read and feeds four matrix instructions per tile.
+constexpr int NTD_ROWB = 128;                                          // bytes of a slab row: 16 genes, f64
+template <typename T>
+__global__ __launch_bounds__(GM_THREADS, 2) void k_cdc_full_linear_dma(const T *__restrict__ e, const T *__restrict__ d, const double *__restrict__ sums,
+                                                                        T *__restrict__ rm, int C, int G, int64_t ld, int64_t cell0, int C_out, int64_t ld_rm,
+                                                                        int accumulate, int ntn)
+{
+    static_assert(NT_N == 64, "the DMA form is laid out for 128 x 64 tiles");
+    constexpr int PG = 16 / (int)sizeof(T);                           // genes per 16-byte piece: 2 (f64) or 4 (f32: converted after the LDS read)
+    constexpr int KSL = 8 * PG;                                       // genes per slab: a slab row is 8 pieces = 128 bytes whatever the type
+    constexpr int BUF = (2 * NT_M + NT_N) * NTD_ROWB;                 // one buffer: E rows, D rows, B rows
+    // TWO arrays, not two halves of one: the compiler makes every LDS read wait for the LDS-DMA writes it cannot tell apart from the
+    // read's address (s_waitcnt vmcnt(0) in front of the slab's first fragment read - the overlap gone); distinct objects it can
+    __shared__ __attribute__((aligned(16))) char bufA[BUF];
+    __shared__ __attribute__((aligned(16))) char bufB[BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int total = (int)gridDim.x, per = (total + 7) / 8;
+    const int q = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    const int mt = q / ntn, nt = q - mt * ntn;
+    if (mt * NT_M >= C_out) return;
+    const int c0 = mt * NT_M, i0 = nt * NT_N;
+    // DMA roles: one instruction = 8 rows x 8 pieces; a wave issues 10 of the 40 a slab needs (4 + 4 for its 32 rows of E and of D, 2 for its
+    // 16 rows of B).  Lane l writes piece l & 7 of row l >> 3 of the group; it reads the genes the swizzle puts there.
+    const int lr = lane >> 3, lp = lane & 7;
+    const T *srcE[4], *srcD[4], *srcB[2];
 #pragma unroll
-    for (int y = 0; y < NT_YT; ++y) {
-        const int i = i0 + wj + y * 16 + lcol;
-        const bool iok = i < C;
-        const double Se_i = iok ? sums[5 * (int64_t)i] : 0.0, See_i = iok ? sums[5 * (int64_t)i + 1] : 0.0;
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int cl = c0 + wi + x * 16 + lrow + 4 * r;
-                if (!(iok && cl < C_out)) continue;
-                const double *sc = sums + 5 * (cell0 + cl);
-                const double Se_c = sc[0], See_c = sc[1], sb = sc[2], sbb = sc[3], sed = sc[4];
-                const double sA = Se_i - Se_c;
-                const double sAA = See_i + See_c - 2.0 * accE[x][y][r];
-                const double sAb = accD[x][y][r] - sed;
-                const double cov = sAb - sA * sb / n, va = sAA - sA * sA / n, vb = sbb - sb * sb / n;
-                double v = cov / sqrt(va * vb);
-                // i == c, duplicate cells (e_i == e_c) and a constant d_c: the reference's centred sums are exactly zero there (0 * inf = NaN);
-                // the expanded moments leave rounding noise of either sign - variances below the noise floor of the expansion (a few ulps
-                // of the terms that cancel) are zero
-                if ((int64_t)i == cell0 + cl || va <= eps64 * (See_i + See_c) || vb <= eps64 * sbb) v = __builtin_nan("");
-                OT *o = rm + (int64_t)cl * ld_rm + i;
-                *o = accumulate ? (OT)((double)*o + v) : (OT)v;
-            }
+    for (int u = 0; u < 4; ++u) {
+        const int r = wave * 32 + u * 8 + lr;                         // row of the tile's c block
+        const int64_t row = cell0 + min(c0 + r, C_out - 1);
+        const int piece = lp ^ (r & 7);
+        srcE[u] = e + row * ld + PG * piece;
+        srcD[u] = d + row * ld + PG * piece;
     }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int r = wave * 16 + u * 8 + lr;
+        const int64_t row = min(i0 + r, C - 1);
+        srcB[u] = e + row * ld + PG * (lp ^ (r & 7));
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    auto dma = [&](char *base, int g0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            __builtin_amdgcn_global_load_lds((glb_void *)(srcE[u] + g0), (lds_void *)(base + (wave * 32 + u * 8) * NTD_ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void *)(srcD[u] + g0), (lds_void *)(base + NT_M * NTD_ROWB + (wave * 32 + u * 8) * NTD_ROWB), 16, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            __builtin_amdgcn_global_load_lds((glb_void *)(srcB[u] + g0), (lds_void *)(base + 2 * NT_M * NTD_ROWB + (wave * 16 + u * 8) * NTD_ROWB), 16, 0, 0);
+    };
+    const int wm = wave >> 1, wn = wave & 1;
+    const int wi = wm * 64, wj = wn * (NT_N / 2);
+    v4d_t accE[4][NT_YT], accD[4][NT_YT];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < NT_YT; ++y) { accE[x][y] = v4d_t{0.0, 0.0, 0.0, 0.0}; accD[x][y] = v4d_t{0.0, 0.0, 0.0, 0.0}; }
+    const int lrow = lane >> 4, lcol = lane & 15;
+    // one slab: the next one streams into `other` while the matrix instructions read `cur`
+    auto slab = [&](const char *cur, char *other, int g0) {
+        if (g0 + KSL < G) dma(other, g0 + KSL);                       // every wave is past the barrier that ended the reads of that buffer
+        __builtin_amdgcn_sched_barrier(0);
+        const char *es = cur, *ds = es + NT_M * NTD_ROWB, *bs = es + 2 * NT_M * NTD_ROWB;
+#pragma unroll
+        for (int kk2 = 0; kk2 < 2; ++kk2) {                             // 8 pieces per row: lane group q = lane >> 4 reads piece 4 kk2 + q
+            struct alignas(16) P { T v[PG]; };
+            P a[4], b2[4], b[NT_YT];
+            const int piece = ((kk2 * 4 + lrow) ^ (lcol & 7)) * 16;  // (the tiles start at multiples of 16 rows: row & 7 = lcol & 7)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                a[x] = *reinterpret_cast<const P *>(es + (wi + x * 16 + lcol) * NTD_ROWB + piece);
+                b2[x] = *reinterpret_cast<const P *>(ds + (wi + x * 16 + lcol) * NTD_ROWB + piece);
+            }
+#pragma unroll
+            for (int y = 0; y < NT_YT; ++y) b[y] = *reinterpret_cast<const P *>(bs + (wj + y * 16 + lcol) * NTD_ROWB + piece);
+#pragma unroll
+            for (int j = 0; j < PG; ++j) {                              // one 16-byte read feeds PG matrix instructions per tile
+                double aj[4], dj[4], bj[NT_YT];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) { aj[x] = (double)a[x].v[j]; dj[x] = (double)b2[x].v[j]; }
+#pragma unroll
+                for (int y = 0; y < NT_YT; ++y) bj[y] = (double)b[y].v[j];
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < NT_YT; ++y) {
+                        accE[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(aj[x], bj[y], accE[x][y], 0, 0, 0);
+                        accD[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(dj[x], bj[y], accD[x][y], 0, 0, 0);
+                    }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of the next slab have landed in LDS
+        __syncthreads();
+    };
+    dma(bufA, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int g0 = 0; g0 < G; g0 += 2 * KSL) {
+        slab(bufA, bufB, g0);
+        if (g0 + KSL < G) slab(bufB, bufA, g0 + KSL);
+    }
+    nt_epilogue<T>(accE, accD, sums, rm, C, G, cell0, C_out, ld_rm, accumulate, c0, i0, wi, wj, lrow, lcol);
 }
 
 }  // namespace vcy
@@ -558,7 +701,19 @@ extern "C" int vcy_coldeltacor_full_linear(const void *e, const void *d, void *r
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(GM_THREADS), lds, st, (const T *)e, (const T *)d, (const double *)sums, (T *)rm, (int)C, (int)G, \
                            ld, cell0, (int)C_out, ld_rm, accumulate, (int)ntn);                                                            \
     } while (0)
-    if (dtype == VCY_F32) VCY_NT(float); else VCY_NT(double);
+#define VCY_NT_DMA_LAUNCH(T)                                                                                                               \
+    do {                                                                                                                                   \
+        hipLaunchKernelGGL(k_cell_linear_sums<T>, dim3((unsigned)C), dim3(256), 0, st, (const T *)e, (const T *)d, sums, (int)G, ld, cell0, (int)C_out); \
+        VCY_LAUNCH_CHECK();                                                                                                                \
+        hipLaunchKernelGGL(k_cdc_full_linear_dma<T>, dim3((unsigned)blocks), dim3(GM_THREADS), 0, st, (const T *)e, (const T *)d, (const double *)sums, \
+                           (T *)rm, (int)C, (int)G, ld, cell0, (int)C_out, ld_rm, accumulate, (int)ntn);                                     \
+    } while (0)
+    // the DMA form needs whole 128-byte slab rows inside the pitch (ld a multiple of 16 f64 / 32 f32 elements: the layout's 64-element padding
+    // gives both); VCY_NT_DMA=0 runs the register-staged form (A/B)
+    const bool dma_ok = env_int("VCY_NT_DMA", 1) != 0 && ld % (dtype == VCY_F32 ? 32 : 16) == 0;
+    if (dtype == VCY_F32) { if (dma_ok) VCY_NT_DMA_LAUNCH(float); else VCY_NT(float); }
+    else { if (dma_ok) VCY_NT_DMA_LAUNCH(double); else VCY_NT(double); }
+#undef VCY_NT_DMA_LAUNCH
 #undef VCY_NT
     VCY_LAUNCH_CHECK();
     return VCY_OK;
