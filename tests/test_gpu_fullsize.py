@@ -556,6 +556,15 @@ def test_fullsize_headline_arithmetic_against_the_oracle(world, oracle):
                 ref_row += ws[t] * src[t]
             got_row = Sx.t[r, :G].cpu().numpy()
             worst_pool = max(worst_pool, float(np.abs(got_row - ref_row).max() / max(1e-300, np.abs(ref_row).max())))
+            # ... and through the ORACLE's own entry point (convolve_by_sparse_weights, neighbors.py:416-423) on the compact problem of this
+            # row's 31 cells: row 0 of the weight matrix is the cell's weights, the other rows are unit rows (the oracle insists on rows summing to 1)
+            from scipy import sparse
+            nn = len(ws)
+            Wsub = sparse.lil_matrix((nn, nn))
+            Wsub.setdiag(1.0)
+            Wsub[0, :] = ws
+            ref_o = oracle.convolve_by_sparse_weights(np.ascontiguousarray(src.T), Wsub.tocsr())[:, 0]
+            worst_pool = max(worst_pool, float(np.abs(got_row - ref_o).max() / max(1e-300, np.abs(ref_o).max())))
         s, u = e_sub[:, :len(cs)], Ux.t[torch.as_tensor(cs, device=dev), :G].cpu().numpy().T
         Dv = (s + (u - g64[:, None] * s)) - s
         d_sub = np.zeros_like(e_sub)
