@@ -197,6 +197,27 @@ def test_coldeltacor_full_linear_gemm_route(ops, oracle, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("G,C", [(1, 2), (2, 3), (17, 65), (33, 129), (2049, 70), (500, 257)])
+def test_coldeltacor_full_linear_edge_shapes(ops, oracle, dtype, G, C):
+    """vcy_coldeltacor_full_linear on shapes around its tile (128 x 64 cells) and slab (16 / 32 genes) edges, against the oracle's
+    speedboosted._colDeltaCor restatement; a single gene gives zero variance everywhere (NaN in the reference as well)."""
+    rng = np.random.default_rng(G * 1000 + C)
+    e, d = rng.gamma(2.0, 1.0, (G, C)), rng.normal(size=(G, C))
+    want = oracle.coldeltacor(e, d, "linear", 0.0)
+    E, D = ops.CellMatrix.from_genes_major(e, dtype), ops.CellMatrix.from_genes_major(d, dtype)
+    got = ops.coldeltacor_full(E, D, ops.LINEAR).cpu().numpy()
+    off = ~np.eye(C, dtype=bool)
+    assert np.isnan(got[~off]).all()
+    if G < 3:                                                # one or two genes: the centred sums of the reference are zero or +-1 up to rounding
+        fin = np.isfinite(want) & np.isfinite(got) & off
+        np.testing.assert_allclose(got[fin], want[fin], atol=1e-6)
+        return
+    ok = np.isfinite(want) & off
+    assert np.isfinite(got[ok]).all()
+    np.testing.assert_allclose(got[ok], want[ok], atol=1e-9 if dtype == "float64" else 5e-5)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_coldeltacor_partial_wide_lists_are_tiled(ops, oracle, dtype):
     """nrndm > 256: the grouped kernel walks the list in column tiles (one launch each) on index-sorted rows and the
     wrapper restores the caller's column order; duplicates and unsorted rows included."""
