@@ -217,6 +217,34 @@ def test_coldeltacor_full_linear_edge_shapes(ops, oracle, dtype, G, C):
     np.testing.assert_allclose(got[ok], want[ok], atol=1e-9 if dtype == "float64" else 5e-5)
 
 
+def test_coldeltacor_full_linear_register_staged_form(ops, tmp_path):
+    """The fallback form of the linear all-pairs kernel (slabs staged through registers; taken for row pitches that do not hold whole
+    128-byte slab rows, or with VCY_NT_DMA=0 - an environment switch the library reads once, hence the subprocess) gives what the
+    LDS-DMA form gives, to the rounding of a different order of the contraction."""
+    import os
+    import subprocess
+    import sys
+    rng = np.random.default_rng(77)
+    G, C = 900, 200
+    e, d = rng.gamma(2.0, 1.0, (G, C)), rng.normal(size=(G, C))
+    np.savez(tmp_path / "in.npz", e=e, d=d)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import velocyto_amd; from velocyto_amd import ops; z = np.load(%r); "
+            "out = {}; \n"
+            "for dt in ('float64', 'float32'):\n"
+            "    E, D = ops.CellMatrix.from_genes_major(z['e'], dt), ops.CellMatrix.from_genes_major(z['d'], dt)\n"
+            "    out[dt] = ops.coldeltacor_full(E, D, ops.LINEAR).cpu().numpy()\n"
+            "np.savez(%r, **out)") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "in.npz"), str(tmp_path / "out.npz"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VCY_NT_DMA="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    staged = np.load(tmp_path / "out.npz")
+    for dt, tol in (("float64", 1e-12), ("float32", 1e-12)):          # f32 storage: the same f64 arithmetic on the same stored values
+        E, D = ops.CellMatrix.from_genes_major(e, dt), ops.CellMatrix.from_genes_major(d, dt)
+        dma = ops.coldeltacor_full(E, D, ops.LINEAR).cpu().numpy()
+        assert np.array_equal(np.isnan(dma), np.isnan(staged[dt]))
+        ok = ~np.isnan(dma)
+        np.testing.assert_allclose(staged[dt][ok].astype(np.float64), dma[ok].astype(np.float64), atol=tol if dt == "float64" else 2e-7)
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_coldeltacor_partial_wide_lists_are_tiled(ops, oracle, dtype):
     """nrndm > 256: the grouped kernel walks the list in column tiles (one launch each) on index-sorted rows and the
