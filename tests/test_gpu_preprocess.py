@@ -284,11 +284,20 @@ def test_gram_kernel_against_the_library_gemm(dtype, C, G):
     raw = ops.gram(M, None)                                                              # no centring: X^T X
     assert float((raw - Xs.T @ Xs).abs().max()) <= 1e-12 * float((Xs * Xs).sum(0).max())
     # the thin block product of the subspace iteration, with an ASYMMETRIC right-hand side (a row <-> column slip cannot hide)
+    thin = {}
     for L in (1, 7, 50, 64, 130):
         Y = torch.randn((C, L), generator=gen, device=dev, dtype=torch.float64) * torch.arange(1, L + 1, device=dev, dtype=torch.float64)
         w = ops.gram_tn(M, mean, Y)
         wref = A.T @ Y
         assert w.shape == (G, L) and float((w - wref).abs().max()) <= 1e-12 * float(wref.abs().max()) + 1e-9
+        thin[L] = (Y, w)
+    # the tile columns past the last gene are staged with the rest of the slab row (whatever lies in the row's padding): they must only
+    # ever reach output rows / columns that are not written
+    if M.ld > G:
+        M.t[:, G:] = float("nan")
+        assert torch.equal(ops.gram(M, mean), got) and torch.equal(ops.gram(M, None), raw)
+        for L, (Y, w) in thin.items():
+            assert torch.equal(ops.gram_tn(M, mean, Y), w)
 
 
 def test_gram_kernel_identity_probe():

@@ -7,8 +7,12 @@
 // and the subspace iteration for few components of many genes needs the same contraction against a thin block,
 //     out[i][j]  = sum_c (X[c][i] - mean[i]) Y[c][j]                      (G x L, Y fp64 (C, L)).
 // Both contract over CELLS, the slow dimension of both operands ("TN" product): a slab of KS cells x 128 genes is one
-// contiguous 1 KiB run per cell, staged once into LDS with the mean subtracted on the way (centring costs one VALU subtract per
-// loaded element and no extra pass), and every staged f64 feeds 8 matrix instructions.
+// contiguous 1 KiB run per cell, staged once into LDS, and every staged f64 feeds 8 matrix instructions; the centring costs one
+// VALU subtract per element and no extra pass.  Two forms: k_gram_dma (the one that runs: slabs DMA'd from global memory straight into
+// LDS, the mean subtracted at the fragment read) and k_gram (slabs staged through registers, the mean subtracted on the way into LDS;
+// VCY_GRAM_DMA=0, kept for A/B).  Measured at 50 000 cells (tools/bench_gram.py, profiles/r05_gram.txt): 10 000 genes 86.5 -> 82.0 ms
+// (f64 storage; 0.80 of the f64 matrix peak) and 96.7 -> 79.2 ms (f32 storage, 0.83: the f32 -> f64 converts no longer sit between a load
+// and an LDS write); the thin block product streams X at 3.1 TB/s instead of 2.8.
 //
 // Matrix core use.  v_mfma_f64_16x16x4_f64: D(16x16) += A(16x4) B(4x16), one f64 of A and of B per lane
 // (A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15]), four f64 of D per lane
@@ -23,6 +27,7 @@
 // over `ksplit` workgroups per tile, each writing its partial tile to a workspace; k_gram_reduce adds the partials in a fixed
 // order (deterministic - no atomics) and mirrors.
 #include "common.h"
+#include <type_traits>
 #ifndef VCY_EXP
 #define VCY_EXP 0
 #endif
@@ -44,6 +49,48 @@ template <typename T> __device__ __forceinline__ void load2(const T *p, double &
     else { const float2 v = *reinterpret_cast<const float2 *>(p); a = (double)v.x; b = (double)v.y; }
 }
 
+// ---- write of a wave's accumulators: D[row = (lane >> 4) + 4 reg][col = lane & 15] of every 16 x 16 tile
+// (split runs: `dst` is the workspace, partial s a compact Ga x Gb matrix of its own - ldo is Gb then)
+template <int XT, int YT>
+__device__ __forceinline__ void gram_write(const v4d_t (&acc)[XT][YT], double *__restrict__ dst, bool mirror, int Ga, int Gb, int64_t ldo, int ci, int cj,
+                                           int lrow, int lcol)
+{
+#pragma unroll
+    for (int x = 0; x < XT; ++x)
+#pragma unroll
+        for (int y = 0; y < YT; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ci + x * 16 + lrow + 4 * r, j = cj + y * 16 + lcol;
+                if (i < Ga && j < Gb) {
+                    dst[(int64_t)i * ldo + j] = acc[x][y][r];
+                    if (mirror) dst[(int64_t)j * ldo + i] = acc[x][y][r];
+                }
+            }
+}
+
+// the (split, tile) a workgroup owns.  XCD-aware: workgroup b runs on XCD b % 8 (observed; speed only) -> an XCD owns a contiguous range of
+// (split, tile): tiles next to each other share a row panel of A in one L2
+template <bool SYM> __device__ __forceinline__ bool gram_tile_of(int nta, int ntb, int ksplit, int &s, int &it, int &jt)
+{
+    const int ntile = SYM ? nta * (nta + 1) / 2 : nta * ntb;
+    const int total = ntile * ksplit, per = (total + 7) / 8;
+    const int q = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (q >= total) return false;
+    s = q / ntile;
+    const int p = q - s * ntile;
+    if (SYM) {
+        it = 0;
+        int rem = p;
+        while (rem >= nta - it) { rem -= nta - it; ++it; }
+        jt = it + rem;
+    } else {
+        it = p / ntb;
+        jt = p - it * ntb;
+    }
+    return true;
+}
+
 // out (Ga x Gb) = (A - ma)^T (B - mb); A (C, lda) of TA, B (C, ldb) of TB.  SYM: B is A (Gb == Ga), only tile pairs it <= jt.
 // TN: columns of the output tile (128: waves 2 x 2, each 64 x 64; 64: waves 4 x 1, each 32 x 64 - the thin blocks of the
 // subspace iteration, where a 128-wide tile would multiply mostly padding).
@@ -61,23 +108,8 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gram(const TA *__restrict__ A
     double *As = reinterpret_cast<double *>(smem);                    // [2][KS][GM_LD]
     double *Bs = As + 2 * GM_KS * GM_LD;                              // [2][KS][LDB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ntile = SYM ? nta * (nta + 1) / 2 : nta * ntb;
-    // XCD-aware: workgroup b runs on XCD b % 8 (observed; speed only) -> an XCD owns a contiguous range of (split, tile): tiles
-    // next to each other share a row panel of A in one L2
-    const int total = ntile * ksplit, per = (total + 7) / 8;
-    const int q = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
-    if (q >= total) return;
-    const int s = q / ntile, p = q - s * ntile;
-    int it, jt;
-    if (SYM) {
-        it = 0;
-        int rem = p;
-        while (rem >= nta - it) { rem -= nta - it; ++it; }
-        jt = it + rem;
-    } else {
-        it = p / ntb;
-        jt = p - it * ntb;
-    }
+    int s, it, jt;
+    if (!gram_tile_of<SYM>(nta, ntb, ksplit, s, it, jt)) return;
     const int i0 = it * GM_T, j0 = jt * TN;
     const int c_begin = s * cells_per_split, c_end = min(C, c_begin + cells_per_split);
     // staging roles.  A slab: column pair cp of the tile (genes 2 cp, 2 cp + 1), rows r0 + 4 u; B slab: pair cpb, rows r0b + RB u
@@ -159,22 +191,133 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gram(const TA *__restrict__ A
         __syncthreads();
         buf ^= 1;
     }
-    // ---- write: D[row = (lane >> 4) + 4 reg][col = lane & 15] of every 16 x 16 tile
-    // (split runs: `out` is the workspace, partial s a compact Ga x Gb matrix of its own - ldo is Gb then)
-    double *dst = out + (ksplit > 1 ? (int64_t)s * part_stride : 0);
-    const bool mirror = SYM && ksplit == 1 && it != jt;
+    gram_write<XT, YT>(acc, out + (ksplit > 1 ? (int64_t)s * part_stride : 0), SYM && ksplit == 1 && it != jt, Ga, Gb, ldo, i0 + wi, j0 + wj, lrow, lcol);
+}
+
+// The same product with the slabs DMA'd from global memory straight into LDS (global_load_lds_dwordx4), the form the linear all-pairs
+// kernel below arrived at first: no staging registers, no ds_write in the wave's instruction stream, nothing between two slabs' matrix
+// instructions but the wait.  One LDS-DMA instruction lays its 64 lanes' 16-byte pieces down back to back = 1 KiB: one slab row of 128 f64
+// genes, or two rows of 512 bytes (128 f32 genes, 64 f64 columns of a thin block) - lanes 0..31 take cell b, lanes 32..63 cell b + 8, so that
+// the four cells of one fragment read (4 kk + (lane >> 4)) always sit in four DIFFERENT instruction blocks, and the blocks are laid out with
+// a pitch of 1 KiB + 128 / 64 bytes: the four 16-lane groups of a fragment read start 32 / 16 banks apart.  What the DMA cannot do on the way
+// is arithmetic, so the RAW values land in LDS (in the storage type) and the centring moves to the fragment read: one f64 subtract (and a
+// convert for f32 storage) per fragment element, 8 per 16 matrix instructions, with the 8 means of the wave's rows and columns in registers.
+// Cells past the end of the split (the last slab of the last split) are clamped copies of its last cell; their fragment elements are
+// zeroed after the centring.  Tile columns past Ga / Gb hold whatever lies there (inside the row, or column 0 beyond the pitch): a column of
+// the operands only reaches its own row / column of the output, which is never written.
+template <typename T, int W> struct GramSlab {                       // a slab of GM_KS cells x W columns of T in LDS-DMA order
+    static constexpr int ROWB = W * (int)sizeof(T);                   // bytes of a slab row
+    static constexpr int RPI = 1024 / ROWB;                           // rows per DMA instruction: 1 or 2
+    static_assert(RPI == 1 || RPI == 2, "slab rows of 1 KiB or 512 bytes");
+    static constexpr int BLK = 1024 + (RPI == 1 ? 128 : 64);          // pitch of the instruction blocks
+    static constexpr int NBLK = GM_KS / RPI;                          // instructions per slab
+    static constexpr int BYTES = NBLK * BLK;
+    static constexpr int PIECE = 16 / (int)sizeof(T);                 // elements per lane of an instruction
+    __device__ static __forceinline__ int cell_of(int blk, int lane) { return RPI == 1 ? blk : blk + 8 * (lane >> 5); }
+    __device__ static __forceinline__ int col_of(int lane) { return (RPI == 1 ? lane : (lane & 31)) * PIECE; }
+    __device__ static __forceinline__ int at(int cell, int col) { return (RPI == 1 ? cell * BLK : (cell & 7) * BLK + (cell >> 3) * 512) + col * (int)sizeof(T); }
+};
+
+template <typename TA, typename TB, bool SYM, int TN>
+__global__ __launch_bounds__(GM_THREADS, 2) void k_gram_dma(const TA *__restrict__ A, const TB *__restrict__ B, const double *__restrict__ ma,
+                                                             const double *__restrict__ mb, double *__restrict__ out, int C, int Ga, int Gb,
+                                                             int64_t lda, int64_t ldb, int64_t ldo, int nta, int ntb, int ksplit, int cells_per_split,
+                                                             int64_t part_stride)
+{
+    static_assert(TN == 128 || TN == 64, "tile widths");
+    constexpr int XT = TN == 128 ? 4 : 2, YT = 4;
+    using SA = GramSlab<TA, GM_T>;
+    using SB = GramSlab<TB, TN>;
+    constexpr int BUF = SA::BYTES + SB::BYTES;
+    // two arrays, not two halves of one: the compiler orders every LDS read behind the LDS-DMA writes it cannot tell apart from it
+    __shared__ __attribute__((aligned(16))) char buf0[BUF];
+    __shared__ __attribute__((aligned(16))) char buf1[BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int s, it, jt;
+    if (!gram_tile_of<SYM>(nta, ntb, ksplit, s, it, jt)) return;
+    const int i0 = it * GM_T, j0 = jt * TN;
+    const int c_begin = s * cells_per_split, c_end = min(C, c_begin + cells_per_split);
+    const int wm = TN == 128 ? wave >> 1 : wave, wn = TN == 128 ? wave & 1 : 0;
+    const int wi = wm * XT * 16, wj = wn * YT * 16;
+    const int lrow = lane >> 4, lcol = lane & 15;
+    v4d_t acc[XT][YT];
 #pragma unroll
     for (int x = 0; x < XT; ++x)
 #pragma unroll
-        for (int y = 0; y < YT; ++y)
+        for (int y = 0; y < YT; ++y) acc[x][y] = v4d_t{0.0, 0.0, 0.0, 0.0};
+    if (c_begin < c_end) {
+        // the means of this lane's fragment columns (0 without centring and past the last column)
+        double mA[XT], mB[YT];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = i0 + wi + x * 16 + lrow + 4 * r, j = j0 + wj + y * 16 + lcol;
-                if (i < Ga && j < Gb) {
-                    dst[(int64_t)i * ldo + j] = acc[x][y][r];
-                    if (mirror) dst[(int64_t)j * ldo + i] = acc[x][y][r];
-                }
+        for (int x = 0; x < XT; ++x) { const int g = i0 + wi + x * 16 + lcol; mA[x] = (ma && g < Ga) ? ma[g] : 0.0; }
+#pragma unroll
+        for (int y = 0; y < YT; ++y) { const int g = j0 + wj + y * 16 + lcol; mB[y] = (mb && g < Gb) ? mb[g] : 0.0; }
+        // DMA roles: wave w issues the instruction blocks w, w + 4, ... of both operands
+        const int colA = i0 + SA::col_of(lane), colB = j0 + SB::col_of(lane);
+        const TA *pA = A + (colA < lda ? colA : 0);
+        const TB *pB = B + (colB < ldb ? colB : 0);
+        typedef __attribute__((address_space(3))) void lds_void;
+        typedef const __attribute__((address_space(1))) void glb_void;
+        auto dma = [&](char *base, int c0) {
+#pragma unroll
+            for (int u = 0; u < SA::NBLK / 4; ++u) {
+                const int blk = wave + 4 * u;
+                const int c = min(c0 + SA::cell_of(blk, lane), c_end - 1);
+                __builtin_amdgcn_global_load_lds((glb_void *)(pA + (int64_t)c * lda), (lds_void *)(base + blk * SA::BLK), 16, 0, 0);
             }
+#pragma unroll
+            for (int u = 0; u < SB::NBLK / 4; ++u) {
+                const int blk = wave + 4 * u;
+                const int c = min(c0 + SB::cell_of(blk, lane), c_end - 1);
+                __builtin_amdgcn_global_load_lds((glb_void *)(pB + (int64_t)c * ldb), (lds_void *)(base + SA::BYTES + blk * SB::BLK), 16, 0, 0);
+            }
+        };
+        // one slab: the next one streams into `other` while the matrix instructions read `cur`; valid = cells of this slab inside the split
+        auto multiply = [&](const char *cur, auto tail, int valid) {
+            const char *as = cur, *bs = cur + SA::BYTES;
+#pragma unroll
+            for (int kk = 0; kk < GM_KS / 4; ++kk) {
+                const int cell = kk * 4 + lrow;
+                double a[XT], b[YT];
+#pragma unroll
+                for (int x = 0; x < XT; ++x) a[x] = (double)*reinterpret_cast<const TA *>(as + SA::at(cell, wi + x * 16 + lcol)) - mA[x];
+#pragma unroll
+                for (int y = 0; y < YT; ++y) b[y] = (double)*reinterpret_cast<const TB *>(bs + SB::at(cell, wj + y * 16 + lcol)) - mB[y];
+                if constexpr (decltype(tail)::value) {                // the slab a split ends inside: cells past its end count as zeros
+                    const bool in = cell < valid;
+#pragma unroll
+                    for (int x = 0; x < XT; ++x) a[x] = in ? a[x] : 0.0;
+#pragma unroll
+                    for (int y = 0; y < YT; ++y) b[y] = in ? b[y] : 0.0;
+                }
+#pragma unroll
+                for (int x = 0; x < XT; ++x)
+#pragma unroll
+                    for (int y = 0; y < YT; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
+            }
+        };
+        // one whole slab: the next one streams into `other` while the matrix instructions read `cur`
+        auto slab = [&](const char *cur, char *other, int c0) {
+            if (c0 + GM_KS < c_end) dma(other, c0 + GM_KS);           // every wave is past the barrier that ended the reads of that buffer
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(cur, std::false_type{}, GM_KS);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of the next slab have landed in LDS
+            __syncthreads();
+        };
+        dma(buf0, c_begin);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int c0 = c_begin;
+        bool second = false;                                          // which buffer holds the slab at c0
+        for (; c0 + 2 * GM_KS <= c_end; c0 += 2 * GM_KS) {
+            slab(buf0, buf1, c0);
+            slab(buf1, buf0, c0 + GM_KS);
+        }
+        if (c0 + GM_KS <= c_end) { slab(buf0, buf1, c0); c0 += GM_KS; second = true; }
+        if (c0 < c_end) multiply(second ? buf1 : buf0, std::true_type{}, c_end - c0);
+    }
+    gram_write<XT, YT>(acc, out + (ksplit > 1 ? (int64_t)s * part_stride : 0), SYM && ksplit == 1 && it != jt, Ga, Gb, ldo, i0 + wi, j0 + wj, lrow, lcol);
 }
 
 // out[i][j] = sum over the splits, in split order; SYM: the lower triangle's tiles are read from their mirror images
@@ -259,13 +402,19 @@ static int launch_gram_t(const void *A, const void *B, const double *ma, const d
     const int64_t total = ntile * ksplit, blocks = (total + 7) / 8 * 8;
     if (blocks >= (1LL << 31)) return fail(VCY_ERR_INVALID, "%s: grid too large", "gram");
     if (ksplit > 1 && !ws) return fail(VCY_ERR_INVALID, "%s: workspace missing (vcy_gram_workspace_bytes)", "gram");
-    const size_t lds = (size_t)2 * GM_KS * (GM_LD + TN + 16) * sizeof(double);
-    auto kern = k_gram<TA, TB, SYM, TN>;
-    rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
-    if (rc) return rc;
     const int64_t part_stride = Ga * Gb;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(GM_THREADS), lds, st, (const TA *)A, (const TB *)B, ma, mb, ksplit > 1 ? (double *)ws : out, (int)C,
-                       (int)Ga, (int)Gb, lda, ldb, ksplit > 1 ? Gb : ldo, (int)nta, (int)ntb, ksplit, (int)cps, part_stride);
+    if (env_int("VCY_GRAM_DMA", 1) != 0) {                            // (0: the register-staged form, for A/B)
+        hipLaunchKernelGGL((k_gram_dma<TA, TB, SYM, TN>), dim3((unsigned)blocks), dim3(GM_THREADS), 0, st, (const TA *)A, (const TB *)B, ma, mb,
+                           ksplit > 1 ? (double *)ws : out, (int)C, (int)Ga, (int)Gb, lda, ldb, ksplit > 1 ? Gb : ldo, (int)nta, (int)ntb, ksplit, (int)cps,
+                           part_stride);
+    } else {
+        const size_t lds = (size_t)2 * GM_KS * (GM_LD + TN + 16) * sizeof(double);
+        auto kern = k_gram<TA, TB, SYM, TN>;
+        rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(GM_THREADS), lds, st, (const TA *)A, (const TB *)B, ma, mb, ksplit > 1 ? (double *)ws : out, (int)C,
+                           (int)Ga, (int)Gb, lda, ldb, ksplit > 1 ? Gb : ldo, (int)nta, (int)ntb, ksplit, (int)cps, part_stride);
+    }
     VCY_LAUNCH_CHECK();
     if (ksplit > 1) {
         const int64_t n = Ga * Gb;
