@@ -15,11 +15,11 @@ tot = collections.defaultdict(float); n = collections.defaultdict(int); dur = co
 for d in ("a", "b", "c"):
     for f in glob.glob(f"/tmp/pg_{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "k_gram<" in r["Kernel_Name"]:
+            if "k_gram<" in r["Kernel_Name"] or "k_gram_dma<" in r["Kernel_Name"]:
                 key = (r["Kernel_Name"].split("(")[0], r["Counter_Name"])
                 tot[key] += float(r["Counter_Value"]); n[key] += 1
                 dur[key] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-print("# rocprofv3 --pmc passes of: ONLY=gram REPS=2 python tools/bench_gram.py (per dispatch averages; k_gram only)")
+print("# rocprofv3 --pmc passes of: ONLY=gram REPS=2 python tools/bench_gram.py (per dispatch averages; k_gram_dma, or k_gram with VCY_GRAM_DMA=0)")
 for (k, c) in sorted(tot):
     print(f"{k:70s} {c:28s} per dispatch {tot[(k, c)] / n[(k, c)]:14.6g}   dispatches {n[(k, c)]:3d}   avg ms {dur[(k, c)] / n[(k, c)]:9.3f}")
 kern = sorted({k for k, _ in tot})
@@ -33,4 +33,4 @@ for k in kern:
               f"effective clock {gui / 8.0 / (ms2 * 1e6):.3f} GHz")
 PY
 cat $R/gpurun_out/${T}_gram_pmc.txt | tail -12
-tail -3 /tmp/pg_a.log /tmp/pg_b.log /tmp/pg_c.log | grep -i "error\|invalid\|fail" | head
+tail -q -n 3 /tmp/pg_a.log /tmp/pg_b.log /tmp/pg_c.log | grep -i "error\|invalid\|fail" | head
