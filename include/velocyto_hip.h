@@ -58,8 +58,8 @@ typedef enum {
 typedef void *vcy_stream;  /* hipStream_t */
 
 const char *vcy_last_error(void);
-/* 3 (round 5).  History: 1 -> 2: vcy_diffuse_step_factored gained `int prepared` before compute_dtype; vcy_gram and vcy_embedding_scaling added;
- * vcy_knn_pool_csr requires >= 4 stored elements.  2 -> 3: vcy_clock_probe and vcy_coldeltacor_full_linear added.  A binder refuses a library whose version it was not built
+/* 4 (round 6).  History: 1 -> 2: vcy_diffuse_step_factored gained `int prepared` before compute_dtype; vcy_gram and vcy_embedding_scaling added;
+ * vcy_knn_pool_csr requires >= 4 stored elements.  2 -> 3: vcy_clock_probe and vcy_coldeltacor_full_linear added.  3 -> 4: vcy_coldeltacor_full_linear_workspace_bytes takes C_out (repair flags).  A binder refuses a library whose version it was not built
  * against (velocyto_amd/_lib.py: EXPECTED_ABI). */
 int vcy_abi_version(void);
 /* Number of CUs / LDS bytes per workgroup of the current device (host query). */
@@ -140,12 +140,15 @@ int vcy_coldeltacor_full(const void *e, const void *d, void *rm, int64_t C, int6
 
 /* The LINEAR all-pairs variant, speedboosted._colDeltaCor (speedboosted.pyx:13-87; estimation.py:11-33), as the dense contraction it is:
  * sum A = Se_i - Se_c, sum A^2 = See_i + See_c - 2 (E E^T)[c][i], sum A b = (D E^T)[c][i] - sum_g e_c[g] d_c[g], the two products over the
- * genes on the f64 matrix cores (v_mfma_f64_16x16x4_f64, 128 x 64 tiles) with Pearson's r, the NaN rule of zero variances (i == c,
- * duplicate cells, a constant d_c: variances below 64 ulp of the terms that cancel) and the `rm[c][i] (+)= r` store fused into the
- * epilogue.  Same arguments as vcy_coldeltacor_full; workspace: vcy_coldeltacor_full_linear_workspace_bytes(C) bytes (five f64 sums per
- * cell).  f64 arithmetic whatever `dtype` the matrices are stored in.  ld must be a multiple of 16 and the columns G .. ld - 1 of e and d
- * zero (the cells-major layout's padding, as vcy_transpose writes it).                                                                  */
-size_t vcy_coldeltacor_full_linear_workspace_bytes(int64_t C);
+ * genes on the f64 matrix cores (v_mfma_f64_16x16x4_f64, 128 x 64 tiles) with Pearson's r and the `rm[c][i] (+)= r` store fused into the
+ * epilogue.  The expansion cancels where e_i is close to e_c (or d_c close to constant): pairs whose variance is below 2^-10 of the terms
+ * it was expanded from are flagged by the epilogue and evaluated by a second, small launch in the reference's own form - A = e_i - e_c
+ * element by element, centred, then squared (speedboosted.pyx:29-78) - so that near-duplicate cells carry the accuracy of every other pair
+ * and NaN appears exactly where the reference's 0 * inf does (i == c, exact duplicates, a constant d_c).  Same arguments as
+ * vcy_coldeltacor_full; workspace: vcy_coldeltacor_full_linear_workspace_bytes(C, C_out) bytes (five f64 sums per cell + one flag bit per
+ * pair), 8-byte aligned.  f64 arithmetic whatever `dtype` the matrices are stored in.  ld must be a multiple of 16 and the columns
+ * G .. ld - 1 of e and d zero (the cells-major layout's padding, as vcy_transpose writes it).                                             */
+size_t vcy_coldeltacor_full_linear_workspace_bytes(int64_t C, int64_t C_out);
 int vcy_coldeltacor_full_linear(const void *e, const void *d, void *rm, void *workspace, int64_t C, int64_t G, int64_t ld, int64_t cell0,
                                 int64_t C_out, int64_t ld_rm, int accumulate, int dtype, vcy_stream stream);
 

@@ -88,11 +88,11 @@ def test_coldeltacor_full_golden(ops, golden, dtype, key, transform, psc_key):
     degenerate = np.eye(C, dtype=bool)
     degenerate[3, 7] = degenerate[7, 3] = True
     np.testing.assert_allclose(rm[~degenerate], ref[~degenerate], atol=CORR_ATOL[dtype])
-    if transform in ("linear", "sqrt"):      # identical cells 3 and 7: zero variance of A -> NaN, as the reference's 0 * inf (also on the GEMM route)
+    if transform in ("linear", "sqrt"):      # identical cells 3 and 7: zero variance of A -> NaN, as the reference's 0 * inf (also on the matrix-core route)
         assert np.isnan(rm[3, 7]) and np.isnan(rm[7, 3]) and np.isnan(rm[5, 5])
     # row-block + accumulate semantics (rm[c,i] += ...)
     blk = ops.coldeltacor_full(e, d, ops.TRANSFORMS[transform], psc, cell0=8, C_out=17)
-    if transform == "linear":      # library GEMM: a row block may be tiled differently from the full product
+    if transform == "linear":      # matrix-core route: a row block is tiled differently from the full product
         np.testing.assert_allclose(blk.cpu().numpy()[~degenerate[8:25]], rm[8:25][~degenerate[8:25]], atol=1e-12 if dtype == "float64" else 1e-6)
     else:
         np.testing.assert_array_equal(blk.cpu().numpy()[~degenerate[8:25]], rm[8:25][~degenerate[8:25]])
@@ -161,13 +161,23 @@ def test_coldeltacor_partial_fused_equals_two_kernels(ops, dtype, transform):
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_coldeltacor_full_linear_gemm_route(ops, oracle, dtype):
     """The all-pairs linear variant as two contractions over the genes on the f64 matrix cores (vcy_coldeltacor_full_linear: Pearson
-    epilogue fused, no library GEMM) == the element-wise kernel == the oracle, including nearly identical cells (where the expanded sum
-    of squares cancels) and exact duplicates (zero variance -> NaN); row blocks (cell0 / C_out), ragged tiles and `rm +=` as well."""
+    epilogue fused, no library GEMM) == the element-wise kernel == the oracle (speedboosted.pyx:13-87), to the SAME tolerance on every
+    pair: nearly identical cells (where the expanded sum of squares cancels) are re-evaluated by the entry's repair launch in the
+    reference's centred difference form, exact duplicates and a constant d_c give the reference's NaN (0 * inf) and nothing else does;
+    row blocks (cell0 / C_out), ragged tiles and `rm +=` as well."""
     rng = np.random.default_rng(31)
     G, C = 700, 130
     e, d = rng.gamma(2.0, 1.0, (G, C)), rng.normal(size=(G, C))
-    e[:, 5] = e[:, 4] + 1e-4 * rng.normal(size=G)           # near-duplicate
+    near = {}
+    for k, noise in enumerate((1e-3, 1e-4, 1e-5, 1e-6, 1e-7, 1e-8, 1e-9)):     # cell 21 + 2 k is a copy of cell 20 + 2 k up to `noise`
+        e[:, 21 + 2 * k] = e[:, 20 + 2 * k] + noise * rng.normal(size=G)
+        near[(20 + 2 * k, 21 + 2 * k)] = noise
+    e[:, 5] = e[:, 4] * (1.0 + 1e-7)                        # a rescaled copy: A = 1e-7 e_c, its mean far from zero
     e[:, 9] = e[:, 8]                                        # exact duplicate
+    d[:, 60] = 0.0                                           # a constant d_c: the whole row is 0 * inf in the reference
+    d[:, 61] = 3.0 + 1e-5 * rng.normal(size=G)              # a nearly constant one (variance 1e-11 of its sum of squares): finite in the reference
+    if dtype == "float32":                                   # the stored values are the inputs: the oracle sees what the kernel sees
+        e, d = e.astype(np.float32).astype(np.float64), d.astype(np.float32).astype(np.float64)
     want = oracle.coldeltacor(e, d, "linear", 0.0)
     E, D = ops.CellMatrix.from_genes_major(e, dtype), ops.CellMatrix.from_genes_major(d, dtype)
     got = ops.coldeltacor_full(E, D, ops.LINEAR).cpu().numpy()
@@ -176,24 +186,83 @@ def test_coldeltacor_full_linear_gemm_route(ops, oracle, dtype):
         kern = ops.coldeltacor_full(E, D, ops.LINEAR).cpu().numpy()
     finally:
         ops.FULL_LINEAR_MFMA = True
-    skip = np.eye(C, dtype=bool)
-    skip[8, 9] = skip[9, 8] = True
-    skip[4, 5] = skip[5, 4] = True                           # checked separately below (cancellation in the expanded sum of squares)
-    assert np.isnan(got[np.eye(C, dtype=bool)]).all()
-    tol = 1e-9 if dtype == "float64" else 5e-5
-    np.testing.assert_allclose(got[~skip], want[~skip], atol=tol)
-    np.testing.assert_allclose(kern[~skip], want[~skip], atol=tol * (1 if dtype == "float64" else 4))
-    # the near-duplicate pair is where an f32 expansion would fail: the f64 contraction keeps it
-    assert abs(got[4, 5] - want[4, 5]) < (1e-6 if dtype == "float64" else 5e-3) and abs(got[5, 4] - want[5, 4]) < (1e-6 if dtype == "float64" else 5e-3)
-    assert np.isnan(got[8, 9]) and np.isnan(got[9, 8])
+    # the NaN pattern is the reference's: the diagonal, the duplicate pair, the row of the constant d_c - nothing else
+    nan_want = np.isnan(want)
+    expect = np.eye(C, dtype=bool)
+    expect[8, 9] = expect[9, 8] = True
+    expect[60, :] = True
+    for (a, b) in near:                                      # (f32 storage may round the smallest noises away: then the pair IS a duplicate)
+        if np.array_equal(e[:, a], e[:, b]):
+            expect[a, b] = expect[b, a] = True
+    assert np.array_equal(nan_want, expect)
+    assert np.array_equal(np.isnan(got), nan_want)
+    ok = ~nan_want
+    # (f32 STORAGE: same f64 arithmetic on the same stored values; the result is rounded to f32 when it is stored)
+    tol = 1e-10 if dtype == "float64" else 1.2e-7
+    np.testing.assert_allclose(got[ok], want[ok], atol=tol, rtol=0)
+    for (a, b), noise in near.items():
+        if expect[a, b]:
+            continue
+        assert abs(got[a, b] - want[a, b]) < tol and abs(got[b, a] - want[b, a]) < tol, (a, b, noise, got[a, b], want[a, b])
+    assert abs(got[4, 5] - want[4, 5]) < tol and abs(got[5, 4] - want[5, 4]) < tol
+    np.testing.assert_allclose(got[61][ok[61]], want[61][ok[61]], atol=tol, rtol=0)
+    # the element-wise kernel (raw f64 moments of A and of d_c): the same pairs, except that it carries the nearly constant d_c of
+    # row 61 - variance 1e-11 of its sum of squares, nothing a velocity vector looks like - to 1e-5 only
+    okk = ok & ~np.isnan(kern)
+    okk[61, :] = False
+    np.testing.assert_allclose(kern[okk], want[okk], atol=1e-9 if dtype == "float64" else 2e-4)
+    np.testing.assert_allclose(kern[61][ok[61]], want[61][ok[61]], atol=1e-4 if dtype == "float64" else 5e-2)
     # a row block in the middle (tile edges inside the matrix) and the reference's accumulate-into semantics
     blk = ops.coldeltacor_full(E, D, ops.LINEAR, cell0=37, C_out=70).cpu().numpy()
-    ok = ~np.isnan(got[37:107])
-    assert np.array_equal(np.isnan(blk), ~ok) and np.array_equal(blk[ok], got[37:107][ok])
+    okb = ok[37:107]
+    assert np.array_equal(np.isnan(blk), ~okb) and np.array_equal(blk[okb], got[37:107][okb])
     rm = torch.full((C, C), 2.0, dtype=E.dtype, device=E.t.device)
     acc = ops.coldeltacor_full(E, D, ops.LINEAR, rm=rm, accumulate=True).cpu().numpy()
-    okf = ~np.isnan(got)
-    np.testing.assert_allclose(acc[okf], got[okf] + 2.0, atol=1e-6 if dtype == "float32" else 1e-14)
+    assert np.array_equal(np.isnan(acc), nan_want)
+    np.testing.assert_allclose(acc[ok], got[ok] + 2.0, atol=1e-6 if dtype == "float32" else 1e-14)
+
+
+def test_coldeltacor_full_linear_pooled_neighbours(ops, oracle):
+    """The population the repair pass exists for: kNN-pooled cells (every cell the mean of itself and its neighbours, so neighbours
+    share most of their pool) - all pairs to 1e-10 in f64 against the oracle, NaN pattern equal."""
+    rng = np.random.default_rng(5)
+    G, C, k = 1500, 200, 30
+    raw = rng.poisson(rng.gamma(0.5, 2.0, (G, 1)) * rng.gamma(5.0, 0.2, (1, C))).astype(np.float64)
+    pos = rng.normal(size=(C, 3))
+    nn = np.argsort(((pos[:, None, :] - pos[None, :, :]) ** 2).sum(-1), axis=1)[:, :k + 1]
+    e = np.stack([raw[:, nn[c]].mean(1) for c in range(C)], axis=1)
+    d = rng.normal(size=(G, C)) * 0.1
+    want = oracle.coldeltacor(e, d, "linear", 0.0)
+    got = ops.coldeltacor_full(ops.CellMatrix.from_genes_major(e, "float64"), ops.CellMatrix.from_genes_major(d, "float64"), ops.LINEAR).cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    np.testing.assert_allclose(got[ok], want[ok], atol=1e-10, rtol=0)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_coldeltacor_full_linear_padding_and_pitch(ops, oracle, dtype):
+    """The matrix-core route contracts over whole 16-gene slabs up to the row pitch: a non-zero (or NaN) padding column is refused
+    by ops.coldeltacor_full(validate=True) instead of giving silently wrong correlations, and a pitch that does not hold whole
+    slabs goes to the element-wise kernel."""
+    rng = np.random.default_rng(3)
+    G, C = 100, 40
+    e, d = rng.gamma(2.0, 1.0, (G, C)), rng.normal(size=(G, C))
+    want = oracle.coldeltacor(e, d, "linear", 0.0)
+    off = ~np.eye(C, dtype=bool)
+    tdt = getattr(torch, dtype)
+    for poison in (7.0, float("nan")):
+        E, D = ops.CellMatrix.from_genes_major(e, dtype), ops.CellMatrix.from_genes_major(d, dtype)
+        assert E.ld > G
+        E.t[3, G + 1] = poison
+        with pytest.raises(ValueError, match="padding"):
+            ops.coldeltacor_full(E, D, ops.LINEAR)
+    # pitch 108: not a multiple of 16 -> element-wise kernel, which reads genes 0 .. G - 1 only (the padding may hold anything)
+    t_e = torch.full((C, 108), 5.0, dtype=tdt, device="cuda")
+    t_d = torch.full((C, 108), float("nan"), dtype=tdt, device="cuda")
+    t_e[:, :G] = torch.from_numpy(e.T.copy()).to(tdt)
+    t_d[:, :G] = torch.from_numpy(d.T.copy()).to(tdt)
+    got = ops.coldeltacor_full(ops.CellMatrix(t_e, G), ops.CellMatrix(t_d, G), ops.LINEAR).cpu().numpy()
+    np.testing.assert_allclose(got[off], want[off], atol=1e-9 if dtype == "float64" else 5e-5)
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
@@ -214,7 +283,7 @@ def test_coldeltacor_full_linear_edge_shapes(ops, oracle, dtype, G, C):
         return
     ok = np.isfinite(want) & off
     assert np.isfinite(got[ok]).all()
-    np.testing.assert_allclose(got[ok], want[ok], atol=1e-9 if dtype == "float64" else 5e-5)
+    np.testing.assert_allclose(got[ok], want[ok], atol=1e-10 if dtype == "float64" else 5e-5)
 
 
 def test_coldeltacor_full_linear_register_staged_form(ops, tmp_path):

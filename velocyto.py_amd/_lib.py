@@ -21,7 +21,7 @@ ARCH = "gfx950"
 _lib = None
 
 c_i64, c_int, c_dbl, c_vp, c_sz = ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t
-EXPECTED_ABI = 3                  # vcy_abi_version() of the header this table mirrors
+EXPECTED_ABI = 4                  # vcy_abi_version() of the header this table mirrors
 
 # name -> (restype, argtypes); mirrors include/velocyto_hip.h one to one
 SIGNATURES = {
@@ -40,7 +40,7 @@ SIGNATURES = {
                                                    c_i64, c_i64, c_int, c_int, c_dbl, c_dbl, c_dbl, c_int, c_vp]),
     "vcy_coldeltacor_full": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_dbl,
                                      c_int, c_int, c_vp]),
-    "vcy_coldeltacor_full_linear_workspace_bytes": (c_sz, [c_i64]),
+    "vcy_coldeltacor_full_linear_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "vcy_coldeltacor_full_linear": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp]),
     "vcy_scatter_rows": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]),
     "vcy_knn_pool": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_vp]),

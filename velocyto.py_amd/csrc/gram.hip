@@ -494,12 +494,22 @@ template <typename T> __global__ __launch_bounds__(256) void k_cell_linear_sums(
     if (threadIdx.x == 0) { double *o = sums + 5 * c; o[0] = se; o[1] = see; o[2] = sb; o[3] = sbb; o[4] = sed; }
 }
 
-// the epilogue of both forms of the kernel: D[row = (lane >> 4) + 4 reg][col = lane & 15] of every 16 x 16 tile -> Pearson's r of the pair (c, i)
+// the epilogue of both forms of the kernel: D[row = (lane >> 4) + 4 reg][col = lane & 15] of every 16 x 16 tile -> Pearson's r of the pair (c, i).
+// The expansion of sum A^2 (and of sum A b) loses what the terms that cancel carry in their last bits: the absolute error of va is a few
+// ulps x sqrt(G) of See_i + See_c, so the RELATIVE error of r grows like (See_i + See_c) / va - nearly identical cells, the population a kNN
+// graph is made of.  The reference centres A = e_i - e_c before it squares (speedboosted.pyx:29-78) and has no such loss.  Pairs whose
+// variance is below NT_TAU of the terms it was expanded from are therefore NOT written here: their bit is set in `flags` (one uint16 per row
+// and 16 columns = one ballot quarter, written whole by the lane of column 0: no atomics, no clearing pass) and k_cdc_linear_repair
+// re-evaluates exactly those pairs in the reference's own centred two-pass form.  NaN is then only ever the reference's 0 * inf:
+// i == c here, exact duplicates and a constant d_c in the repair pass.
+constexpr double NT_TAU = 1.0 / 1024.0;    // error of r from the expansion <= ~1e-13 (See_i + See_c) / va: below 1e-10 above this ratio
+
 template <typename OT>
 __device__ __forceinline__ void nt_epilogue(const v4d_t (&accE)[4][NT_YT], const v4d_t (&accD)[4][NT_YT], const double *__restrict__ sums, OT *__restrict__ rm,
-                                            int C, int G, int64_t cell0, int C_out, int64_t ld_rm, int accumulate, int c0, int i0, int wi, int wj, int lrow, int lcol)
+                                            unsigned short *__restrict__ flags, int64_t flag_pitch, int C, int G, int64_t cell0, int C_out, int64_t ld_rm,
+                                            int accumulate, int c0, int i0, int wi, int wj, int lrow, int lcol)
 {
-    const double n = (double)G, eps64 = 64.0 * 2.220446049250313e-16;
+    const double n = (double)G;
 #pragma unroll
     for (int y = 0; y < NT_YT; ++y) {
         const int i = i0 + wj + y * 16 + lcol;
@@ -510,28 +520,83 @@ __device__ __forceinline__ void nt_epilogue(const v4d_t (&accE)[4][NT_YT], const
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int cl = c0 + wi + x * 16 + lrow + 4 * r;
-                if (!(iok && cl < C_out)) continue;
-                const double *sc = sums + 5 * (cell0 + cl);
-                const double Se_c = sc[0], See_c = sc[1], sb = sc[2], sbb = sc[3], sed = sc[4];
-                const double sA = Se_i - Se_c;
-                const double sAA = See_i + See_c - 2.0 * accE[x][y][r];
-                const double sAb = accD[x][y][r] - sed;
-                const double cov = sAb - sA * sb / n, va = sAA - sA * sA / n, vb = sbb - sb * sb / n;
-                double v = cov / sqrt(va * vb);
-                // i == c, duplicate cells (e_i == e_c) and a constant d_c: the reference's centred sums are exactly zero there (0 * inf = NaN);
-                // the expanded moments leave rounding noise of either sign - variances below the noise floor of the expansion (a few ulps
-                // of the terms that cancel) are zero
-                if ((int64_t)i == cell0 + cl || va <= eps64 * (See_i + See_c) || vb <= eps64 * sbb) v = __builtin_nan("");
-                OT *o = rm + (int64_t)cl * ld_rm + i;
-                *o = accumulate ? (OT)((double)*o + v) : (OT)v;
+                const bool ok = iok && cl < C_out;
+                bool redo = false;
+                if (ok) {
+                    const double *sc = sums + 5 * (cell0 + cl);
+                    const double Se_c = sc[0], See_c = sc[1], sb = sc[2], sbb = sc[3], sed = sc[4];
+                    const double sA = Se_i - Se_c;
+                    const double sAA = See_i + See_c - 2.0 * accE[x][y][r];
+                    const double sAb = accD[x][y][r] - sed;
+                    const double cov = sAb - sA * sb / n, va = sAA - sA * sA / n, vb = sbb - sb * sb / n;
+                    const bool self = (int64_t)i == cell0 + cl;
+                    // (!(a >= b): a NaN or infinite moment goes to the repair pass as well, which reproduces the reference's arithmetic on it)
+                    redo = !self && (!(va >= NT_TAU * (See_i + See_c)) || !(vb >= NT_TAU * sbb));
+                    if (!redo) {
+                        const double v = self ? __builtin_nan("") : cov / sqrt(va * vb);
+                        OT *o = rm + (int64_t)cl * ld_rm + i;
+                        *o = accumulate ? (OT)((double)*o + v) : (OT)v;
+                    }
+                }
+                const unsigned long long m = __ballot(redo);                 // bits 16 q .. 16 q + 15: row lrow = q of this quad of rows, columns lcol
+                if (lcol == 0 && cl < C_out)
+                    flags[(int64_t)cl * flag_pitch + ((i0 + wj + y * 16) >> 4)] = (unsigned short)(m >> (16 * lrow));
             }
+    }
+}
+
+// The repair pass of the linear all-pairs variant: every flagged pair again, as the reference evaluates it (speedboosted.pyx:29-78) - A = e_i - e_c
+// formed element by element, centred on its mean, then squared; b = d_c likewise - one wave per pair, f64, two passes over the three rows.
+// A workgroup owns one cell c: its waves walk the row's flag words (16 columns each) and take the set bits in turn.  A launch without
+// flagged pairs reads C_out x C / 8 bytes of flags and ends.
+template <typename T>
+__global__ __launch_bounds__(256) void k_cdc_linear_repair(const T *__restrict__ e, const T *__restrict__ d, const unsigned short *__restrict__ flags,
+                                                           int64_t flag_pitch, T *__restrict__ rm, int C, int G, int64_t ld, int64_t cell0, int64_t ld_rm,
+                                                           int accumulate)
+{
+    const int cl = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const unsigned short *fr = flags + (int64_t)cl * flag_pitch;
+    const int nwords = (C + 15) >> 4;
+    const T *ec = e + (cell0 + cl) * ld, *dc = d + (cell0 + cl) * ld;
+    const double n = (double)G;
+    int taken = 0;                                                     // flagged pairs of this row met so far (the same count in every wave)
+    for (int w0 = 0; w0 < nwords; w0 += 64) {
+        const unsigned mine = (w0 + lane < nwords) ? (unsigned)fr[w0 + lane] : 0u;
+        unsigned long long any = __ballot(mine != 0);
+        while (any) {
+            const int wl = __builtin_ctzll(any);
+            any &= any - 1;
+            unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)mine, wl);
+            while (bits) {
+                const int b = __builtin_ctz(bits);
+                bits &= bits - 1;
+                if ((taken++ % nw) != wave) continue;
+                const int i = ((w0 + wl) << 4) + b;
+                const T *ei = e + (int64_t)i * ld;
+                double sA = 0.0, sb = 0.0;
+                for (int g = lane; g < G; g += 64) { sA += (double)ei[g] - (double)ec[g]; sb += (double)dc[g]; }
+                const double muA = wave_sum(sA) / n, mub = wave_sum(sb) / n;
+                double ssA = 0.0, ssb = 0.0, sab = 0.0;
+                for (int g = lane; g < G; g += 64) {
+                    const double a = ((double)ei[g] - (double)ec[g]) - muA, bb = (double)dc[g] - mub;
+                    ssA = fma(a, a, ssA); ssb = fma(bb, bb, ssb); sab = fma(a, bb, sab);
+                }
+                ssA = wave_sum(ssA); ssb = wave_sum(ssb); sab = wave_sum(sab);
+                // sum_j (A_mA[j] / sqrt(ssA)) (b_mb[j] / sqrt(ssb)): zero variance gives 0 * inf = NaN, as the reference's products do
+                const double v = (sab * (1.0 / sqrt(ssA))) * (1.0 / sqrt(ssb));
+                if (lane == 0) {
+                    T *o = rm + (int64_t)cl * ld_rm + i;
+                    *o = accumulate ? (T)((double)*o + v) : (T)v;
+                }
+            }
+        }
     }
 }
 
 template <typename T, typename OT>
 __global__ __launch_bounds__(GM_THREADS, NT_N == 128 ? 1 : 2) void k_cdc_full_linear(const T *__restrict__ e, const T *__restrict__ d, const double *__restrict__ sums,
-                                                                    OT *__restrict__ rm, int C, int G, int64_t ld, int64_t cell0, int C_out, int64_t ld_rm,
-                                                                    int accumulate, int ntn)
+                                                                    OT *__restrict__ rm, unsigned short *__restrict__ flags, int64_t flag_pitch, int C, int G, int64_t ld,
+                                                                    int64_t cell0, int C_out, int64_t ld_rm, int accumulate, int ntn)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *Es = reinterpret_cast<double *>(smem);                    // [2][NT_M][NT_LD]   e of the tile's cells c
@@ -626,22 +691,15 @@ __global__ __launch_bounds__(GM_THREADS, NT_N == 128 ? 1 : 2) void k_cdc_full_li
             // a slab to arrive, and the LDS writes run beside the matrix pipe instead of after it
             if (kk2 == 0) {
                 __builtin_amdgcn_sched_barrier(0);
-#if VCY_EXP == 1       /* probe: no global loads, no LDS writes after the first slab (results wrong): what the MFMA / LDS-read / barrier skeleton costs */
-#elif VCY_EXP == 2     /* probe: LDS writes of stale registers, no loads */
-                if (more) stash(buf ^ 1, g0 + NT_KS);
-#else
                 if (more) stash(buf ^ 1, g0 + NT_KS);
                 if (g0 + 2 * NT_KS < G) fetch(g0 + 2 * NT_KS);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-#if VCY_EXP != 3
         __syncthreads();
-#endif
         buf ^= 1;
     }
-    nt_epilogue<OT>(accE, accD, sums, rm, C, G, cell0, C_out, ld_rm, accumulate, c0, i0, wi, wj, lrow, lcol);
+    nt_epilogue<OT>(accE, accD, sums, rm, flags, flag_pitch, C, G, cell0, C_out, ld_rm, accumulate, c0, i0, wi, wj, lrow, lcol);
 }
 
 
@@ -656,8 +714,8 @@ __global__ __launch_bounds__(GM_THREADS, NT_N == 128 ? 1 : 2) void k_cdc_full_li
 constexpr int NTD_ROWB = 128;                                          // bytes of a slab row: 16 genes, f64
 template <typename T>
 __global__ __launch_bounds__(GM_THREADS, 2) void k_cdc_full_linear_dma(const T *__restrict__ e, const T *__restrict__ d, const double *__restrict__ sums,
-                                                                        T *__restrict__ rm, int C, int G, int64_t ld, int64_t cell0, int C_out, int64_t ld_rm,
-                                                                        int accumulate, int ntn)
+                                                                        T *__restrict__ rm, unsigned short *__restrict__ flags, int64_t flag_pitch, int C, int G, int64_t ld,
+                                                                        int64_t cell0, int C_out, int64_t ld_rm, int accumulate, int ntn)
 {
     static_assert(NT_N == 64, "the DMA form is laid out for 128 x 64 tiles");
     constexpr int PG = 16 / (int)sizeof(T);                           // genes per 16-byte piece: 2 (f64) or 4 (f32: converted after the LDS read)
@@ -755,7 +813,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_cdc_full_linear_dma(const T *
         slab(bufA, bufB, g0);
         if (g0 + KSL < G) slab(bufB, bufA, g0 + KSL);
     }
-    nt_epilogue<T>(accE, accD, sums, rm, C, G, cell0, C_out, ld_rm, accumulate, c0, i0, wi, wj, lrow, lcol);
+    nt_epilogue<T>(accE, accD, sums, rm, flags, flag_pitch, C, G, cell0, C_out, ld_rm, accumulate, c0, i0, wi, wj, lrow, lcol);
 }
 
 }  // namespace vcy
@@ -822,7 +880,15 @@ extern "C" int vcy_gram_tn(const void *X, const double *mean, const double *Y, d
     return launch_gram<double, double, false>(X, Y, mean, nullptr, out, workspace, C, G, L, ld, ldy, ldo, st);
 }
 
-extern "C" size_t vcy_coldeltacor_full_linear_workspace_bytes(int64_t C) { return C > 0 ? (size_t)C * 5 * sizeof(double) : 0; }
+// workspace of the linear all-pairs variant: five f64 sums per cell, then the repair flags - one uint16 per output row and 16 columns
+static inline int64_t nt_flag_pitch(int64_t C) { return (C + NT_N - 1) / NT_N * (NT_N / 16); }
+static inline size_t nt_sums_bytes(int64_t C) { return ((size_t)C * 5 * sizeof(double) + 255) / 256 * 256; }
+
+extern "C" size_t vcy_coldeltacor_full_linear_workspace_bytes(int64_t C, int64_t C_out)
+{
+    if (C <= 0 || C_out <= 0) return 0;
+    return nt_sums_bytes(C) + (size_t)C_out * (size_t)nt_flag_pitch(C) * sizeof(unsigned short);
+}
 
 extern "C" int vcy_coldeltacor_full_linear(const void *e, const void *d, void *rm, void *workspace, int64_t C, int64_t G, int64_t ld, int64_t cell0,
                                            int64_t C_out, int64_t ld_rm, int accumulate, int dtype, vcy_stream stream)
@@ -833,8 +899,11 @@ extern "C" int vcy_coldeltacor_full_linear(const void *e, const void *d, void *r
     VCY_REQUIRE(dtype == VCY_F32 || dtype == VCY_F64, "coldeltacor_full_linear: bad dtype");
     VCY_REQUIRE(ld % NT_KS == 0 && ((uintptr_t)e % 16) == 0 && ((uintptr_t)d % 16) == 0,
                 "coldeltacor_full_linear: the row pitch must be a multiple of 16 elements (zero beyond G) and the matrices 16-byte aligned");
+    VCY_REQUIRE((uintptr_t)workspace % 8 == 0, "coldeltacor_full_linear: the workspace must be 8-byte aligned");
     hipStream_t st = as_stream(stream);
     double *sums = (double *)workspace;
+    unsigned short *flags = (unsigned short *)((char *)workspace + nt_sums_bytes(C));
+    const int64_t fp = nt_flag_pitch(C);
     const int64_t ntm = (C_out + NT_M - 1) / NT_M, ntn = (C + NT_N - 1) / NT_N;
     const int64_t blocks = (ntm * ntn + 7) / 8 * 8;
     VCY_REQUIRE(blocks < (1LL << 31), "coldeltacor_full_linear: grid too large");
@@ -847,21 +916,28 @@ extern "C" int vcy_coldeltacor_full_linear(const void *e, const void *d, void *r
         auto kern = k_cdc_full_linear<T, T>;                                                                                               \
         rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);                                                                \
         if (rc) return rc;                                                                                                                 \
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(GM_THREADS), lds, st, (const T *)e, (const T *)d, (const double *)sums, (T *)rm, (int)C, (int)G, \
-                           ld, cell0, (int)C_out, ld_rm, accumulate, (int)ntn);                                                            \
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(GM_THREADS), lds, st, (const T *)e, (const T *)d, (const double *)sums, (T *)rm, flags, fp, \
+                           (int)C, (int)G, ld, cell0, (int)C_out, ld_rm, accumulate, (int)ntn);                                            \
     } while (0)
 #define VCY_NT_DMA_LAUNCH(T)                                                                                                               \
     do {                                                                                                                                   \
         hipLaunchKernelGGL(k_cell_linear_sums<T>, dim3((unsigned)C), dim3(256), 0, st, (const T *)e, (const T *)d, sums, (int)G, ld, cell0, (int)C_out); \
         VCY_LAUNCH_CHECK();                                                                                                                \
         hipLaunchKernelGGL(k_cdc_full_linear_dma<T>, dim3((unsigned)blocks), dim3(GM_THREADS), 0, st, (const T *)e, (const T *)d, (const double *)sums, \
-                           (T *)rm, (int)C, (int)G, ld, cell0, (int)C_out, ld_rm, accumulate, (int)ntn);                                     \
+                           (T *)rm, flags, fp, (int)C, (int)G, ld, cell0, (int)C_out, ld_rm, accumulate, (int)ntn);                        \
     } while (0)
+#define VCY_NT_REPAIR(T)                                                                                                                   \
+    hipLaunchKernelGGL(k_cdc_linear_repair<T>, dim3((unsigned)C_out), dim3(256), 0, st, (const T *)e, (const T *)d, (const unsigned short *)flags, fp, \
+                       (T *)rm, (int)C, (int)G, ld, cell0, ld_rm, accumulate)
     // the DMA form needs whole 128-byte slab rows inside the pitch (ld a multiple of 16 f64 / 32 f32 elements: the layout's 64-element padding
     // gives both); VCY_NT_DMA=0 runs the register-staged form (A/B)
     const bool dma_ok = env_int("VCY_NT_DMA", 1) != 0 && ld % (dtype == VCY_F32 ? 32 : 16) == 0;
     if (dtype == VCY_F32) { if (dma_ok) VCY_NT_DMA_LAUNCH(float); else VCY_NT(float); }
     else { if (dma_ok) VCY_NT_DMA_LAUNCH(double); else VCY_NT(double); }
+    VCY_LAUNCH_CHECK();
+    // the pairs the expansion cannot carry (nearly identical cells, duplicates, a nearly constant d_c), in the reference's centred form
+    if (dtype == VCY_F32) VCY_NT_REPAIR(float); else VCY_NT_REPAIR(double);
+#undef VCY_NT_REPAIR
 #undef VCY_NT_DMA_LAUNCH
 #undef VCY_NT
     VCY_LAUNCH_CHECK();

@@ -114,7 +114,7 @@ using namespace vcy;
 extern "C" const char *vcy_last_error(void) { return g_err; }
 // 2: vcy_diffuse_step_factored gained `prepared` (round 3); vcy_gram added and vcy_knn_pool_csr's 4-element minimum stated (round 4)
 // 3: vcy_clock_probe added (round 5)
-extern "C" int vcy_abi_version(void) { return 3; }
+extern "C" int vcy_abi_version(void) { return 4; }
 
 extern "C" int vcy_clock_probe(int64_t *samples, int64_t nblocks, int64_t nsamples, int64_t interval_ticks, vcy_stream stream)
 {

@@ -614,8 +614,10 @@ def coldeltacor_partial_fused_dual(Sx: CellMatrix, Ux: CellMatrix, gamma: torch.
 
 
 def coldeltacor_full(e: CellMatrix, d: CellMatrix, transform: int, psc: float = 0.0, cell0: int = 0,
-                     C_out: Optional[int] = None, rm: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
-    """Dense correlation rows rm[c, i] for c in [cell0, cell0+C_out), all i."""
+                     C_out: Optional[int] = None, rm: Optional[torch.Tensor] = None, accumulate: bool = False, validate: bool = True) -> torch.Tensor:
+    """Dense correlation rows rm[c, i] for c in [cell0, cell0+C_out), all i (speedboosted._colDeltaCor / Sqrt / Log10,
+    speedboosted.pyx:13-257).  `validate` (linear variant on the matrix cores only): check that the padding columns G .. ld - 1 of
+    e and d are zero, which that kernel's contraction over whole 16-gene slabs relies on (one small device reduction + a sync)."""
     assert e.t.shape == d.t.shape and e.dtype == d.dtype
     C_out = e.C - cell0 if C_out is None else C_out
     if rm is None:
@@ -623,9 +625,14 @@ def coldeltacor_full(e: CellMatrix, d: CellMatrix, transform: int, psc: float = 
         accumulate = False
     assert rm.is_contiguous() and rm.shape == (C_out, e.C) and rm.dtype == e.dtype
     L = _lib.lib()
-    if transform == LINEAR and FULL_LINEAR_MFMA:
-        # the one dense block contraction of the path (E E^T and D E^T over the genes): f64 matrix cores, Pearson epilogue fused
-        ws = torch.empty(int(L.vcy_coldeltacor_full_linear_workspace_bytes(e.C)), dtype=torch.uint8, device=e.t.device)
+    # the matrix-core kernel walks whole 16-gene slabs: a row pitch that does not hold them goes to the element-wise kernel
+    if transform == LINEAR and FULL_LINEAR_MFMA and e.ld % 16 == 0 and e.t.data_ptr() % 16 == 0 and d.t.data_ptr() % 16 == 0:
+        if validate and e.ld > e.G and bool(((e.t[:, e.G:] != 0) | (d.t[:, e.G:] != 0)).any()):     # (NaN != 0 as well)
+            raise ValueError("coldeltacor_full: the padding columns G .. ld - 1 of e and d must be zero (CellMatrix.empty(zero_pad=True), "
+                             "from_genes_major and every kernel of this library write them so)")
+        # the one dense block contraction of the path (E E^T and D E^T over the genes): f64 matrix cores, Pearson epilogue fused,
+        # nearly identical cells re-evaluated in the reference's centred form by the entry's own repair launch
+        ws = torch.empty(int(L.vcy_coldeltacor_full_linear_workspace_bytes(e.C, C_out)), dtype=torch.uint8, device=e.t.device)
         _lib.check(L.vcy_coldeltacor_full_linear(e.t.data_ptr(), d.t.data_ptr(), rm.data_ptr(), ws.data_ptr(), e.C, e.G, e.ld, cell0, C_out,
                                                  rm.shape[1], int(accumulate), e.code, _stream()), "coldeltacor_full_linear")
         return rm
