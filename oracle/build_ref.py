@@ -34,8 +34,15 @@ def build(force: bool = False) -> str:
     os.makedirs(OUT, exist_ok=True)
     ext = sysconfig.get_config_var("EXT_SUFFIX")
     so = os.path.join(OUT, "speedboosted" + ext)
-    if os.path.exists(so) and not force:
+    def mark():
+        # the opt-in the tests and smoke() read (oracle.reference_module_expected): this tree was given the reference kernels, for this ABI
+        import json
+        with open(os.path.join(OUT, "built.json"), "w") as f:
+            json.dump({"ext_suffix": ext, "module": os.path.basename(so)}, f)
         return so
+
+    if os.path.exists(so) and not force:
+        return mark()
     if not os.path.exists(REF_PYX):
         raise FileNotFoundError(f"{REF_PYX} not present: the reference only exists in the build container")
     c_file = os.path.join(OUT, "speedboosted.c")
@@ -46,7 +53,7 @@ def build(force: bool = False) -> str:
            f"-I{inc}", f"-I{np.get_include()}", c_file, "-o", so]
     subprocess.check_call(cmd)
     os.remove(c_file)  # generated from reference source: keep only the binary
-    return so
+    return mark()
 
 
 if __name__ == "__main__":

@@ -118,7 +118,7 @@ def test_facade_normalize_impute(vcy, golden, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
-def test_facade_fit_gammas(vcy, golden, oracle, dtype):
+def test_facade_fit_gammas(vcy, golden, oracle, fit_parity, dtype):
     g = golden("pipeline")
     gt = TOL[dtype]["gam"]
     vlm = make_vlm(vcy, g, dtype)
@@ -150,6 +150,10 @@ def test_facade_fit_gammas(vcy, golden, oracle, dtype):
         assert np.all(ours <= ref * (1 + 1e-4) + 1e-7), np.max(ours - ref)
         if wname == "maxmin_diag":
             loose(vlm.gammas, g["gammas"])
+            # the same bar with q included and the objective of every gene - the outlier above all - in one place (conftest.fit_parity):
+            # one gene of the 90 (a boundary gene: the exact q is 0, L-BFGS-B stopped at 0.149 with a worse objective) = 1.1 %
+            frac = fit_parity(vlm.gammas, vlm.q, g["gammas"], g["q"], Y, X, W, max_outlier_frac=1.5 / 90, slack=1e-4)
+            assert frac <= 1.5 / 90
     vlm.fit_gammas(limit_gamma=True)
     ge, qe, _ = oracle.fit_gammas(g["Sx"], g["Ux"], g["Sx"], g["Ux"], limit_gamma=True, exact=True)
     close(vlm.gammas, ge, max(gt, 1e-5), max(gt, 1e-6))
@@ -353,7 +357,7 @@ def test_facade_randomized_control_values_follow_from_the_permuted_matrix(vcy, g
     np.testing.assert_allclose(vlm.corrcoef, g["corrcoef_sqrt"], atol=tol)
 
 
-def test_estimation_module_api(vcy, golden):
+def test_estimation_module_api(vcy, golden, fit_parity):
     est = vcy.estimation
     g = golden("coldeltacor")
     e, d, ixs = g["e"], g["d"], g["ixs"]
@@ -384,8 +388,7 @@ def test_estimation_module_api(vcy, golden):
         m, r2 = est.fit_slope_weighted(f["Y"], f["X"], f["W"], return_R2=True, limit_gamma=lg, dtype="float64")
         np.testing.assert_allclose(m[1:], f[f"weighted_{t}_m"][1:], rtol=1e-4, atol=2e-5)
         m, q, r2 = est.fit_slope_weighted_offset(f["Y"], f["X"], f["W"], limit_gamma=lg, dtype="float64")
-        np.testing.assert_allclose(m[1:], f[f"woffset_{t}_m"][1:], rtol=2e-3, atol=2e-3)
-        np.testing.assert_allclose(q, f[f"woffset_{t}_q"], rtol=2e-3, atol=2e-3)
+        fit_parity(m, q, f[f"woffset_{t}_m"], f[f"woffset_{t}_q"], f["Y"], f["X"], f["W"], slack=1e-6, skip=(0,))   # (m, q are float32 outputs)
         assert np.isnan(m[0]) and m.dtype == np.float32
     m, q, r2 = est.fit_slope_weighted_offset(f["Y"], f["X"], f["W"], fixperc_q=True, dtype="float64")
     np.testing.assert_allclose(q, f["woffset_fix_q"], rtol=1e-6, atol=1e-12)

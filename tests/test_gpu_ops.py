@@ -663,7 +663,7 @@ def test_gene_quantiles_every_register_variant(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
-def test_fit_weighted_vs_oracle_exact(ops, oracle, golden, dtype):
+def test_fit_weighted_vs_oracle_exact(ops, oracle, golden, fit_parity, dtype):
     g = golden("fits")
     rt = 1e-9 if dtype == "float64" else 2e-5
     Y, X, W = (ops.CellMatrix.from_genes_major(g[k], dtype) for k in ("Y", "X", "W"))
@@ -673,8 +673,10 @@ def test_fit_weighted_vs_oracle_exact(ops, oracle, golden, dtype):
     np.testing.assert_allclose(m.cpu().numpy()[1:], me[1:], rtol=rt, atol=rt)
     np.testing.assert_allclose(q.cpu().numpy(), qe, rtol=rt, atol=rt)
     np.testing.assert_allclose(r2.cpu().numpy()[2:], r2e[2:], rtol=10 * rt, atol=10 * rt)
-    # vs the reference's L-BFGS-B stopping point (golden): loose, see SURVEY.md section 7
-    np.testing.assert_allclose(m.cpu().numpy()[1:], g["woffset_nolg_m"][1:], rtol=2e-3, atol=2e-3)
+    # vs the reference's L-BFGS-B stopping point (golden), SURVEY.md section 7's bar: rtol 1e-4 on >= 99 % of the genes (here: all of them),
+    # the objective never worse (f32 storage: the objective is evaluated on the f64 inputs, the parameters come from their f32 roundings)
+    fit_parity(m.cpu().numpy(), q.cpu().numpy(), g["woffset_nolg_m"], g["woffset_nolg_q"], g["Y"], g["X"], g["W"],
+               slack=1e-9 if dtype == "float64" else 1e-5, skip=(0,))
     # gamma only, bounded (fit_slope_weighted) and unweighted with intercept (fit_slope_offset)
     m, _, r2 = ops.fit_weighted(Y, X, 0, W=W, fit_offset=False, lo_gamma=0.0)
     me, r2e = oracle.fit_slope_weighted(g["Y"], g["X"], g["W"], exact=True)

@@ -216,7 +216,7 @@ class AtlasPath:
             tK = ev[0].elapsed_time(ev[1])
         # ---- pass 1: A (pooling of the own cells) + B (fit_slope moments, estimation.py:267-279), block by block
         mom = torch.zeros((3, G), dtype=torch.float64, device=dev)
-        abs_st = None
+        abs_st = absmax = None
         for (b0, b1, erows_out, ixs) in self._plan:
             nb = b1 - b0
             ev[0].record()
@@ -227,8 +227,10 @@ class AtlasPath:
             mom += ops.fit_slope_moments(Ux_b, Sx_b)
             ev[2].record()
             if self.rules is None:                    # first pass only: the scale facts of e = Sx_sz over ALL cells of ALL ranks
-                if self.dtype == torch.float64:       # the f64 sqrt element's domain, checked on every pooled block - the matrix itself, never
-                    ops.check_f64_sqrt_domain(Sx_b)   # the staging buffer (its halo rows are not written yet on the first pass)
+                if self.dtype == torch.float64:       # the f64 sqrt element's domain: max |Sx| of every pooled block - the matrix itself, never
+                    lo, hi = Sx_b.t.aminmax()         # the staging buffer (its halo rows are not written yet on the first pass); judged after
+                    m = torch.maximum(lo.abs(), hi.abs()).double().reshape(1)     # the all-reduce below, by every rank alike
+                    absmax = m if absmax is None else torch.maximum(absmax, m)
                 st = ops.abs_stats(Sx_b)
                 abs_st = st if abs_st is None else torch.stack([abs_st[0] + st[0], torch.minimum(abs_st[1], st[1]), abs_st[2] + st[2]])
             if timed:
@@ -239,7 +241,16 @@ class AtlasPath:
             # every block size (a per-block or per-rank decision could differ on borderline data)
             if abs_st is None:                      # a rank without a block still takes part in the all-reduce: the neutral element
                 abs_st = torch.tensor([0.0, float("inf"), 0.0], dtype=torch.float64, device=self._ebuf.t.device)
-            self.rules = ops.partial_rules_for(self._ebuf, ops.SQRT, self.psc, stats=D.all_reduce_abs_stats(abs_st), cells=self.C, domain_checked=True)
+            stats = D.all_reduce_abs_stats(abs_st)
+            if self.dtype == torch.float64:
+                # a rank that raised on its own block would leave the others waiting in the collectives: the fact is reduced first (MAX),
+                # then every rank takes the same decision
+                if absmax is None:
+                    absmax = torch.zeros(1, dtype=torch.float64, device=self._ebuf.t.device)
+                m = float(D.all_reduce_max(absmax))
+                if not m < ops.F64_SQRT_MAX:
+                    raise ValueError(f"colDeltaCor sqrt transform in f64: |e| reaches {m:.3g}, outside the supported range (< {ops.F64_SQRT_MAX:g})")
+            self.rules = ops.partial_rules_for(self._ebuf, ops.SQRT, self.psc, stats=stats, cells=self.C, domain_checked=True)
         ev[0].record()
         D.all_reduce_sum(mom)
         gamma = ops.fit_slope_from_moments(mom)

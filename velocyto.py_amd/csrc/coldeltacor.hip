@@ -550,7 +550,6 @@ __global__ __launch_bounds__(1024) void k_cdc_partial_grouped(const T *__restric
         //    alternate (NV is even: no copies at the loop edge).
         static_assert(NV % 2 == 0, "operand buffers alternate");
 #define VCY_FENCE() __builtin_amdgcn_sched_barrier(0)
-        constexpr int RQ = 4;
         // (a full chunk - every chunk but the last - loads its rows without predicates: the guarded form costs a v_cmp + s_and_saveexec +
         //  branch per vector, and in the f64 dual kernel the eight lane offsets it keeps for the compares were spilled and each reload
         //  put an s_waitcnt vmcnt(0) in front of the next row load; the two forms are two instances of the row loop below)

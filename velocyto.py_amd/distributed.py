@@ -87,6 +87,18 @@ def all_reduce_abs_stats(st: torch.Tensor, group=None) -> torch.Tensor:
     return st
 
 
+def all_reduce_max(t: torch.Tensor, group=None) -> torch.Tensor:
+    """MAX over the ranks, in place (a fact every rank must judge alike before it raises - e.g. the f64 sqrt element's domain)."""
+    if active():
+        if _host_staged(t, group):
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t
+
+
 def all_gather_rows(local: torch.Tensor, n_total: int, out: Optional[torch.Tensor] = None, group=None) -> torch.Tensor:
     """Reassemble a row-sharded (shard_bounds) tensor: local (n_loc, ...) -> (n_total, ...).
     Equal shards use one all_gather_into_tensor straight into `out`; ragged shards pad to the
@@ -399,11 +411,21 @@ def self_check(device: torch.device, group=None) -> dict:
             table = tuple(tuple(0 if (src == dst or (7 * src + 3 * dst) % 4 == 0) else 5 + 997 * ((src + 2 * dst) % 5) for src in range(ws)) for dst in range(ws))
         recv_splits = list(table[rank])
         send_splits = [table[p][rank] for p in range(ws)]
-        width = 4
+        # Row width and element type are ONE decision for the whole group: free memory is a rank-local fact (and a shared, moving one
+        # when several ranks sit on one device), and an all_to_all_single whose ranks disagree on the element size hangs or corrupts.
+        # Every rank states whether the wide buffers fit where it is; the MIN over the ranks (the all-reduce verified just above) decides.
+        fits = 0.0
         if ws == 8 and device.type == "cuda":
             free, _ = torch.cuda.mem_get_info(device)
-            if free > 3 * (sum(recv_splits) + sum(send_splits)) * 30016 * 8:
-                width = 30016
+            fits = 1.0 if free > 3 * (sum(recv_splits) + sum(send_splits)) * 30016 * 8 else 0.0
+        agreed = torch.tensor([fits], dtype=torch.float64, device=device)
+        if _host_staged(agreed, group):
+            h = agreed.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MIN, group=group)
+            agreed = h
+        else:
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN, group=group)
+        width = 30016 if float(agreed[0]) > 0.5 else 4
         dt = torch.float64 if width > 4 else torch.float32
         send = torch.empty((sum(send_splits), width), dtype=dt, device=device)
         o = 0

@@ -1723,8 +1723,10 @@ class ClockProbe:
         self.samples = None
 
     def start(self, duration_ms: float) -> None:
-        n = int(min(4096, max(2, duration_ms * 1e5 / self.interval + 1)))
+        # (the kernel refuses nsamples x interval beyond 3e8 ticks = 3 s of the 100 MHz counter: a longer request samples its first 3 s)
+        n = int(min(4096, 300_000_000 // max(self.interval, 1), max(2, duration_ms * 1e5 / self.interval + 1)))
         self.samples = torch.zeros((self.nblocks, n, 2), dtype=torch.int64, device=self.dev)
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))     # the zero fill runs on the current stream: the probe starts after it
         _lib.check(_lib.lib().vcy_clock_probe(self.samples.data_ptr(), self.nblocks, n, self.interval, self.stream.cuda_stream), "clock_probe")
 
     def ghz(self) -> Tuple[float, float, float]:
