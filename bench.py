@@ -69,8 +69,9 @@ MIX_CLK_PER_ELEMENT = {1: 27.7, 2: 23.3}
 # wall-clock column; the 19-instruction form it replaced: 83.2)
 MIX_CLK_PER_ELEMENT_F64 = 77.4
 F64_ISSUE_CLK = 4.1               # clocks per wave64 v_add_f64 / v_mul_f64 / v_fma_f64 per SIMD (same file): the f64 issue peak is 1 instruction / 4 clocks
-COUNTERS_FILE = os.path.join(ROOT, "profiles", "r05_cdc_counters.json")     # written by tools/summarize_profiles.py from the rocprofv3 passes
-COUNTERS_FALLBACK = os.path.join(ROOT, "profiles", "r04_cdc_counters.json")
+COUNTERS_FILE = os.path.join(ROOT, "profiles", "r06_cdc_counters.json")     # written by tools/summarize_profiles.py from the rocprofv3 passes
+COUNTERS_FALLBACK = os.path.join(ROOT, "profiles", "r05_cdc_counters.json")
+WIDE_COUNTERS_FILE = os.path.join(ROOT, "profiles", "r06_cdc_wide_counters.json")   # tools/pmc_wide.sh: the launch at the reference's default list width
 
 
 def parse():
@@ -113,6 +114,9 @@ def parse():
     ap.add_argument("--no-overlap", dest="overlap", action="store_false",
                     help="N > 1 with the halo exchange: do not split stage D into interior cells (run while the halo moves) and the rest")
     ap.add_argument("--dump", default=None, help="rank 0 saves gamma and the gathered correlation rows of the last step to this .npz (tests)")
+    ap.add_argument("--generator", choices=["survey", "bench"], default="survey",
+                    help="synthetic dataset: 'survey' (default from round 6) = SURVEY.md 8(d)'s - numpy PCG64(20180808 + cfg#), 12 clusters on a branching latent "
+                         "time, the splicing ODE's closed form; 'bench' = the device-side generator rounds 1-5 were timed on (one branch point, seed 20180811)")
     ap.add_argument("--curve", choices=["morton", "hilbert"], default="hilbert",
                     help="space-filling curve of the stage-D schedule and of the cell relabelling of sharded runs (Hilbert: no jumps, "
                          "8-cell groups share more neighbours: 97.3 vs 98.6 ms)")
@@ -171,6 +175,95 @@ def synth_counts(C, G, P, dev, seed=20180811):
     return cS, cU, fS, fU, pcs
 
 
+SURVEY_SEED0 = 20180808          # seed = 20180808 + cfg#
+
+# the branching latent time of the survey generator: 12 clusters = 12 (lineage, time interval) pieces of a tree with three leaves.
+# Lineage bits: 1 = A1, 2 = A2, 4 = B (a cell on the trunk belongs to all three, a cell on branch A to A1 and A2).
+_SURVEY_CLUSTERS = ((7, 0.00, 0.12), (7, 0.12, 0.25),                                  # trunk
+                    (3, 0.25, 0.37), (3, 0.37, 0.49), (3, 0.49, 0.60),                 # branch A before it splits
+                    (1, 0.60, 0.80), (1, 0.80, 1.00), (2, 0.60, 0.80), (2, 0.80, 1.00),   # leaves A1, A2
+                    (4, 0.25, 0.50), (4, 0.50, 0.75), (4, 0.75, 1.00))                 # branch B
+
+
+def synth_counts_survey(C, G, P, dev, cfg=3):
+    """SURVEY.md section 8(d)'s generator: numpy.random.Generator(PCG64(20180808 + cfg#)); 12 clusters on a branching latent time
+    t_c in [0, 1]; per gene alpha ~ LogNormal(0, 1), beta = 1, gamma ~ LogNormal(-0.5, 0.5), 60 % of the genes switch on or off at a
+    random t (the analytic u(t), s(t) of the splicing ODE du/dt = alpha - u, ds/dt = u - gamma s, ODE time = 10 x latent time), the
+    rest constitutive (steady state); per-cell size factor ~ LogNormal(0, 0.3); U ~ Poisson(size u 0.3), S ~ Poisson(size s); uint16.
+    Every PARAMETER (cluster, latent time, alpha, gamma, switch time, direction, lineage mask, size) is drawn on the host from that PCG64 stream,
+    identically on every box; the 3e9 Poisson draws themselves are made on the device (torch's Philox generator, seeded from the same stream) -
+    on the host they would take minutes.  Returns (cS, cU, fS, fU, pcs) like synth_counts."""
+    from velocyto_amd import ops
+    rng = np.random.Generator(np.random.PCG64(SURVEY_SEED0 + cfg))
+    T_ODE = 10.0
+    cl = rng.integers(0, len(_SURVEY_CLUSTERS), C)
+    tab = np.array(_SURVEY_CLUSTERS, dtype=np.float64)
+    t_np = tab[cl, 1] + rng.random(C) * (tab[cl, 2] - tab[cl, 1])
+    lin_np = tab[cl, 0].astype(np.int64)
+    alpha_np = np.exp(rng.normal(0.0, 1.0, G))
+    gamma_np = np.exp(rng.normal(-0.5, 0.5, G))
+    gamma_np = np.where(np.abs(gamma_np - 1.0) < 1e-3, 1.001, gamma_np)          # (the closed form divides by gamma - beta)
+    switching_np = rng.random(G) < 0.6
+    t_sw_np = rng.random(G) * 0.8
+    turns_on_np = rng.random(G) < 0.5                                            # else: starts at steady state and is switched off
+    mask_np = np.where(rng.random(G) < 0.5, 7, rng.integers(1, 7, G))            # lineages on which the switch happens (half of them: everywhere)
+    size_np = np.exp(rng.normal(0.0, 0.3, C))
+    gen = torch.Generator(device=dev).manual_seed(int(rng.integers(0, 2 ** 62)))
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    t, size = f32(t_np), f32(size_np)
+    lin = torch.from_numpy(lin_np).to(dev)
+    alpha, gam, t_sw = f32(alpha_np), f32(gamma_np), f32(t_sw_np)
+    switching, turns_on = torch.from_numpy(switching_np).to(dev), torch.from_numpy(turns_on_np).to(dev)
+    gmask = torch.from_numpy(mask_np.astype(np.int64)).to(dev)
+    ld = ops.padded_ld(G)
+    S = torch.zeros((C, ld), dtype=torch.int16, device=dev)
+    U = torch.zeros((C, ld), dtype=torch.int16, device=dev)
+    sumS = torch.zeros(C, dtype=torch.float64, device=dev)
+    sumU = torch.zeros(C, dtype=torch.float64, device=dev)
+    u_ss, s_ss = alpha[None, :], (alpha / gam)[None, :]
+    blk = 4096
+    for b in range(0, C, blk):
+        tt = t[b:b + blk, None]
+        # the switch has happened for this cell if its lineage carries it and its latent time is past the switch time
+        active = switching[None, :] & ((lin[b:b + blk, None] & gmask[None, :]) != 0) & (tt > t_sw[None, :])
+        tau = torch.clamp(tt - t_sw[None, :], min=0.0) * T_ODE
+        e1, eg = torch.exp(-tau), torch.exp(-gam[None, :] * tau)
+        u_on = alpha[None, :] * (1 - e1)
+        s_on = (alpha / gam)[None, :] * (1 - eg) + (alpha / (gam - 1.0))[None, :] * (eg - e1)
+        u_off = alpha[None, :] * e1
+        s_off = (s_ss - u_ss / (gam[None, :] - 1.0)) * eg + u_ss * e1 / (gam[None, :] - 1.0)
+        on = turns_on[None, :]
+        u = torch.where(active, torch.where(on, u_on, u_off), torch.where(on & switching[None, :], torch.zeros_like(u_on), u_ss.expand_as(u_on)))
+        sp = torch.where(active, torch.where(on, s_on, s_off), torch.where(on & switching[None, :], torch.zeros_like(s_on), s_ss.expand_as(s_on)))
+        sz = size[b:b + blk, None]
+        cu = torch.poisson(0.3 * sz * u.clamp_(min=0.0), generator=gen).clamp_(max=65535)
+        cs = torch.poisson(sz * sp.clamp_(min=0.0), generator=gen).clamp_(max=65535)
+        sumU[b:b + blk], sumS[b:b + blk] = cu.sum(1).double(), cs.sum(1).double()
+        U[b:b + blk, :G] = cu.to(torch.int32).to(torch.int16)
+        S[b:b + blk, :G] = cs.to(torch.int32).to(torch.int16)
+    fS = sumS.mean() / sumS.clamp(min=1.0)
+    fU = sumU.mean() / sumU.clamp(min=1.0)
+    cS, cU = ops.CountMatrix(S, G).narrowed(), ops.CountMatrix(U, G).narrowed()
+    if cS.t.dtype != cU.t.dtype:
+        cS, cU = ops.CountMatrix(S, G), ops.CountMatrix(U, G)
+    L = torch.empty((C, G), dtype=torch.float32, device=dev)
+    for b in range(0, C, blk):
+        L[b:b + blk] = torch.log2(cS.as_int32(b, b + blk).float() * fS[b:b + blk, None].float() + 1.0)
+    L -= L.mean(0, keepdim=True)
+    torch.manual_seed(SURVEY_SEED0 + cfg)
+    Uu, Ss, _ = torch.svd_lowrank(L, q=P, niter=2)
+    pcs = (Uu * Ss).double().contiguous()
+    del L
+    return cS, cU, fS, fU, pcs
+
+
+def make_dataset(a, dev):
+    """The headline dataset of this run (--generator)."""
+    if getattr(a, "generator", "survey") == "survey":
+        return synth_counts_survey(a.cells, a.genes, a.pca_dims, dev, cfg=3)
+    return synth_counts(a.cells, a.genes, a.pca_dims, dev)
+
+
 def synth(C, G, P, dev, seed=20180811):
     """The same dataset as size-normalised f32 matrices S_sz, U_sz (cells-major) + pcs."""
     cS, cU, fS, fU, pcs = synth_counts(C, G, P, dev, seed)
@@ -209,7 +302,7 @@ class Pipeline:
         self.rules = None                        # stage-D branch rule, decided on the first pooled matrix
         C, G = args.cells, args.genes
         # resident inputs: the loom's count layers + per-cell size factors (S_sz = fS * S is never materialised)
-        self.cS, self.cU, self.fS, self.fU, self.pcs = data if data is not None else synth_counts(C, G, args.pca_dims, dev)
+        self.cS, self.cU, self.fS, self.fU, self.pcs = data if data is not None else make_dataset(args, dev)
         if counts == "u16":                      # real looms are uint16 on disk (constants.py:11); a few heavy genes exceed 255
             widen = lambda m: m if m.t.dtype == torch.int16 else ops.CountMatrix(m.t.to(torch.int16), m.G)
             self.cS, self.cU = widen(self.cS), widen(self.cU)
@@ -372,8 +465,10 @@ class Pipeline:
             x = smp.cpu().numpy().astype(np.float64)
             dc, dr = np.diff(x[:, :, 0], axis=1), np.diff(x[:, :, 1], axis=1)
             f.append(dc / np.maximum(dr, 1.0) * 0.1)
-        f = np.concatenate([v.ravel() for v in f])
-        return {"mean": float(f.mean()), "min": float(f.min()), "max": float(f.max()), "launches": len(self.probe_samples), "readings": int(f.size)}
+        per_xcd = np.concatenate(f, axis=1)                     # (8 probe workgroups = 8 XCDs, readings)
+        f = per_xcd.ravel()
+        return {"mean": float(f.mean()), "min": float(f.min()), "max": float(f.max()), "launches": len(self.probe_samples), "readings": int(f.size),
+                "per_xcd_mean": [round(float(v), 4) for v in per_xcd.mean(1)], "per_xcd_min": [round(float(v), 4) for v in per_xcd.min(1)]}
 
     def probe_clock(self, steps=3):
         """`steps` extra, untimed steps with the clock probe running beside their stage-D launches (after the timed steps: same data, same
@@ -784,12 +879,14 @@ def run(a, rank, local_rank, world):
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
+    smi_before = smi_sample() if rank == 0 else None
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         pipe.step(timed=True)
     barrier()
     dt = time.perf_counter() - t0
+    smi_after = smi_sample() if rank == 0 else None
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -850,6 +947,11 @@ def run(a, rank, local_rank, world):
                                    f"{a.pca_dims} PCs) -> fit_slope -> velocity chain -> colDeltaCorSqrtpartial(nrndm={nr}, "
                                    f"n_neighbors={a.n_neighbors}, sampled_fraction={a.sampled_fraction}, psc=1e-10)",
                        "cells": C, "genes": G, "k": a.k, "nrndm": nr,
+                       "generator": ("survey: SURVEY.md 8(d) - numpy PCG64(20180808 + 3) parameters, 12 clusters on a branching latent time, closed-form splicing ODE; "
+                                     "Poisson draws on the device" if a.generator == "survey" else
+                                     "bench: device-side torch generator, seed 20180811 (= 20180808 + cfg 3), alpha ~ LogNormal(0, 1), gamma ~ LogNormal(-0.5, 0.5), 60 % switching "
+                                     "genes, one branch point, size ~ LogNormal(0, 0.3), U ~ Poisson(0.3 size u), S ~ Poisson(size s) - the dataset of rounds 1-5; "
+                                     "--generator survey is SURVEY.md 8(d)'s 12-cluster tree (DESIGN.md section 4)"),
                        "inputs": f"spliced/unspliced count layers ({'uint8: narrowed, no count of this dataset exceeds 255' if pipe.cS.t.dtype == torch.uint8 else 'uint16, the loom type of constants.py:11'}) "
                                  "+ per-cell size factors (S_sz = factor*counts), pcs, sampled neighbours",
                        "count_layer_dtype": "uint8" if pipe.cS.t.dtype == torch.uint8 else "uint16",
@@ -868,6 +970,9 @@ def run(a, rank, local_rank, world):
                        "velocity_chain": "folded into the staging of d[c] in the stage-D kernel" if a.fuse else "k_velocity_chain (dmat materialised)",
                        "cell_order_D": a.order + (f" ({a.curve} curve)" if a.order == "embedding" else "")},
             "roofline": roof, "stages": stages,
+            "telemetry": {"smi_before_timed_steps": smi_before, "smi_after_timed_steps": smi_after,
+                          "note": "rocm-smi of GPU 0 (socket power, temperatures, clocks as the SMI reports them) sampled on the host right before and right "
+                                  "after the timed steps; the shader clock UNDER stage D is roofline.effective_clock (per XCD: per_xcd_mean / per_xcd_min)"},
         }
         if world == 1 and not a.no_extra:
             res["precision_modes"], res["extra"] = extra_lines(a, dev, pipe, res)
@@ -907,6 +1012,27 @@ def _free_port():
         return sk.getsockname()[1]
 
 
+def smi_sample():
+    """Socket power, temperatures and clocks of GPU 0 as the SMI reports them (rocm-smi, read-only; an ordinary user may call it).  A
+    213-ms-versus-247-ms pair of runs of the same binary at the same shader clock should explain itself: every bench
+    line carries one sample taken before the timed steps and one right after them.  Never raises: a box without the tool says so."""
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        r = subprocess.run([exe, "-d", "0", "--showpower", "--showtemp", "--showclocks", "--showperflevel", "--json"], capture_output=True, text=True, timeout=20)
+        d = json.loads(r.stdout[r.stdout.index("{"):])
+        card = d[sorted(d)[0]]
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(w in kl for w in ("power", "temperature", "sclk", "mclk", "fclk", "socclk", "performance level")):
+                keep[k] = v
+        return keep or {"error": "rocm-smi returned no power / temperature / clock field", "fields": sorted(card)[:12]}
+    except Exception as e:                                                      # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"[:200]}
+
+
 def _short(p, steps):
     """One untimed + `steps` timed steps of a pipeline (wall clock between device syncs, HIP-event stage times inside)."""
     p.step()
@@ -938,7 +1064,38 @@ def wide_list_line(a, dev, pipe):
     ms = e0.elapsed_time(e1)
     pairs = float(C) * wide.shape[1]
     fin = torch.isfinite(out)
+    # its own roofline: row sharing is very different at this width (adjacent cells share most of their 10 000 nearest), so the
+    # instructions per pair-chunk come from a PMC pass of THIS launch (tools/pmc_wide.sh), not from the nrndm = 250 one
+    roof = None
+    s = 8 if pipe.dtype == torch.float64 else 4
+    if s == 8 and pipe.rules == 1:
+        try:
+            with open(WIDE_COUNTERS_FILE) as f:
+                cnt = json.load(f)["f64_wide"]
+        except Exception:
+            cnt = None
+        G = a.genes
+        chunk = 8 * 64 * 2
+        pair_chunks = pairs * ((G + chunk - 1) // chunk)
+        mix_floor_ms = pairs * G * MIX_CLK_PER_ELEMENT_F64 / 64.0 / (1024 * 2.4e9) * 1e3
+        roof = {"bound": "valu", "kernel": "k_cdc_partial_grouped<double, SQRT, rules 1, 6 cells, 8 vectors> in column tiles (velocity chain folded in)",
+                "unit": "Ginstr/s", "peak": VALU_ISSUE_PEAK / 1e9, "avg_launch_ms": ms, "mix_floor_ms": mix_floor_ms, "frac_of_mix_floor": mix_floor_ms / ms,
+                "algorithmic_bytes_per_launch": C * ((wide.shape[1] + 2) * G * s + wide.shape[1] * (4 + s))}
+        roof["vs_noreuse_model"] = roof["algorithmic_bytes_per_launch"] / (ms * 1e-3) / HBM_PEAK
+        if cnt and cnt.get("valu_insts_per_pair_chunk"):
+            achieved = cnt["valu_insts_per_pair_chunk"] * pair_chunks / (ms * 1e-3)
+            roof.update({"achieved": achieved / 1e9, "frac": achieved / VALU_ISSUE_PEAK, "frac_of_f64_issue_peak": achieved / (VALU_ISSUE_PEAK * 2.0 / F64_ISSUE_CLK),
+                         "profile_valu_insts_per_pair_chunk": cnt["valu_insts_per_pair_chunk"], "profile_launch_ms": cnt.get("profiled_launch_ms"),
+                         "profile_wave_time": cnt.get("wave_time"), "profile_effective_clock_ghz": cnt.get("effective_clock_ghz"),
+                         "traffic": cnt.get("hbm_bytes_per_launch"),
+                         "hbm_frac_measured": (cnt["hbm_bytes_per_launch"] / (ms * 1e-3) / HBM_PEAK) if cnt.get("hbm_bytes_per_launch") else None,
+                         "counters_from": os.path.relpath(WIDE_COUNTERS_FILE, ROOT)})
+        else:
+            roof.update({"achieved": None, "frac": None, "counters_from": None})
     return {"ms": ms, "launches_timed": 1, "nrndm": int(wide.shape[1]), "n_neighbors": nn, "sampled_fraction": 0.3, "dtype": a.dtype,
+            "cells_per_s": C / (ms * 1e-3), "roofline": roof,
+            "parity": "tests/test_gpu_fullsize.py::test_fullsize_stage_d_reference_default_list_width_against_the_oracle: 128 whole cells x all 3000 columns x "
+                      "30 000 genes against the fp64 oracle in every arithmetic mode (f64 1e-9, f32 5e-5), single and dual-control launches",
             "ns_per_pair": ms * 1e6 / pairs, "ns_per_pair_at_nrndm_250": float(np.mean(pipe.d_ms)) * 1e6 / (float(C) * pipe.nrndm),
             "finite_fraction": float(fin.float().mean()), "max_abs_corr": float(out[fin].abs().max()),
             "note": "estimate_transition_prob's defaults (analysis.py:1452-1457); the compact (cells, 3000) output, one launch"}
@@ -994,7 +1151,8 @@ def cfg2_lines(a, dev, dtype):
     facade (knn_imputation -> fit_gammas(fit_offset=False, weighted=False) = fit_slope), unbalanced and balanced=True, b_sight=240, b_maxl=120."""
     import velocyto_amd as vcy
     C, G = 10000, 20000
-    cS, cU, fS, fU, pcs = synth_counts(C, G, a.pca_dims, dev, seed=20180810)
+    cS, cU, fS, fU, pcs = (synth_counts_survey(C, G, a.pca_dims, dev, cfg=2) if getattr(a, "generator", "survey") == "survey"
+                           else synth_counts(C, G, a.pca_dims, dev, seed=20180810))
     vlm = vcy.analysis.VelocytoLoom.from_arrays(cS, cU, dtype=dtype)
     vlm.pcs = pcs.cpu().numpy()
     vlm.normalize("both", size=True, log=False)

@@ -419,8 +419,8 @@ def sparse_from_lists(dsi, dist, n):
 def test_fullsize_stage_d_reference_default_list_width_against_the_oracle(world, oracle):
     """Stage D at the headline size with the reference's DEFAULT neighbour lists (analysis.py:1452-1457, 1528-1572: n_neighbors =
     cells / 5 = 10 000, sampled_fraction = 0.3 => nrndm = 3000, walked in 12+ column tiles per group) against the fp64 oracle on
-    32 whole cells x ALL 3000 columns x 30 000 genes: 16 cells from the middle of the launch schedule and the LAST 16 of it
-    (the groups beyond the last full round, which run as narrower column tiles).  Every arithmetic mode of the build:
+    128 whole cells x ALL 3000 columns x 30 000 genes (384 000 correlations per mode): six batches of 16 cells from across the launch
+    schedule and the LAST 32 of it (the groups beyond the last full round, which run as narrower column tiles).  Every arithmetic mode of the build:
     f64 storage with the literal rule (the reference's arithmetic, 1e-9), f32 with the production rule and with the literal
     rule (5e-5); the fused launch and the fused dual-control launch (the control's correlations against the oracle too, and the
     real ones of the dual launch equal to the single launch: bit for bit in f32 - same chunk length, same order of summation -, to
@@ -433,9 +433,10 @@ def test_fullsize_stage_d_reference_default_list_width_against_the_oracle(world,
     wide, _ = bench.sample_neighbors_device(emb, C // 5, 0.3, dev)
     assert wide.shape == (C, 3000)
     order = ops.hilbert_order(emb)
-    pos_mid = 20000
-    cells = torch.cat([order[pos_mid:pos_mid + 16], order[C - 16:]]).long()
-    assert C - 16 >= (C // 8 // 256) * 256 * 8 and C - 16 >= (-(-C // 6) // 256) * 256 * 6       # the last 16 sit in the tiled tail part (8- and 6-cell groups)
+    NCHK = 128
+    cells = torch.cat([order[p:p + 16] for p in (4000, 12000, 20000, 28000, 36000, 44000)] + [order[C - 32:]]).long()
+    assert cells.numel() == NCHK
+    assert C - 32 >= (C // 8 // 256) * 256 * 8 and C - 32 >= (-(-C // 6) // 256) * 256 * 6       # the last 32 sit in the tiled tail part (8- and 6-cell groups)
     # the graph and the pooled matrices from the count layers, in both storage types
     idx, dist = ops.knn_search(pcs, K)
     cS, cU, fS, fU, _ = bench_counts()
@@ -476,7 +477,7 @@ def test_fullsize_stage_d_reference_default_list_width_against_the_oracle(world,
     Sx, Ux, g64, d2 = ref_inputs
     tol = {"f64": 1e-9, "f32": 5e-5}
     worst = {}
-    for b in range(0, 32, 16):
+    for b in range(0, NCHK, 16):
         cs = cells[b:b + 16]
         nb = wide[cs].long().cpu().numpy()
         cs_np = cs.cpu().numpy()
