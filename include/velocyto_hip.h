@@ -59,7 +59,7 @@ typedef void *vcy_stream;  /* hipStream_t */
 
 const char *vcy_last_error(void);
 /* 4 (round 6).  History: 1 -> 2: vcy_diffuse_step_factored gained `int prepared` before compute_dtype; vcy_gram and vcy_embedding_scaling added;
- * vcy_knn_pool_csr requires >= 4 stored elements.  2 -> 3: vcy_clock_probe and vcy_coldeltacor_full_linear added.  3 -> 4: vcy_coldeltacor_full_linear_workspace_bytes takes C_out (repair flags).  A binder refuses a library whose version it was not built
+ * vcy_knn_pool_csr requires >= 4 stored elements.  2 -> 3: vcy_clock_probe and vcy_coldeltacor_full_linear added.  3 -> 4: vcy_coldeltacor_full_linear_workspace_bytes takes C_out (repair flags); vcy_gemm_nt added.  A binder refuses a library whose version it was not built
  * against (velocyto_amd/_lib.py: EXPECTED_ABI). */
 int vcy_abi_version(void);
 /* Number of CUs / LDS bytes per workgroup of the current device (host query). */
@@ -490,6 +490,18 @@ int vcy_gram(const void *X, const double *mean, double *gram, void *workspace, i
              vcy_stream stream);
 int vcy_gram_tn(const void *X, const double *mean, const double *Y, double *out, void *workspace, int64_t C, int64_t G, int64_t L, int64_t ld,
                 int64_t ldy, int64_t ldo, int dtype, vcy_stream stream);
+
+/* The products of the same caller that contract over the GENES (analysis.py:678-702 through sklearn's PCA: the projection of the centred matrix on
+ * a thin block - every pass of the subspace iteration, and `transform`, the scores pcs = (X - mean) components^T - and, with fewer cells than
+ * genes, the cells' own Gram matrix):
+ *     out[i][j] = sum_{g < K} A[i][g] B[j][g]  -  row_corr[i]  -  col_corr[j]  +  c0          out (M, ldo) fp64
+ * A: (M, lda) of dtype_a (VCY_F32 / VCY_F64), B: (N, ldb) of dtype_b (dtype_a, or VCY_F64 beside an f32 A), both walked along their contiguous
+ * dimension; row_corr (M) / col_corr (N) fp64 device vectors or NULL.  Centring is algebra on the corrections, not a pass over the matrix:
+ * (X - m) Z = X Z - 1 (m Z); (X - m)(X - m)^T = X X^T - a 1^T - 1 a^T + m.m with a = X m - the rows are read as stored, once.
+ * v_mfma_f64_16x16x4_f64, 128 x 64 tiles, slabs DMA'd into LDS (global_load_lds_dwordx4), fp64 accumulation in a fixed order.  Both row pitches must
+ * hold whole slabs of 16 (f64 A) / 32 (f32 A) genes with ZEROS beyond K (the cells-major layout's padding), rows 16-byte aligned.            */
+int vcy_gemm_nt(const void *A, const void *B, const double *row_corr, const double *col_corr, double c0, double *out, int64_t M, int64_t N, int64_t K,
+                int64_t lda, int64_t ldb, int64_t ldo, int dtype_a, int dtype_b, vcy_stream stream);
 
 /* ---------------------------------------------------------------- upstream callers: epsilon-SVR, RBF kernel, scalar inputs
  * The noise models of score_cv_vs_mean (analysis.py:280-282, 324-326: sklearn.svm.SVR(gamma=150/G).fit(log2 mean, log2 CV), one point

@@ -313,3 +313,93 @@ def test_gram_kernel_identity_probe():
     M = ops.CellMatrix.from_cells_major(X, torch.float64)
     assert torch.equal(ops.gram_tn(M, None, Y), Y[:G])
     assert torch.equal(ops.gram(M, None), torch.eye(G, dtype=torch.float64, device=dev))
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("C,G,N", [(5, 3, 1), (130, 17, 7), (300, 65, 64), (1000, 257, 50), (700, 1153, 130), (257, 96, 257)])
+def test_gemm_nt_kernel_against_the_library_gemm(dtype, C, G, N):
+    """vcy_gemm_nt (csrc/gram.hip, v_mfma_f64_16x16x4_f64, slabs DMA'd into LDS): the products of perform_PCA that contract over the
+    genes (analysis.py:678-702 through sklearn's PCA: projection on a thin block, `transform`, the cells' Gram matrix), against torch's
+    fp64 GEMM of the explicitly centred matrix.  Shapes cover one partial tile, ragged tile edges in both directions, gene counts that
+    end inside a slab (zero padding), thin (N = 1) and wide blocks; f32 storage of X beside an fp64 block (256-byte slab rows)."""
+    import velocyto_amd
+    from velocyto_amd import ops
+    dev = ops.require_gpu()
+    gen = torch.Generator(device=dev).manual_seed(C * 7 + G + N)
+    X = torch.randn((C, G), generator=gen, device=dev, dtype=torch.float64) * torch.linspace(0.5, 3.0, G, device=dev, dtype=torch.float64) + \
+        torch.linspace(-2.0, 40.0, G, device=dev, dtype=torch.float64)
+    M = ops.CellMatrix.from_cells_major(X, getattr(torch, dtype))
+    Xs = M.t[:, :G].double()
+    mean = ops.col_means(M)
+    A = Xs - mean
+    B = torch.randn((N, G), generator=gen, device=dev, dtype=torch.float64) * torch.arange(1, N + 1, device=dev, dtype=torch.float64)[:, None]
+    # plain product, asymmetric right-hand side
+    got = ops.gemm_nt(M, B)
+    ref = Xs @ B.T
+    assert got.shape == (C, N) and float((got - ref).abs().max()) <= 1e-12 * float(ref.abs().max()) + 1e-12
+    assert torch.equal(got, ops.gemm_nt(M, B)), "fixed summation order: run-to-run identical"
+    # the centred projection (X - m) B^T through the column correction - what DevicePCA's subspace pass and `transform` call
+    proj = ops.gemm_nt(M, B, col_corr=B @ mean)
+    pref = A @ B.T
+    assert float((proj - pref).abs().max()) <= 1e-11 * float(ref.abs().max()) + 1e-12       # (error of the expansion: relative to the uncentred product)
+    # into a strided output (a column block of a wider buffer), as the subspace pass writes Y
+    wide = torch.full((C, N + 3), 7.0, dtype=torch.float64, device=dev)
+    ops.gemm_nt(M, B, col_corr=B @ mean, out=wide[:, :N])
+    assert torch.equal(wide[:, :N], proj) and bool((wide[:, N:] == 7.0).all())
+    # the cells' own Gram matrix, centred by algebra: (X - m)(X - m)^T = X X^T - a 1^T - 1 a^T + m.m, a = X m
+    a = ops.gemm_nt(M, mean[None, :])[:, 0].contiguous()
+    assert float((a - Xs @ mean).abs().max()) <= 1e-12 * float((Xs @ mean).abs().max()) + 1e-12
+    gram = ops.gemm_nt(M, M, row_corr=a, col_corr=a, c0=float(mean @ mean))
+    gref = A @ A.T
+    assert float((gram - gref).abs().max()) <= 1e-11 * float((Xs @ Xs.T).abs().max())
+    assert float((gram - gram.T).abs().max()) <= 1e-11 * float((Xs @ Xs.T).abs().max())
+
+
+def test_gemm_nt_kernel_identity_probe():
+    """Lane maps and the piece swizzle of vcy_gemm_nt pinned exactly: X = [I | 0] (cells x genes) against an asymmetric B gives X B^T =
+    B^T's first rows, bit for bit - in both storage types of X (128- and 256-byte slab rows of B)."""
+    import velocyto_amd
+    from velocyto_amd import ops
+    dev = ops.require_gpu()
+    C, G, N = 200, 333, 96
+    X = torch.zeros((C, G), dtype=torch.float64, device=dev)
+    X[:, :C] = torch.eye(C, dtype=torch.float64, device=dev)
+    B = (torch.arange(N, device=dev, dtype=torch.float64)[:, None] * 1000.0 + torch.arange(G, device=dev, dtype=torch.float64)[None, :]).contiguous()
+    for dt in (torch.float64, torch.float32):
+        M = ops.CellMatrix.from_cells_major(X, dt)
+        assert torch.equal(ops.gemm_nt(M, B), B[:, :C].T.contiguous())
+
+
+def test_pca_products_are_the_librarys_own_kernels(monkeypatch):
+    """perform_PCA's device route sends no (cells x genes) operand through a library GEMM: with torch.matmul made to refuse operands of the
+    matrix's size, all three routes (covariance, dual for more genes than cells, subspace iteration) still run - and agree."""
+    import velocyto_amd
+    from velocyto_amd import ops
+    from velocyto_amd.preprocess import DevicePCA
+    dev = ops.require_gpu()
+    gen = torch.Generator(device=dev).manual_seed(11)
+    C, G, r = 5000, 4500, 8
+    L = torch.randn((C, r), generator=gen, device=dev, dtype=torch.float64) * torch.linspace(10, 3, r, device=dev, dtype=torch.float64)
+    X = L @ torch.randn((r, G), generator=gen, device=dev, dtype=torch.float64) + torch.randn((C, G), generator=gen, device=dev, dtype=torch.float64) + 1.5
+    M = ops.CellMatrix.from_cells_major(X, torch.float64)
+    Mw = ops.CellMatrix.from_cells_major(X[:900], torch.float64)          # 900 cells x 4500 genes: the dual route
+    real_matmul = torch.Tensor.__matmul__
+
+    def guarded(a, b):
+        for t in (a, b):
+            assert not (torch.is_tensor(t) and t.dim() == 2 and min(t.shape) >= 900 and max(t.shape) >= 4000), f"library GEMM on a {tuple(t.shape)} operand"
+        return real_matmul(a, b)
+    monkeypatch.setattr(torch.Tensor, "__matmul__", guarded)
+    exact = DevicePCA(n_components=6, svd_solver="full")
+    p_exact = exact.fit_transform(M)
+    sub = DevicePCA(n_components=6, svd_solver="subspace")
+    p_sub = sub.fit_transform(M)
+    dual = DevicePCA(n_components=6, svd_solver="full")
+    p_dual = dual.fit_transform(Mw)
+    monkeypatch.undo()
+    np.testing.assert_allclose(sub.explained_variance_, exact.explained_variance_, rtol=1e-8)
+    np.testing.assert_allclose(p_sub, p_exact, atol=1e-5 * np.abs(p_exact).max())
+    Xw = X[:900].cpu().numpy()
+    Uu, s, Vt = np.linalg.svd(Xw - Xw.mean(0), full_matrices=False)
+    np.testing.assert_allclose(np.abs(p_dual), np.abs(Uu[:, :6] * s[:6]), atol=1e-8 * s[0])
+    np.testing.assert_allclose(dual.singular_values_, s[:6], rtol=1e-10)

@@ -79,6 +79,7 @@ SIGNATURES = {
     "vcy_col_means": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]),
     "vcy_gram": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp]),
     "vcy_gram_tn": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_vp]),
+    "vcy_gemm_nt": (c_int, [c_vp, c_vp, c_vp, c_vp, c_dbl, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp]),
     "vcy_svr_workspace_bytes": (c_i64, [c_i64]),
     "vcy_svr_rbf_fit": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_dbl, c_dbl, c_dbl, c_dbl, c_i64, c_vp]),
     "vcy_svr_rbf_predict": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_dbl, c_vp]),

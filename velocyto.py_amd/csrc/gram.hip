@@ -816,6 +816,155 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_cdc_full_linear_dma(const T *
     nt_epilogue<T>(accE, accD, sums, rm, flags, flag_pitch, C, G, cell0, C_out, ld_rm, accumulate, c0, i0, wi, wj, lrow, lcol);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The products of perform_PCA that contract over the GENES (velocyto/analysis.py:678-702 through sklearn's PCA: the projection of the centred
+// matrix on a thin block, `transform`, and - with fewer cells than genes - the cells' own Gram matrix):
+//     out[i][j] = sum_g A[i][g] B[j][g]  -  rc[i]  -  cc[j]  +  c0            A (M, lda) of TA, B (N, ldb) of TB, out (M, ldo) fp64
+// Both operands are walked along their contiguous dimension ("NT"), exactly the shape of the linear all-pairs kernel above, and the kernel is
+// that kernel's LDS-DMA form with one product instead of two: 128 x 64 tiles, slabs of 128-byte A rows DMA'd from global memory straight into
+// LDS (global_load_lds_dwordx4), XOR-swizzled pieces, f64 matrix cores.  Centring is algebra, not a pass over the matrix: with m the gene means,
+//     (X - m) Z         = X Z - 1 (m Z)                     cc = m Z                                  (subspace pass, transform)
+//     (X - m)(X - m)^T  = X X^T - a 1^T - 1 a^T + m.m       rc = cc = a = X m, c0 = m.m               (fewer cells than genes)
+// so the rows are read AS STORED (f32 or f64; no fp64 block copies of X) and once.  B may be fp64 beside an f32 A (the thin block of the
+// subspace iteration must not be rounded to f32): its slab rows are then 256 bytes, 16 pieces, swizzled over 16 rows.
+// Thin blocks (N <= 64: one column of tiles) make this a stream over A: 12 GB of f64 rows per pass at 50 000 x 30 000.
+// TM: rows of A per workgroup (128: square products, every staged f64 of A feeds 4 matrix instructions per wave; 64: thin blocks, twice the
+// workgroups).  NPA: 16-byte pieces of an A row per slab (8: 128-byte rows; 16: 256-byte rows - a thin product is a stream over A, and HBM serves
+// 50 000 interleaved row streams the better the longer each request run is).  NST LDS buffers, slab s + NST - 1 requested before slab s is
+// multiplied: a wave waits only for the slab it needs next (s_waitcnt vmcnt(<its requests still allowed in flight>)), never for the one just issued.
+template <typename TA, typename TB, int TM, int NPA, int NST>
+__global__ __launch_bounds__(GM_THREADS) void k_gemm_nt_dma(const TA *__restrict__ A, const TB *__restrict__ B, const double *__restrict__ rc,
+                                                            const double *__restrict__ cc, double c0, double *__restrict__ out, int M, int N, int K,
+                                                            int64_t lda, int64_t ldb, int64_t ldo, int ntn)
+{
+    static_assert((TM == 128 || TM == 64) && (NPA == 8 || NPA == 16) && (NST == 2 || NST == 3), "shapes");
+    constexpr int TNB = 64;
+    constexpr int XT = TM / 32;                                       // 16-row MFMA tiles per wave along i (waves 2 x 2: a wave owns TM / 2 x 32)
+    constexpr int PGA = 16 / (int)sizeof(TA), PGB = 16 / (int)sizeof(TB);  // genes per 16-byte piece
+    constexpr int KSL = NPA * PGA;                                    // genes per slab
+    constexpr int NPB = KSL / PGB;                                    // pieces of a B row of a slab: NPA (same type) or 2 NPA (f32 A, f64 B)
+    constexpr int NB = PGA / PGB;                                     // B pieces beside one A piece
+    constexpr int ROWB_A = NPA * 16, ROWB_B = NPB * 16;
+    constexpr int BUF = TM * ROWB_A + TNB * ROWB_B;
+    static_assert(NST * BUF <= 160 * 1024, "the slabs in flight must fit the LDS of a CU");
+    __shared__ __attribute__((aligned(16))) char buf0[BUF];           // (separate arrays: see k_cdc_full_linear_dma)
+    __shared__ __attribute__((aligned(16))) char buf1[BUF];
+    __shared__ __attribute__((aligned(16))) char buf2[NST == 3 ? BUF : 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int total = (int)gridDim.x, per = (total + 7) / 8;
+    const int q = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    const int mt = q / ntn, nt = q - mt * ntn;
+    if (mt * TM >= M) return;
+    const int i0 = mt * TM, j0 = nt * TNB;
+    // DMA roles.  One instruction = 64 pieces = 64 / NP rows of NP pieces; lane l writes LDS slot l of the group and reads the genes the swizzle
+    // puts there (piece p of row r holds the genes of piece p ^ (r & min(NP, 16) - 1): a fragment read - 16 rows, one piece each - then takes
+    // different bank groups in every 8-lane phase).  A wave covers its TM / 4 rows of A and its 16 rows of B.
+    constexpr int RIA = 64 / NPA, UA = (TM / 4) / RIA;                // rows per A instruction, A instructions per wave
+    constexpr int RIB = 64 / NPB > 0 ? 64 / NPB : 1, LPB = NPB > 64 ? 64 : NPB;
+    static_assert(NPB <= 32, "B rows of at most 512 bytes");
+    constexpr int UB = 16 / RIB;                                      // B instructions per wave
+    constexpr int SWA = NPA - 1, SWB = (NPB > 16 ? 16 : NPB) - 1;    // swizzle masks
+    const TA *srcA[UA];
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+        const int r = wave * (TM / 4) + u * RIA + lane / NPA;
+        srcA[u] = A + (int64_t)min(i0 + r, M - 1) * lda + PGA * ((lane % NPA) ^ (r & SWA));
+    }
+    const TB *srcB[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+        const int r = wave * 16 + u * RIB + lane / LPB;
+        srcB[u] = B + (int64_t)min(j0 + r, N - 1) * ldb + PGB * ((lane % LPB) ^ (r & SWB));
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    auto dma = [&](char *base, int g0) {
+#pragma unroll
+        for (int u = 0; u < UA; ++u)
+            __builtin_amdgcn_global_load_lds((glb_void *)(srcA[u] + g0), (lds_void *)(base + (wave * (TM / 4) + u * RIA) * ROWB_A), 16, 0, 0);
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+            __builtin_amdgcn_global_load_lds((glb_void *)(srcB[u] + g0), (lds_void *)(base + TM * ROWB_A + (wave * 16 + u * RIB) * ROWB_B), 16, 0, 0);
+    };
+    const int wm = wave >> 1, wn = wave & 1;
+    const int wi = wm * (TM / 2), wj = wn * 32;
+    v4d_t acc[XT][2];
+#pragma unroll
+    for (int x = 0; x < XT; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = v4d_t{0.0, 0.0, 0.0, 0.0};
+    const int lrow = lane >> 4, lcol = lane & 15;
+    // one slab: slab s + NST - 1 streams into `ahead` (free since the barrier that ended slab s - 1) while the matrix instructions read `cur`
+    auto slab = [&](const char *cur, char *ahead, int g0) {
+        const bool more = g0 + (NST - 1) * KSL < K;
+        if (more) dma(ahead, g0 + (NST - 1) * KSL);
+        __builtin_amdgcn_sched_barrier(0);
+        const char *as = cur, *bs = cur + TM * ROWB_A;
+#pragma unroll
+        for (int kk2 = 0; kk2 < NPA / 4; ++kk2) {                      // lane group lrow reads A piece 4 kk2 + lrow and the B pieces beside it
+            struct alignas(16) PA { TA v[PGA]; };
+            struct alignas(16) PB { TB v[PGB]; };
+            PA a[XT];
+            PB b[2][NB];
+            const int pa = kk2 * 4 + lrow;
+#pragma unroll
+            for (int x = 0; x < XT; ++x) a[x] = *reinterpret_cast<const PA *>(as + (wi + x * 16 + lcol) * ROWB_A + ((pa ^ (lcol & SWA)) * 16));
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int h = 0; h < NB; ++h)
+                    b[y][h] = *reinterpret_cast<const PB *>(bs + (wj + y * 16 + lcol) * ROWB_B + (((pa * NB + h) ^ (lcol & SWB)) * 16));
+#pragma unroll
+            for (int j = 0; j < PGA; ++j) {
+                double aj[XT], bj[2];
+#pragma unroll
+                for (int x = 0; x < XT; ++x) aj[x] = (double)a[x].v[j];
+#pragma unroll
+                for (int y = 0; y < 2; ++y) bj[y] = (double)b[y][j / PGB].v[j % PGB];
+#pragma unroll
+                for (int x = 0; x < XT; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(aj[x], bj[y], acc[x][y], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // this wave's pieces of slab s + 1 have landed (requested before those of the later slabs, and loads retire in order)
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (UA + UB)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    dma(buf0, 0);
+    if (NST == 3 && KSL < K) dma(buf1, KSL);
+    if (NST == 3 && KSL < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UA + UB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if constexpr (NST == 3) {
+        for (int g0 = 0; g0 < K; g0 += 3 * KSL) {
+            slab(buf0, buf2, g0);
+            if (g0 + KSL < K) slab(buf1, buf0, g0 + KSL);
+            if (g0 + 2 * KSL < K) slab(buf2, buf1, g0 + 2 * KSL);
+        }
+    } else {
+        for (int g0 = 0; g0 < K; g0 += 2 * KSL) {
+            slab(buf0, buf1, g0);
+            if (g0 + KSL < K) slab(buf1, buf0, g0 + KSL);
+        }
+    }
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+        const int j = j0 + wj + y * 16 + lcol;
+        const double ccj = (cc && j < N) ? cc[j] : 0.0;
+#pragma unroll
+        for (int x = 0; x < XT; ++x)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + wi + x * 16 + lrow + 4 * r;
+                if (i < M && j < N) out[(int64_t)i * ldo + j] = acc[x][y][r] - (rc ? rc[i] : 0.0) - ccj + c0;
+            }
+    }
+}
+
 }  // namespace vcy
 
 using namespace vcy;
@@ -878,6 +1027,52 @@ extern "C" int vcy_gram_tn(const void *X, const double *mean, const double *Y, d
     hipStream_t st = as_stream(stream);
     if (dtype == VCY_F32) return launch_gram<float, double, false>(X, Y, mean, nullptr, out, workspace, C, G, L, ld, ldy, ldo, st);
     return launch_gram<double, double, false>(X, Y, mean, nullptr, out, workspace, C, G, L, ld, ldy, ldo, st);
+}
+
+/* out (M, ldo) fp64 = A B^T - rc 1^T - 1 cc^T + c0 over K genes; see k_gemm_nt_dma */
+extern "C" int vcy_gemm_nt(const void *A, const void *B, const double *row_corr, const double *col_corr, double c0, double *out, int64_t M, int64_t N,
+                           int64_t K, int64_t lda, int64_t ldb, int64_t ldo, int dtype_a, int dtype_b, vcy_stream stream)
+{
+    VCY_REQUIRE(A && B && out, "gemm_nt: null pointer");
+    VCY_REQUIRE(M > 0 && N > 0 && K > 0 && ldo >= N, "gemm_nt: bad shape");
+    VCY_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), "gemm_nt: dimension too large");
+    VCY_REQUIRE((dtype_a == VCY_F32 || dtype_a == VCY_F64) && (dtype_b == dtype_a || dtype_b == VCY_F64), "gemm_nt: A is f32 or f64, B of A's type or f64");
+    const int64_t ksl = dtype_a == VCY_F32 ? 32 : 16;                 // genes per slab
+    const int64_t kpad = (K + ksl - 1) / ksl * ksl;
+    VCY_REQUIRE(lda >= kpad && ldb >= kpad, "gemm_nt: both row pitches must hold whole slabs of 16 (f64 A) / 32 (f32 A) genes, zero beyond K");
+    VCY_REQUIRE(lda % (dtype_a == VCY_F32 ? 4 : 2) == 0 && ldb % (dtype_b == VCY_F32 ? 4 : 2) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0,
+                "gemm_nt: rows must be 16-byte aligned");
+    // the tile shapes of k_gemm_nt_dma: rows of A per workgroup x bytes of a slab row x LDS buffers
+    const int64_t ksl2 = 2 * ksl;
+    const bool wide_ok = lda >= (K + ksl2 - 1) / ksl2 * ksl2 && ldb >= (K + ksl2 - 1) / ksl2 * ksl2;
+    const int shape = env_int("VCY_GEMM_NT_SHAPE", -1);            // (A/B: 0 = 128 rows x 128 B x 2 buffers, 1 = 64 x 128 x 3, 2 = 64 x 256 x 2, 3 = 64 x 256 x 3)
+    // measured at 50 000 x 30 000 (profiles/r06_pca_products.txt): a 50-column block 4.6 / 4.7 / 4.8 / 5.0 ms in shapes 0 / 1 / 2 / 3 (f64 rows; f32 rows
+    // 4.1 / 4.1 / 4.6 / 4.6) - 2.6 TB/s of A, twice the issue time of its matrix instructions, whatever the tile: shape 0; two columns of tiles (100
+    // columns) 8.9 / 7.6 / 7.9 / 7.9: shape 1
+    const int pick = shape >= 0 ? shape : ((N > 64 && N <= 128) ? 1 : 0);
+    VCY_REQUIRE(pick <= 1 || wide_ok, "gemm_nt: VCY_GEMM_NT_SHAPE asks for 256-byte slab rows the pitches do not hold");
+    const int tm = pick == 0 ? 128 : 64;
+    const int64_t ntm = (M + tm - 1) / tm, ntn = (N + 63) / 64;
+    const int64_t blocks = (ntm * ntn + 7) / 8 * 8;
+    VCY_REQUIRE(blocks < (1LL << 31), "gemm_nt: grid too large");
+    hipStream_t st = as_stream(stream);
+#define VCY_GNT_L(TA, TB, TM_, NPA_, NST_)                                                                                                 \
+    hipLaunchKernelGGL((k_gemm_nt_dma<TA, TB, TM_, NPA_, NST_>), dim3((unsigned)blocks), dim3(GM_THREADS), 0, st, (const TA *)A, (const TB *)B, row_corr, \
+                       col_corr, c0, out, (int)M, (int)N, (int)K, lda, ldb, ldo, (int)ntn)
+#define VCY_GNT(TA, TB)                                                                                                                    \
+    do {                                                                                                                                   \
+        if (pick == 0) VCY_GNT_L(TA, TB, 128, 8, 2);                                                                                       \
+        else if (pick == 1) VCY_GNT_L(TA, TB, 64, 8, 3);                                                                                   \
+        else if (pick == 2) VCY_GNT_L(TA, TB, 64, 16, 2);                                                                                  \
+        else VCY_GNT_L(TA, TB, 64, 16, 3);                                                                                                 \
+    } while (0)
+    if (dtype_a == VCY_F64) VCY_GNT(double, double);
+    else if (dtype_b == VCY_F64) VCY_GNT(float, double);
+    else VCY_GNT(float, float);
+#undef VCY_GNT_L
+#undef VCY_GNT
+    VCY_LAUNCH_CHECK();
+    return VCY_OK;
 }
 
 // workspace of the linear all-pairs variant: five f64 sums per cell, then the repair flags - one uint16 per output row and 16 columns

@@ -1251,6 +1251,39 @@ def gram_tn(X: CellMatrix, mean: Optional[torch.Tensor], Y: torch.Tensor) -> tor
     return out
 
 
+def _gene_rows(B: torch.Tensor, G: int, ld: int, dtype=torch.float64) -> torch.Tensor:
+    """(N, G) rows over the genes -> the zero-padded (N, ld) operand of gemm_nt."""
+    out = torch.zeros((int(B.shape[0]), ld), dtype=dtype, device=B.device)
+    out[:, :G] = B
+    return out
+
+
+def gemm_nt(X: CellMatrix, B, row_corr: Optional[torch.Tensor] = None, col_corr: Optional[torch.Tensor] = None, c0: float = 0.0,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[i, j] = sum_g X[i, g] B[j, g] - row_corr[i] - col_corr[j] + c0 in fp64 on the f64 matrix cores (vcy_gemm_nt): the products of
+    perform_PCA that contract over the genes - X is read as stored (f32 / f64 rows, no fp64 copies), centring enters through the corrections.
+    B: a (N, G) fp64 tensor of gene rows (components, a transposed thin block, the mean) - padded here - or a CellMatrix over the same genes
+    (the cells' Gram matrix X X^T)."""
+    dev = X.t.device
+    assert X.ld % (32 if X.dtype == torch.float32 else 16) == 0, "the cells-major layout pads rows to 64 elements"
+    if isinstance(B, CellMatrix):               # rows over the same genes: X itself (the cells' Gram matrix) or an fp64 block (CellMatrix.from_genes_major(Z))
+        assert B.G == X.G and B.ld >= X.ld and (B.dtype == X.dtype or B.dtype == torch.float64)
+        Bt, N, code_b = B.t, B.C, B.code
+    else:
+        assert B.dim() == 2 and B.shape[1] == X.G
+        Bt = _gene_rows(B.to(device=dev, dtype=torch.float64), X.G, X.ld)
+        N, code_b = int(B.shape[0]), _DT[torch.float64]
+    if out is None:
+        out = torch.empty((X.C, N), dtype=torch.float64, device=dev)
+    assert out.dtype == torch.float64 and out.shape == (X.C, N) and out.stride(1) == 1
+    rc = None if row_corr is None else row_corr.to(device=dev, dtype=torch.float64).contiguous()
+    cc = None if col_corr is None else col_corr.to(device=dev, dtype=torch.float64).contiguous()
+    assert (rc is None or rc.numel() == X.C) and (cc is None or cc.numel() == N)
+    _lib.check(_lib.lib().vcy_gemm_nt(X.t.data_ptr(), Bt.data_ptr(), _p(rc), _p(cc), float(c0), out.data_ptr(), X.C, N, X.G, X.ld, int(Bt.shape[1]),
+                                      int(out.stride(0)), X.code, code_b, _stream()), "gemm_nt")
+    return out
+
+
 def svr_fit(x, t, C: float = 1.0, epsilon: float = 0.1, gamma: float = 1.0, tol: float = 1e-3, max_iter: int = -1):
     """epsilon-SVR (RBF kernel, scalar inputs) fitted on the device: (coef (n) = alpha - alpha*, intercept (1), info (4) int32 =
     [SMO steps, converged, barrier failed, workgroups]).  The fit sklearn.svm.SVR(C, epsilon, gamma, tol).fit(x[:, None], t) does

@@ -7,8 +7,9 @@ What runs where:
     expressing cells / winsorised moments (``vcy_gene_stats``), per-gene percentiles (``vcy_gene_quantiles``), per-cell
     totals (``vcy_row_sums``), scaling and log (``vcy_scale_log``);
   * gene / cell subsetting and the per-cell rescalings are index / broadcast plumbing on the device tensors;
-  * PCA is the covariance route on the device in fp64 (Gram matrix by blocked GEMM, symmetric eigensolver), identical
-    to scikit-learn's ``PCA`` up to rounding, with scikit-learn's sign convention;
+  * PCA is the covariance route on the device in fp64, identical to scikit-learn's ``PCA`` up to rounding, with scikit-learn's
+    sign convention: every product with a (cells x genes) operand is a hand-written f64 matrix-core kernel of csrc/gram.hip (vcy_gram,
+    vcy_gram_tn, vcy_gemm_nt - the matrix is read as stored, centring is algebra), the small eigensolvers / QR are library calls;
   * the SVR noise models of score_cv_vs_mean (one point per gene) and adjust_totS_totU (one point per cell), which the
     reference delegates to scikit-learn / libsvm, are fitted by the same SMO iteration on the device (``DeviceSVR`` ->
     ``vcy_svr_rbf_fit``: 0.5-0.7 s at 50 000 points against about a minute for libsvm); t-SNE stays with scikit-learn.
@@ -113,17 +114,17 @@ class DevicePCA:
             w, V = torch.linalg.eigh(gram)
             w, V = w.flip(0).clamp_(min=0.0), V.flip(1)                  # descending
             comps = V[:, :k].T.contiguous()                               # (k, G)
-        else:           # fewer cells than genes: eigenvectors of the (C x C) Gram matrix of the cells, mapped back
-            A = X.t[:, :G].double() - mean
-            w, Uc = torch.linalg.eigh(A @ A.T)
+        else:           # fewer cells than genes: eigenvectors of the (C x C) Gram matrix of the cells, mapped back.  Both products on the
+            #             f64 matrix cores, X read as stored: (X - m)(X - m)^T = X X^T - a 1^T - 1 a^T + m.m with a = X m (vcy_gemm_nt), and
+            #             the map back (X - m)^T U_k is the contraction over the cells of the subspace pass (vcy_gram_tn)
+            a = ops.gemm_nt(X, mean[None, :])[:, 0].contiguous()
+            w, Uc = torch.linalg.eigh(ops.gemm_nt(X, X, row_corr=a, col_corr=a, c0=float(mean @ mean)))
             w, Uc = w.flip(0).clamp_(min=0.0), Uc.flip(1)
-            comps = (Uc[:, :k].T @ A) / torch.sqrt(w[:k]).clamp(min=1e-300)[:, None]
+            comps = ops.gram_tn(X, mean, Uc[:, :k].contiguous()).T / torch.sqrt(w[:k]).clamp(min=1e-300)[:, None]
         # sklearn.utils.extmath.svd_flip(u_based_decision=False): the largest-|.| loading of every component is positive
         idx = comps.abs().argmax(1)
         comps = comps * torch.sign(comps[torch.arange(k, device=dev), idx])[:, None]
-        pcs = torch.empty((C, k), dtype=torch.float64, device=dev)
-        for s in range(0, C, block):
-            pcs[s:s + block] = (X.t[s:s + block, :G].double() - mean) @ comps.T
+        pcs = ops.gemm_nt(X, comps, col_corr=(comps * mean).sum(1))     # (X - mean) comps^T = X comps^T - 1 (comps mean)
         total_var = float(w.sum()) / (C - 1)
         self.components_ = comps.cpu().numpy()
         self.explained_variance_ = (w[:k] / (C - 1)).cpu().numpy()
@@ -138,29 +139,26 @@ class DevicePCA:
     def _fit_subspace(self, X: CellMatrix, k: int, block: int) -> np.ndarray:
         """Leading k principal components by blocked subspace iteration on the centred matrix A = X - mean (never formed):
         Z <- orth(A^T (A Z)) on a G x (k + 20) block until the Ritz values stop moving (relative `tol`), then Rayleigh-Ritz.
-        Every pass is two streams over X with fp64 GEMMs (plain library GEMMs: the one dense contraction next to the path);
+        Every pass is two streams over X on the f64 matrix cores - the projection over the genes (vcy_gemm_nt) and the contraction
+        over the cells (vcy_gram_tn), X read as stored both times; the small (k + 20)-wide QR / eigenproblems are library calls;
         memory O((C + G) (k + 20)).  Deterministic (seeded start), converged rather than truncated, so the leading
         components agree with the exact route to the tolerance whenever the spectrum has a gap behind them."""
         C, G = X.C, X.G
         dev = X.t.device
         l = min(min(C, G), k + 20)
-        mean = torch.zeros(G, dtype=torch.float64, device=dev)
-        ssq = torch.zeros((), dtype=torch.float64, device=dev)
-        for s in range(0, C, block):
-            b = X.t[s:s + block, :G].double()
-            mean += b.sum(0)
-            ssq += (b * b).sum()
-        mean /= C
-        total_var = float((ssq - C * (mean * mean).sum()) / (C - 1))            # trace of the covariance
+        st = ops.gene_stats(X)                                                  # per-gene sum of squares over the cells (vcy_gene_stats, fp64)
+        mean = ops.col_means(X)
+        total_var = float((st[1].sum() - C * (mean * mean).sum()) / (C - 1))    # trace of the covariance
+        ldy = l + (l % 2)                                                       # (vcy_gram_tn wants 16-byte aligned rows of Y)
+        Ybuf = torch.zeros((C, ldy), dtype=torch.float64, device=dev)
 
         def AtA(Z):                                                             # A^T (A Z), A centred
-            # Y = A Z (C x l): a thin projection, library GEMM per block of cells; A^T Y (G x l): the contraction over the cells
-            # on the f64 matrix cores with the centring folded into the staging (vcy_gram_tn)
-            mz = mean @ Z
-            Y = torch.empty((C, Z.shape[1]), dtype=torch.float64, device=dev)
-            for s in range(0, C, block):
-                Y[s:s + block] = X.t[s:s + block, :G].double() @ Z - mz
-            return ops.gram_tn(X, mean, Y)
+            # Y = A Z (C x l) = X Z - 1 (mean Z): the thin projection over the genes (vcy_gemm_nt), X read as stored; A^T Y (G x l): the
+            # contraction over the cells with the centring folded into the fragment read (vcy_gram_tn) - both on the f64 matrix cores
+            # (the block transposed to rows over the genes by the layout's own transpose kernel; mean Z as a column sum - the library's
+            #  gemv takes 4.9 ms for this 30 000 x 50 product, more than the projection itself)
+            ops.gemm_nt(X, CellMatrix.from_genes_major(Z, torch.float64), col_corr=(Z * mean[:, None]).sum(0), out=Ybuf[:, :Z.shape[1]])
+            return ops.gram_tn(X, mean, Ybuf) if ldy == Z.shape[1] else ops.gram_tn(X, mean, Ybuf)[:, :Z.shape[1]]
         gen = torch.Generator(device=dev).manual_seed(int(self.random_state))
         Z = torch.linalg.qr(torch.randn((G, l), generator=gen, device=dev, dtype=torch.float64))[0]
         prev = None
@@ -185,9 +183,7 @@ class DevicePCA:
         comps = (Z @ V[:, :k]).T.contiguous()                                   # (k, G)
         idx = comps.abs().argmax(1)
         comps = comps * torch.sign(comps[torch.arange(k, device=dev), idx])[:, None]     # sklearn's svd_flip
-        pcs = torch.empty((C, k), dtype=torch.float64, device=dev)
-        for s in range(0, C, block):
-            pcs[s:s + block] = (X.t[s:s + block, :G].double() - mean) @ comps.T
+        pcs = ops.gemm_nt(X, comps, col_corr=(comps * mean).sum(1))
         self.components_ = comps.cpu().numpy()
         self.explained_variance_ = (w[:k] / (C - 1)).cpu().numpy()
         self.explained_variance_ratio_ = self.explained_variance_ / total_var
