@@ -1241,6 +1241,53 @@ def test_f64_sqrt_element_accuracy_and_domain(ops, oracle):
     ops.coldeltacor_partial(E, Dm, ixs, ops.LINEAR, ops.RULES_PARTIAL, 0.0)                  # other transforms have no such limit
 
 
+def test_f64_exp2_element_accuracy(ops):
+    """The fp64 Gauss-transform element of run_markov (csrc/misc.hip exp2_neg_tab: 2^(-d2) = 2^i T[j] 2^r from a 64-entry table and a
+    degree-5 polynomial, 10 f64 instructions where the degree-13 form took 17) against numpy's exp2, element by element, through the real
+    step kernels: one source cell at the origin with weight 1, targets at distance sqrt(d2) - y[j] = coef 2^(-d2_j) and nothing else.
+    Within 1 ulp of exp2 plus the one rounding of the product with coef over [0, 1000]; beyond the clamp the value is below 1e-300
+    (the reference's exp() is 0 there: both vanish from any sum); both the plain and the culled transform."""
+    dev = ops.require_gpu()
+    L = ops._lib.lib()
+    rng = np.random.default_rng(12)
+    n = 1 << 15
+    d2 = np.concatenate([[0.0, 1e-300, 2.0 ** -60, 1.0 / 64, 1.0, 1000.0, 1e-9], rng.uniform(0, 40, n // 2), 10.0 ** rng.uniform(-12, 3, n - n // 2 - 9), [1001.0, 5e4]])
+    assert d2.size == n
+    es = np.sqrt(d2)
+    d2 = es * es                                            # the kernel's own argument: fl(df * df), df = es_j - 0
+    es[0] = 0.0                                             # cell 0 is the source
+    sigma_W = 0.7
+    coef = 0.2 / np.sqrt(2.0 * np.pi * sigma_W * sigma_W)
+    x = torch.zeros(n, dtype=torch.float64, device=dev)
+    x[0] = 1.0
+    ones = torch.ones(n, dtype=torch.float64, device=dev)
+    colptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)               # no sparse part
+    rowidx = torch.zeros(1, dtype=torch.int32, device=dev)
+    scsc = torch.zeros(1, dtype=torch.float64, device=dev)
+    es_t = torch.from_numpy(es.reshape(n, 1).copy()).to(dev)
+    ws = torch.empty(int(L.vcy_markov_factored_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+    y = torch.zeros(n, dtype=torch.float64, device=dev)
+    ops._lib.check(L.vcy_diffuse_step_factored(x.data_ptr(), y.data_ptr(), None, colptr.data_ptr(), rowidx.data_ptr(), scsc.data_ptr(), ones.data_ptr(), ones.data_ptr(),
+                                               es_t.data_ptr(), 1, sigma_W, ws.data_ptr(), n, 0, ops.F64, ops._stream()), "diffuse_step_factored")
+    got = y.cpu().numpy()
+    want = coef * np.exp2(-d2)
+    inside = d2 <= 1000.0
+    ulp = np.spacing(want[inside])
+    err = np.abs(got[inside] - want[inside]) / ulp
+    assert err.max() <= 2.0, (err.max(), d2[inside][np.argmax(err)])        # 1 ulp of the element + the rounding of coef * e + numpy's own
+    assert np.mean(err > 1.0) < 0.02
+    assert np.all(got[~inside] < 1e-300) and np.all(got[~inside] >= 0)
+    assert got[0] == coef                                                   # 2^0 exactly
+    # a NaN coordinate: the cell's own normalisation is NaN in a real chain (kw sums the same distances) - with kw given as NaN here every
+    # target the cell reaches is NaN, as in the dense chain
+    kw = ones.clone()
+    kw[0] = float("nan")
+    y2 = torch.zeros(n, dtype=torch.float64, device=dev)
+    ops._lib.check(L.vcy_diffuse_step_factored(x.data_ptr(), y2.data_ptr(), None, colptr.data_ptr(), rowidx.data_ptr(), scsc.data_ptr(), ones.data_ptr(), kw.data_ptr(),
+                                               es_t.data_ptr(), 1, sigma_W, ws.data_ptr(), n, 0, ops.F64, ops._stream()), "diffuse_step_factored")
+    assert bool(torch.isnan(y2).all())
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 @pytest.mark.parametrize("C,G,n", [(9, 70, 3), (100, 1003, 17), (333, 4100, 64), (70, 515, 256)])
 def test_embedding_scaling_against_the_two_step_route(ops, dtype, C, G, n):

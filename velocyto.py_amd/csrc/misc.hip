@@ -476,32 +476,58 @@ __global__ void k_markov_scale_x(const double *__restrict__ x, const double *__r
 }
 
 __device__ __forceinline__ float exp2_neg(float d2) { return __builtin_amdgcn_exp2f(-d2); }
-// f64: 2^(-d2) for d2 >= 0 without the library's general exp2 (range checks, denormal paths, a table: ~45 instructions).  -d2 = k + r
-// with k = rint(-d2) and r in [-1/2, 1/2] (exact), 2^r = exp(r ln 2) by the degree-13 Taylor polynomial (truncation 4e-18 at
-// |r ln 2| <= 0.347; within 1 ulp of exp2() over [0, 1100], checked against numpy), scaled by v_ldexp_f64: 17 f64 instructions.
-// Arguments beyond 1100 give 0 like exp2 does (2^-1100 is below the smallest denormal).  The Markov step of the f64 facade spends its
-// time here: 0.76 -> 0.5 ms per step at 50 000 cells.
-__device__ __forceinline__ double exp2_neg(double d2)
+// f64: 2^(-d2) for d2 >= 0 without the library's general exp2 (range checks, denormal paths: ~45 instructions).
+// Round 4-5 form (tools/experiments/r06_exp2_poly13.patch keeps it for A/B): -d2 = k + r with k = rint(-d2), 2^r by the degree-13 Taylor
+// polynomial of exp(r ln 2) on |r| <= 1/2, scaled by v_ldexp_f64 - 17 f64 instructions, 17 of the 22 of a (target, source) pair.
+// Round 6 form (exp2_neg_tab): -d2 = (64 i + j) / 64 + r with |r| <= 2^-7,
+//     2^(-d2) = 2^i  x  T[j]  x  2^r,        T[j] = 2^(j / 64) correctly rounded (64 doubles in LDS: entry j sits in bank pair j, so the 64
+//                                            lanes of a read hit different banks or the same word - never a conflict),
+//     2^r - 1 = r (c1 + r (c2 + r (c3 + r (c4 + r c5))))    Taylor of exp(r ln 2), truncation 3.5e-17 at |r| = 2^-7,
+// the integer 64 i + j read out of the low word of fma(x, 64, 1.5 x 2^52) (no v_rndne, no conversion), 2^i applied by v_ldexp_f64 (the argument is
+// clamped to -1000: below 2^-1000 the reference's exp() has long underflowed any sum it could enter): fmax, fma, sub, fma, four fma + a
+// multiply, fma, ldexp = 11 f64 instructions and three 32-bit ones (22 % off a step of the full transform, 2.00 -> 1.56 ms at 50 000 cells), within
+// 1 ulp of exp2() (tests/test_gpu_ops.py::test_f64_exp2_element_accuracy).  A NaN distance (a NaN or infinite coordinate) is dropped by the
+// clamp - and does not need to survive it: such a cell's own normalisation kw[c] is NaN (it sums the same distances), so u[c] is NaN and
+// fma(u[c], finite, .) poisons every target exactly as the dense chain does.
+__constant__ double c_exp2_tab[64] = {                               // 2^(j / 64), j = 0 .. 63, correctly rounded (50-digit decimal arithmetic)
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0,
+};
+// (the table sits in LDS: every kernel that evaluates exp2_neg_tab fills it - 64 threads - before its first barrier)
+__device__ __forceinline__ double exp2_neg_tab(double d2, const double *__restrict__ T)
 {
-    const double x = (d2 != d2) ? d2 : fmax(-d2, -1100.0);         // (fmax drops a NaN: a NaN distance stays NaN, as in the f32 form and in exp2())
-    const double kf = rint(x);
-    const double r = x - kf;
-    double p = 1.3691488853904124e-12;                              // ln2^13 / 13!
-    p = fma(p, r, 2.5678435993488196e-11);
-    p = fma(p, r, 4.44553827187081e-10);
-    p = fma(p, r, 7.054911620801121e-09);
-    p = fma(p, r, 1.0178086009239696e-07);
-    p = fma(p, r, 1.3215486790144305e-06);
-    p = fma(p, r, 1.5252733804059838e-05);
-    p = fma(p, r, 0.00015403530393381606);
-    p = fma(p, r, 0.0013333558146428441);
-    p = fma(p, r, 0.009618129107628477);
-    p = fma(p, r, 0.055504108664821576);
-    p = fma(p, r, 0.2402265069591007);
-    p = fma(p, r, 0.6931471805599453);
-    p = fma(p, r, 1.0);
-    return ldexp(p, (int)kf);
+    constexpr double MAGIC = 6755399441055744.0;                    // 1.5 x 2^52: the low word of x 64 + MAGIC is rint(64 x) in two's complement
+    const double x = fmax(-d2, -1000.0);
+    const double s = fma(x, 64.0, MAGIC);
+    const int k = __double2loint(s);                                // 64 i + j
+    const double r = fma(s - MAGIC, -0.015625, x);                  // exact, |r| <= 2^-7
+    double q = 0.0013333558146428443;                               // ln2^5 / 5!
+    q = fma(q, r, 0.009618129107628477);
+    q = fma(q, r, 0.05550410866482158);
+    q = fma(q, r, 0.2402265069591007);
+    q = fma(q, r, 0.6931471805599453);
+    q *= r;                                                         // 2^r - 1
+    const double t = T[k & 63];
+    const double w = fma(t, q, t);                                  // 2^(j / 64 + r) in [0.99, 2.02)
+    return ldexp(w, k >> 6);                                        // (one v_ldexp_f64: the integer add on the exponent field cost two moves beside it)
 }
+template <typename CT> __device__ __forceinline__ CT exp2_neg_any(CT d2, const double *T);
+template <> __device__ __forceinline__ float exp2_neg_any<float>(float d2, const double *) { return exp2_neg(d2); }
+template <> __device__ __forceinline__ double exp2_neg_any<double>(double d2, const double *T) { return exp2_neg_tab(d2, T); }
 
 // The sparse half of a step, y[j] = sum_p scsc[p] v[rowidx[p]] over column j (k_vecmat_csc), riding in the Gauss-transform launch: the two
 // halves are independent, and a loop of thousands of steps is bound by the number of launches as soon as the kernels are small
@@ -530,7 +556,12 @@ template <typename CT, int EDIM, int JPT>
 __global__ __launch_bounds__(256) void k_gauss_transform(const CT *__restrict__ es, const CT *__restrict__ u, double *__restrict__ part, int n,
                                                           int nparts, SparseHalf sp)
 {
+    __shared__ double s_tab[64];
     if ((int)blockIdx.y < sp.rows) { sparse_half(sp); return; }
+    if (sizeof(CT) == 8) {                                      // the fp64 instance's table of 2^(j / 64) (exp2_neg_tab)
+        if (threadIdx.x < 64) s_tab[threadIdx.x] = c_exp2_tab[threadIdx.x];
+        __syncthreads();
+    }
     const int by = (int)blockIdx.y - sp.rows;
     const int j0 = blockIdx.x * 256 * JPT + threadIdx.x;
     CT ej[JPT][EDIM];
@@ -555,7 +586,7 @@ __global__ __launch_bounds__(256) void k_gauss_transform(const CT *__restrict__ 
             CT d2 = CT(0);
 #pragma unroll
             for (int a = 0; a < EDIM; ++a) { const CT df = ej[t][a] - ec[a]; d2 = fma(df, df, d2); }
-            fold[t] = fma(uc, exp2_neg(d2), fold[t]);
+            fold[t] = fma(uc, exp2_neg_any<CT>(d2, s_tab), fold[t]);
         }
     };
     int c = c0;
@@ -609,7 +640,9 @@ __global__ __launch_bounds__(256) void k_gauss_transform_culled(const CT *__rest
                                                                  int nparts, SparseHalf sp)
 {
     __shared__ CT red[2][EDIM][4];
+    __shared__ double s_tab[64];
     if ((int)blockIdx.y < sp.rows) { sparse_half(sp); return; }
+    if (sizeof(CT) == 8 && threadIdx.x < 64) s_tab[threadIdx.x] = c_exp2_tab[threadIdx.x];     // (published by the barrier below)
     const int by = (int)blockIdx.y - sp.rows;
     const int j0 = blockIdx.x * 256 * JPT + threadIdx.x;
     CT ej[JPT][EDIM];
@@ -653,7 +686,7 @@ __global__ __launch_bounds__(256) void k_gauss_transform_culled(const CT *__rest
             CT d2 = CT(0);
 #pragma unroll
             for (int a = 0; a < EDIM; ++a) { const CT df = ej[t][a] - ec[a]; d2 = fma(df, df, d2); }
-            fold[t] = fma(uc, exp2_neg(d2), fold[t]);
+            fold[t] = fma(uc, exp2_neg_any<CT>(d2, s_tab), fold[t]);
         }
     };
     for (int qq = qa; qq < qb; qq += 64) {
