@@ -26,7 +26,7 @@ def test_header_symbols_exported(lib):
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in velocyto_hip.h but not exported"
     assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
-    assert L.vcy_abi_version() == 3
+    assert L.vcy_abi_version() == 4
     # and the maintainer's guide names every one of them (which reference call it replaces, or what a binder needs it for)
     guide = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert not [n for n in sorted(declared) if n not in guide]
