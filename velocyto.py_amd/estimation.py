@@ -7,7 +7,7 @@ numpy arrays of the reference's dtypes.  All arithmetic runs in the gfx950 kerne
 libvelocyto_hip.so; there is no CPU path.
 
 ``threads`` is accepted and ignored (the reference's rule, estimation.py:26-30, only sizes an
-OpenMP pool).  Storage dtype: ``VELOCYTO_AMD_DTYPE`` (float32 default | float64) or ``dtype=``.
+OpenMP pool).  Storage dtype: ``VELOCYTO_AMD_DTYPE`` (float64 default: the reference's arithmetic | float32: production mode) or ``dtype=``.
 """
 from __future__ import annotations
 
