@@ -316,7 +316,7 @@ def test_gram_kernel_identity_probe():
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
-@pytest.mark.parametrize("C,G,N", [(5, 3, 1), (130, 17, 7), (300, 65, 64), (1000, 257, 50), (700, 1153, 130), (257, 96, 257)])
+@pytest.mark.parametrize("C,G,N", [(5, 3, 1), (130, 17, 7), (300, 65, 64), (1000, 257, 50), (900, 515, 100), (700, 1153, 130), (257, 96, 257)])
 def test_gemm_nt_kernel_against_the_library_gemm(dtype, C, G, N):
     """vcy_gemm_nt (csrc/gram.hip, v_mfma_f64_16x16x4_f64, slabs DMA'd into LDS): the products of perform_PCA that contract over the
     genes (analysis.py:678-702 through sklearn's PCA: projection on a thin block, `transform`, the cells' Gram matrix), against torch's
