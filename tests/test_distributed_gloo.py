@@ -246,3 +246,38 @@ def test_collective_self_check(world, inject):
             assert (res[name] != "ok") == (rank == int(bad_rank))              # only that rank saw it fail ...
             assert res["agreed"][name] is False                                # ... every rank knows
             assert all(ok for n, ok in res["agreed"].items() if n != name)
+
+
+def _disagree_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), VCY_SELF_CHECK_FITS="0,3,5")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import velocyto_amd
+        from velocyto_amd import distributed as D
+        res = D.self_check(torch.device("cpu"))
+        m = D.all_reduce_max(torch.tensor([float(rank) * 1.5], dtype=torch.float64))
+        q.put((rank, res, float(m)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_self_check_row_width_is_a_collective_decision():
+    """The halo-size check picks its row width (30 016 fp64 columns when the device has room, 4 fp32 otherwise) from a LOCAL fact - free
+    memory.  Ranks that disagreed would enter all_to_all_single with different element sizes (a hang or corruption on RCCL): the choice is
+    all-reduced (MIN).  Here three of eight ranks claim the wide buffers fit; every rank must run the narrow check and pass it.  Also
+    distributed.all_reduce_max, the reduction the atlas path judges its fp64 sqrt domain with before any rank raises."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_disagree_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res, m in got:
+        assert res["all_to_all_halo_sizes"] == "ok" and all(res["agreed"].values()), (rank, res)
+        assert m == 1.5 * (world - 1)

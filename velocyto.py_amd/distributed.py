@@ -418,6 +418,9 @@ def self_check(device: torch.device, group=None) -> dict:
         if ws == 8 and device.type == "cuda":
             free, _ = torch.cuda.mem_get_info(device)
             fits = 1.0 if free > 3 * (sum(recv_splits) + sum(send_splits)) * 30016 * 8 else 0.0
+        claim = os.environ.get("VCY_SELF_CHECK_FITS")            # tests: "r0,r1,..." = the ranks whose local view says the wide buffers fit
+        if claim is not None:
+            fits = 1.0 if str(rank) in claim.split(",") else 0.0
         agreed = torch.tensor([fits], dtype=torch.float64, device=device)
         if _host_staged(agreed, group):
             h = agreed.cpu()
