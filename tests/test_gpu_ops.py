@@ -1243,7 +1243,7 @@ def test_f64_sqrt_element_accuracy_and_domain(ops, oracle):
 
 def test_f64_exp2_element_accuracy(ops):
     """The fp64 Gauss-transform element of run_markov (csrc/misc.hip exp2_neg_tab: 2^(-d2) = 2^i T[j] 2^r from a 64-entry table and a
-    degree-5 polynomial, 10 f64 instructions where the degree-13 form took 17) against numpy's exp2, element by element, through the real
+    degree-5 polynomial, 11 f64 instructions where the degree-13 form took 17; exp2_neg_tab256 in the culled kernel) against numpy's exp2, element by element, through the real
     step kernels: one source cell at the origin with weight 1, targets at distance sqrt(d2) - y[j] = coef 2^(-d2_j) and nothing else.
     Within 1 ulp of exp2 plus the one rounding of the product with coef over [0, 1000]; beyond the clamp the value is below 1e-300
     (the reference's exp() is 0 there: both vanish from any sum); both the plain and the culled transform."""
@@ -1278,6 +1278,14 @@ def test_f64_exp2_element_accuracy(ops):
     assert np.mean(err > 1.0) < 0.02
     assert np.all(got[~inside] < 1e-300) and np.all(got[~inside] >= 0)
     assert got[0] == coef                                                   # 2^0 exactly
+    # the culled transform evaluates the same element from a 256-entry table and a degree-4 polynomial (exp2_neg_tab256): same bar, with a cut so
+    # wide that no source run is skipped
+    fac = ops.MarkovFactors(None, es_t, 1.0, sigma_W, colptr, rowidx, scsc, ones, ones, es_t, torch.float64).enable_culling(cut=1e12)
+    gc, _ = ops.diffuse(x, fac, 1, accumulate=False)
+    gc = gc.cpu().numpy()
+    errc = np.abs(gc[inside] - want[inside]) / ulp
+    assert errc.max() <= 2.0 and np.mean(errc > 1.0) < 0.02, (errc.max(), d2[inside][np.argmax(errc)])
+    assert np.all(gc[~inside] < 1e-300) and np.all(gc[~inside] >= 0) and gc[0] == coef
     # a NaN coordinate: the cell's own normalisation is NaN in a real chain (kw sums the same distances) - with kw given as NaN here every
     # target the cell reaches is NaN, as in the dense chain
     kw = ones.clone()
