@@ -40,6 +40,14 @@ for r0 in range(0, C, 2000):
 raw = ops.CellMatrix(torch.rand((C, ops.padded_ld(G)), device=dev, dtype=torch.float64), G)
 raw.t[:, G:] = 0
 t_raw = best(lambda: ops.coldeltacor_full(raw, d, ops.LINEAR, rm=rm, validate=False))
+# accuracy at scale on the pooled matrices: the matrix-core route (with its repair launch) against the element-wise kernel (raw fp64 moments of the differences)
+mm = ops.coldeltacor_full(Sx, d, ops.LINEAR, validate=False)
+ops.FULL_LINEAR_MFMA = False
+ew = ops.coldeltacor_full(Sx, d, ops.LINEAR, validate=False)
+ops.FULL_LINEAR_MFMA = True
+both = torch.isfinite(mm) & torch.isfinite(ew)
+print(f"pooled matrices, all {C * C} pairs: NaN pattern equal {bool(torch.equal(torch.isnan(mm), torch.isnan(ew)))}, max |matrix-core - element-wise| = {float((mm[both] - ew[both]).abs().max()):.2e}")
+del mm, ew
 fin = torch.isfinite(rm)
 print(f"linear all-pairs kernel, {C} cells x {G} genes, f64: pooled Sx (k = 30) {t_pooled:.1f} ms with {flagged} of {C * (C - 1)} pairs ({flagged / (C * (C - 1)):.2e}) "
       f"re-evaluated by the repair launch; random matrix (nothing flagged) {t_raw:.1f} ms")
