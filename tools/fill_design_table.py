@@ -27,8 +27,10 @@ tab = f"""<!-- R6_TABLE_BEGIN (tools/fill_design_table.py) -->
 | all-pairs linear kernel incl. its repair launch (10 000 × 20 000, `profiles/r06_full_kernels.txt`) | 120.5-121.5 ms f64 / 118 ms f32 storage = 0.84 / 0.86 of the f64 matrix peak; kNN-pooled matrices 127 ms |
 | GPU suite from the repository root | 353 passed in 332 s; `smoke()` ok against the oracle and the reference's own kernel (1.1e-15) |
 
-Box-to-box: the same binary gave stage D = 217.4 ms (206 k cells/s) on one box of this round and 229-232 ms on others at the same measured shader
-clock (2.30-2.37 GHz); `telemetry` travels with every line (this run: {pw(tel['smi_before_timed_steps'])} W / {tj(tel['smi_before_timed_steps'])} °C before, {tj(tel['smi_after_timed_steps'])} °C after the timed steps).
+Box-to-box, now with the telemetry beside it: the same binary gave stage D = 217.4 ms (206 k cells/s) on one box of this round - shader clock under
+stage D 2.37 GHz (per XCD 2.35-2.39), 841 W / 46 °C before the timed steps - and 229-232 ms on others - 2.30-2.32 GHz, 895-901 W / 48-50 °C
+(`profiles/r06_generators_two_boxes.txt` and this run: {pw(tel['smi_before_timed_steps'])} W / {tj(tel['smi_before_timed_steps'])} °C before, {tj(tel['smi_after_timed_steps'])} °C after).  The boxes that draw more power for the same work hold a 2-3 % lower clock:
+that explains about half of the 5-6 % spread; fabric and memory clocks are the same (1250 / 2000 MHz), the rest is still unexplained.
 <!-- R6_TABLE_END -->"""
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
