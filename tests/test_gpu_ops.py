@@ -222,6 +222,48 @@ def test_coldeltacor_full_linear_gemm_route(ops, oracle, dtype):
     np.testing.assert_allclose(acc[ok], got[ok] + 2.0, atol=1e-6 if dtype == "float32" else 1e-14)
 
 
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_coldeltacor_full_linear_random_degeneracies(ops, oracle, seed):
+    """Randomised shapes, row blocks and degeneracies for the matrix-core route with its repair launch: copies of cells at random noise levels
+    (1e-2 ... 1e-12, additive and multiplicative), exact duplicates, constant and nearly constant d columns, a random row block (cell0 / C_out:
+    the flag words of a block start at the block's first row) - against the oracle's restatement of speedboosted.pyx:13-87, every finite pair to
+    1e-10 in f64, NaN pattern equal."""
+    rng = np.random.default_rng(1000 + seed)
+    G = int(rng.integers(40, 1400))
+    C = int(rng.integers(20, 330))
+    e, d = rng.gamma(2.0, 1.0, (G, C)) * (rng.random((G, C)) < 0.8), rng.normal(size=(G, C))
+    for _ in range(int(rng.integers(1, 9))):
+        a, b = rng.choice(C, 2, replace=False)
+        kind = rng.integers(0, 4)
+        noise = 10.0 ** rng.uniform(-12, -2)
+        if kind == 0:
+            e[:, b] = e[:, a] + noise * rng.normal(size=G)
+        elif kind == 1:
+            e[:, b] = e[:, a] * (1.0 + noise)
+        elif kind == 2:
+            e[:, b] = e[:, a]
+        else:
+            d[:, b] = rng.choice([0.0, 2.5]) + (noise if rng.random() < 0.5 else 0.0) * rng.normal(size=G)
+    want = oracle.coldeltacor(e, d, "linear", 0.0)
+    E, D = ops.CellMatrix.from_genes_major(e, "float64"), ops.CellMatrix.from_genes_major(d, "float64")
+    got = ops.coldeltacor_full(E, D, ops.LINEAR).cpu().numpy()
+    # A nearly constant d column is ill-conditioned in the REFERENCE'S arithmetic as well: b - mean(b) carries the rounding of the mean, eps |mean| against
+    # deviations of size std(b) - two correct centred evaluations (other summation orders) differ by about eps |mean| / std.  The bar scales with it; a
+    # column that is constant up to 1e-13 of its size is noise in both and is skipped.
+    sd, mx = d.std(0), np.abs(d).max(0)
+    okrow = ~((sd > 0) & (sd <= 1e-13 * np.maximum(1.0, mx)))
+    assert np.array_equal(np.isnan(got)[okrow], np.isnan(want)[okrow])
+    tol = 1e-10 + 16 * np.finfo(np.float64).eps * mx / np.where(sd > 0, sd, 1.0)
+    fin = np.isfinite(want) & okrow[:, None]
+    assert np.all(np.abs(got - want)[fin] <= np.broadcast_to(tol[:, None], got.shape)[fin]), float(np.max((np.abs(got - want) / tol[:, None])[fin]))
+    c0 = int(rng.integers(0, C - 1))
+    n = int(rng.integers(1, C - c0 + 1))
+    blk = ops.coldeltacor_full(E, D, ops.LINEAR, cell0=c0, C_out=n).cpu().numpy()
+    assert np.array_equal(np.isnan(blk), np.isnan(got[c0:c0 + n]))
+    okb = ~np.isnan(blk)
+    np.testing.assert_allclose(blk[okb], got[c0:c0 + n][okb], atol=1e-12, rtol=0)
+
+
 def test_coldeltacor_full_linear_pooled_neighbours(ops, oracle):
     """The population the repair pass exists for: kNN-pooled cells (every cell the mean of itself and its neighbours, so neighbours
     share most of their pool) - all pairs to 1e-10 in f64 against the oracle, NaN pattern equal."""
